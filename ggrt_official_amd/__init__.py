@@ -1,0 +1,12 @@
+"""ggrt_official_amd — MI355X-native differentiable 3D-Gaussian rasterizer, drop-in for the
+``diff_gaussian_rasterization`` extension GGRt uses on its render hot path
+(reference ``ggrt/model/pixelsplat/decoder/cuda_splatting.py``).
+
+Scope: the rasterizer (forward + backward) behind a C ABI, the call-site glue
+(`render_cuda`, `render_depth_cuda`, `DecoderSplattingCUDA`), one-frame-per-GPU sharding helpers and a
+synthetic-scene generator for the benchmark.  Everything else of GGRt is out of scope.
+"""
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__version__ = "0.1.0"

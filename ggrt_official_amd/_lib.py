@@ -1,0 +1,107 @@
+"""ctypes binding of the C ABI declared in ``include/ggr_raster.h``.
+
+There is deliberately NO fallback: if ``libggr_raster.so`` is missing or does not export the
+symbols the header declares, importing the rasterizer raises.  (The CPU restatements under
+``oracle/`` are test infrastructure and are never reachable from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libggr_raster.so")
+ABI_VERSION = 1
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class GgrSettings(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32), ("sh_degree", C.c_int32),
+        ("sh_stride", C.c_int32), ("num_points", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("scale_modifier", C.c_float), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
+        ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+    ]
+
+
+class GgrForwardIn(C.Structure):
+    _fields_ = [
+        ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
+        ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+    ]
+
+
+class GgrForwardOut(C.Structure):
+    _fields_ = [
+        ("out_color", C.c_void_p), ("radii", C.c_void_p), ("out_depth", C.c_void_p), ("geom_buffer", C.c_void_p),
+        ("image_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("num_rendered", C.c_int64),
+    ]
+
+
+class GgrBackwardIn(C.Structure):
+    _fields_ = [
+        ("fwd", GgrForwardIn), ("radii", C.c_void_p), ("geom_buffer", C.c_void_p), ("image_buffer", C.c_void_p),
+        ("binning_buffer", C.c_void_p), ("num_rendered", C.c_int64), ("dL_dout_color", C.c_void_p),
+        ("dL_dout_depth", C.c_void_p), ("scratch", C.c_void_p),
+    ]
+
+
+class GgrBackwardOut(C.Structure):
+    _fields_ = [
+        ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
+        ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+        ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("dL_dviewmatrix", C.c_void_p),
+        ("dL_dprojmatrix", C.c_void_p), ("dL_dcampos", C.c_void_p),
+    ]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+# every symbol include/ggr_raster.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("ggr_abi_version", C.c_int, []),
+    ("ggr_last_error", C.c_char_p, []),
+    ("ggr_geom_bytes", C.c_size_t, [C.c_int32]),
+    ("ggr_image_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
+    ("ggr_binning_bytes", C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    ("ggr_backward_scratch_bytes", C.c_size_t, [C.c_int32]),
+    ("ggr_forward", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrForwardIn), C.POINTER(GgrForwardOut),
+                              ALLOC_FN, C.c_void_p, C.c_void_p]),
+    ("ggr_backward", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrBackwardIn), C.POINTER(GgrBackwardOut),
+                               C.c_void_p]),
+    ("ggr_mark_visible", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ggr_debug_unpack_geom", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ggr_debug_unpack_binning", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise ImportError(f"{LIB_PATH} does not export {name}")
+        fn.restype = restype
+        fn.argtypes = argtypes
+    v = lib.ggr_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {v}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ggr_last_error().decode("utf-8", "replace")

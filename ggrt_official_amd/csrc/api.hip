@@ -1,0 +1,242 @@
+// api.hip — the C-ABI of include/ggr_raster.h: orchestration of the gfx950 kernels.
+//
+// Replaces `RasterizeGaussiansCUDA` / `RasterizeGaussiansBackwardCUDA` of the extension GGRt
+// imports at reference ggrt/model/pixelsplat/decoder/cuda_splatting.py:6-9.
+// No global mutable state: the only static is a thread_local error string.
+#include "../../include/ggr_raster.h"
+#include "ggr_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(GGR_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define KCHECK(dbg, s, what)                                                                    \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ == hipSuccess && (dbg)) e_ = hipStreamSynchronize(s);                            \
+        if (e_ != hipSuccess) return fail(GGR_E_HIP, "%s: %s", what, hipGetErrorString(e_));    \
+    } while (0)
+
+int ceil_log2(uint32_t v) {
+    int b = 0;
+    while ((1ull << b) < v) b++;
+    return b;
+}
+
+int validate(const GgrSettings* st, const GgrForwardIn* in) {
+    if (!st || !in) return fail(GGR_E_INVALID, "null settings / inputs");
+    if (st->num_points < 0 || st->image_width < 0 || st->image_height < 0)
+        return fail(GGR_E_INVALID, "negative size");
+    if ((in->shs == nullptr) == (in->colors_precomp == nullptr) && st->num_points > 0)
+        return fail(GGR_E_INVALID, "Please provide excatly one of either SHs or precomputed colors!");
+    const bool has_sr = in->scales != nullptr && in->rotations != nullptr;
+    const bool any_sr = in->scales != nullptr || in->rotations != nullptr;
+    if (st->num_points > 0 && ((!has_sr && in->cov3D_precomp == nullptr) || (any_sr && in->cov3D_precomp != nullptr)))
+        return fail(GGR_E_INVALID,
+                    "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (in->shs && st->sh_stride < (st->sh_degree > 3 ? 16 : (st->sh_degree + 1) * (st->sh_degree + 1)))
+        return fail(GGR_E_INVALID, "sh_stride %d too small for sh_degree %d", st->sh_stride, st->sh_degree);
+    const int64_t tiles = (int64_t)((st->image_width + GGR_TILE - 1) / GGR_TILE) * ((st->image_height + GGR_TILE - 1) / GGR_TILE);
+    if (tiles > 65536) return fail(GGR_E_LIMIT, "image has %lld tiles; at most 65536 supported", (long long)tiles);
+    if (st->image_width > 65535 * GGR_TILE || st->image_height > 65535 * GGR_TILE) return fail(GGR_E_LIMIT, "image too large");
+    return GGR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ggr_abi_version(void) { return GGR_ABI_VERSION; }
+const char* ggr_last_error(void) { return g_err; }
+
+size_t ggr_geom_bytes(int32_t P) { return ggr_carve_geom(nullptr, (size_t)(P > 0 ? P : 0)).bytes; }
+size_t ggr_image_bytes(int32_t W, int32_t H) { return ggr_carve_image(nullptr, W, H).bytes; }
+size_t ggr_binning_bytes(int64_t N, int32_t, int32_t) { return ggr_carve_bin(nullptr, (size_t)(N > 0 ? N : 0)).bytes; }
+size_t ggr_backward_scratch_bytes(int32_t P) { return ggr_carve_bwd(nullptr, (size_t)(P > 0 ? P : 0)).bytes; }
+
+int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* out, GgrAllocFn alloc,
+                void* alloc_ctx, void* stream) {
+    g_err[0] = 0;
+    int rc = validate(st, in);
+    if (rc) return rc;
+    if (!out || !out->out_color || !out->geom_buffer || !out->image_buffer || !alloc)
+        return fail(GGR_E_INVALID, "null output / buffer / allocator");
+    if (st->num_points > 0 && !out->radii) return fail(GGR_E_INVALID, "null radii");
+    hipStream_t s = (hipStream_t)stream;
+    const int P = st->num_points, W = st->image_width, H = st->image_height;
+    const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
+    const size_t tiles = (size_t)gx * gy;
+    const bool dbg = st->debug != 0;
+
+    GeomLayout g = ggr_carve_geom(out->geom_buffer, (size_t)P);
+    ImageLayout im = ggr_carve_image(out->image_buffer, W, H);
+
+    // 1. per-Gaussian projection
+    ggr::launch_preprocess_fwd(P, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
+                               in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
+                               st->viewmatrix, st->projmatrix, st->campos, W, H, st->tanfovx, st->tanfovy,
+                               out->radii, g, s);
+    KCHECK(dbg, s, "preprocess_fwd");
+
+    // 2. stable sort of the Gaussians by depth bits (ties keep ascending id)
+    uint32_t *dk = nullptr, *order = nullptr;
+    if (P > 0) {
+        HIP_TRY(hipMemcpyAsync(g.keys_a, g.depth_key, (size_t)P * 4, hipMemcpyDeviceToDevice, s));
+        ggr::launch_iota(g.vals_a, (size_t)P, s);
+        ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, 32, &dk, &order, s);
+        KCHECK(dbg, s, "depth sort");
+    }
+
+    // 3. offsets (inclusive scan of tiles_touched in depth order) and num_rendered
+    ggr::launch_scan_tiles(g.tiles_touched, order, g.offsets, g.scan_tmp, g.counters, (size_t)P, s);
+    KCHECK(dbg, s, "offsets scan");
+    uint32_t num_rendered = 0;
+    HIP_TRY(hipMemcpyAsync(&num_rendered, g.counters, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));  // the single host sync of forward
+    if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
+    out->num_rendered = (int64_t)num_rendered;
+
+    void* bin_mem = alloc(alloc_ctx, ggr_carve_bin(nullptr, num_rendered).bytes);
+    if (!bin_mem) return fail(GGR_E_ALLOC, "binning allocator returned NULL");
+    out->binning_buffer = bin_mem;
+    BinLayout b = ggr_carve_bin(bin_mem, num_rendered);
+
+    // 4. emit (tile, id) pairs in depth order; 5. stable sort by tile id; 6. ranges
+    uint32_t *tk = b.keys_a, *pl = b.vals_a;
+    if (num_rendered > 0) {
+        ggr::launch_emit_pairs((size_t)P, order, g.offsets, g.tiles_touched, g.rect, gx, b.keys_a, b.vals_a, s);
+        KCHECK(dbg, s, "emit_pairs");
+        ggr::radix_sort_pairs(b.keys_a, b.keys_b, b.vals_a, b.vals_b, b.hist, num_rendered,
+                              ceil_log2((uint32_t)tiles), &tk, &pl, s);
+        KCHECK(dbg, s, "tile sort");
+    }
+    // the sorted list must live in vals_a / keys_a so that backward finds it without extra state
+    if (pl != b.vals_a && num_rendered > 0) {
+        HIP_TRY(hipMemcpyAsync(b.vals_a, pl, (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b.keys_a, tk, (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, s));
+    }
+    ggr::launch_tile_ranges(b.keys_a, num_rendered, im.ranges, tiles, s);
+    KCHECK(dbg, s, "tile_ranges");
+
+    // 7. blend
+    ggr::launch_blend_fwd(W, H, im.ranges, b.vals_a, g.splat, st->bg, out->out_color, im.final_T, im.n_contrib,
+                          out->out_depth, s);
+    KCHECK(dbg, s, "blend_fwd");
+    return GGR_OK;
+}
+
+int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut* out, void* stream) {
+    g_err[0] = 0;
+    if (!in) return fail(GGR_E_INVALID, "null inputs");
+    int rc = validate(st, &in->fwd);
+    if (rc) return rc;
+    if (!out || !out->dL_dmeans3D || !out->dL_dmeans2D || !out->dL_dopacities || !out->dL_dcov3D)
+        return fail(GGR_E_INVALID, "null gradient output");
+    if (!in->geom_buffer || !in->image_buffer || !in->scratch || !in->dL_dout_color)
+        return fail(GGR_E_INVALID, "null saved buffer / scratch / upstream gradient");
+    const bool has_cp = in->fwd.colors_precomp != nullptr;
+    if (has_cp ? !out->dL_dcolors_precomp : !out->dL_dshs) return fail(GGR_E_INVALID, "null colour gradient output");
+    const bool has_sr = in->fwd.scales != nullptr;
+    if (has_sr && (!out->dL_dscales || !out->dL_drotations)) return fail(GGR_E_INVALID, "null scale/rotation gradient output");
+    const int npose = (out->dL_dviewmatrix != nullptr) + (out->dL_dprojmatrix != nullptr) + (out->dL_dcampos != nullptr);
+    if (npose != 0 && npose != 3) return fail(GGR_E_INVALID, "camera gradients: give all three outputs or none");
+    hipStream_t s = (hipStream_t)stream;
+    const int P = st->num_points, W = st->image_width, H = st->image_height;
+    const bool dbg = st->debug != 0;
+    if (P == 0) {
+        if (npose) {
+            HIP_TRY(hipMemsetAsync(out->dL_dviewmatrix, 0, 64, s));
+            HIP_TRY(hipMemsetAsync(out->dL_dprojmatrix, 0, 64, s));
+            HIP_TRY(hipMemsetAsync(out->dL_dcampos, 0, 12, s));
+        }
+        return GGR_OK;
+    }
+    if (in->num_rendered > 0 && !in->binning_buffer) return fail(GGR_E_INVALID, "null binning buffer");
+
+    GeomLayout g = ggr_carve_geom((void*)in->geom_buffer, (size_t)P);
+    ImageLayout im = ggr_carve_image((void*)in->image_buffer, W, H);
+    BinLayout b = ggr_carve_bin((void*)in->binning_buffer, (size_t)in->num_rendered);
+    BwdScratch sc = ggr_carve_bwd(in->scratch, (size_t)P);
+
+    HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));
+    HIP_TRY(hipMemsetAsync(out->dL_dmeans2D, 0, (size_t)P * 12, s));
+    HIP_TRY(hipMemsetAsync(out->dL_dopacities, 0, (size_t)P * 4, s));
+
+    if (in->num_rendered > 0) {
+        ggr::launch_blend_bwd(W, H, im.ranges, b.vals_a, g.splat, st->bg, im.final_T, im.n_contrib,
+                              in->dL_dout_color, in->dL_dout_depth, out->dL_dmeans2D, sc.dL_dconic,
+                              out->dL_dopacities, sc.dL_drgb, in->dL_dout_depth ? sc.dL_dz : nullptr, s);
+        KCHECK(dbg, s, "blend_bwd");
+    }
+    const float* cov = in->fwd.cov3D_precomp ? in->fwd.cov3D_precomp : g.cov3D;
+    ggr::launch_preprocess_bwd(P, st->sh_degree, st->sh_stride, in->fwd.means3D, in->fwd.shs, has_cp ? 1 : 0,
+                               in->fwd.scales, in->fwd.rotations, st->scale_modifier, cov, st->viewmatrix,
+                               st->projmatrix, st->campos, W, H, st->tanfovx, st->tanfovy, in->radii, g.clamped,
+                               sc.dL_dconic, sc.dL_drgb, in->dL_dout_depth ? sc.dL_dz : nullptr, out->dL_dmeans3D,
+                               out->dL_dmeans2D, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
+                               out->dL_dscales, out->dL_drotations, npose ? sc.pose_acc : nullptr, s);
+    KCHECK(dbg, s, "preprocess_bwd");
+    if (npose) {
+        HIP_TRY(hipMemcpyAsync(out->dL_dviewmatrix, sc.pose_acc, 64, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(out->dL_dprojmatrix, sc.pose_acc + 16, 64, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(out->dL_dcampos, sc.pose_acc + 32, 12, hipMemcpyDeviceToDevice, s));
+    }
+    return GGR_OK;
+}
+
+int ggr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present,
+                     void* stream) {
+    g_err[0] = 0;
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(GGR_E_INVALID, "bad arguments");
+    ggr::launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    KCHECK(false, (hipStream_t)stream, "mark_visible");
+    return GGR_OK;
+}
+
+int ggr_debug_unpack_geom(const void* geom_buffer, int32_t P, float* depth, float* xy, float* conic_opacity,
+                          float* rgb, int32_t* tiles_touched, uint8_t* clamped, void* stream) {
+    g_err[0] = 0;
+    if (!geom_buffer) return fail(GGR_E_INVALID, "null geom buffer");
+    GeomLayout g = ggr_carve_geom((void*)geom_buffer, (size_t)(P > 0 ? P : 0));
+    ggr::launch_unpack_geom(g, P, depth, xy, conic_opacity, rgb, tiles_touched, clamped, (hipStream_t)stream);
+    KCHECK(false, (hipStream_t)stream, "unpack_geom");
+    return GGR_OK;
+}
+
+int ggr_debug_unpack_binning(const void* binning_buffer, const void* image_buffer, int64_t N, int32_t W, int32_t H,
+                             uint32_t* point_list, int32_t* ranges, float* final_T, int32_t* n_contrib, void* stream) {
+    g_err[0] = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (!image_buffer) return fail(GGR_E_INVALID, "null image buffer");
+    ImageLayout im = ggr_carve_image((void*)image_buffer, W, H);
+    const size_t tiles = (size_t)((W + GGR_TILE - 1) / GGR_TILE) * ((H + GGR_TILE - 1) / GGR_TILE);
+    if (point_list && N > 0) {
+        if (!binning_buffer) return fail(GGR_E_INVALID, "null binning buffer");
+        BinLayout b = ggr_carve_bin((void*)binning_buffer, (size_t)N);
+        HIP_TRY(hipMemcpyAsync(point_list, b.vals_a, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (ranges && tiles) HIP_TRY(hipMemcpyAsync(ranges, im.ranges, tiles * 8, hipMemcpyDeviceToDevice, s));
+    if (final_T) HIP_TRY(hipMemcpyAsync(final_T, im.final_T, (size_t)W * H * 4, hipMemcpyDeviceToDevice, s));
+    if (n_contrib) HIP_TRY(hipMemcpyAsync(n_contrib, im.n_contrib, (size_t)W * H * 4, hipMemcpyDeviceToDevice, s));
+    return GGR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// blend_fwd.hip — per-tile front-to-back alpha compositing for gfx950.
+//
+// Replaces the forward `renderCUDA` stage of the rasterizer behind reference
+// cuda_splatting.py:114-125 with identical skip/stop rules.
+//
+// Mapping: one 256-thread workgroup per 16×16 tile = 4 wave64; wave w owns the 8×8 quadrant
+// (w&1, w>>1) of the tile so that a wave's pixels are spatially compact (tight early-out and
+// tight per-wave culling).  The tile's list is staged through LDS in batches of 256 entries
+// (one 48-B splat record gathered per thread); inside a batch every wave first culls the entries
+// against its own 8×8 quadrant (lane-per-entry conservative test + ballot) and then walks only
+// the surviving entries, reading the record as LDS broadcasts.  A wave that is done (all 64
+// pixels saturated) stops walking; the workgroup stops fetching when all four waves are done.
+//
+// The quadrant cull is exact with respect to the reference semantics: an entry is dropped for a
+// quadrant only if α < 1/255 (or power > 0 is impossible) for every pixel of the quadrant, i.e.
+// only entries the per-pixel rule would `continue` past anyway; their list positions are still
+// counted, so n_contrib is unchanged.
+#include "ggr_common.h"
+
+namespace ggr {
+
+#define BATCH 256
+
+struct __attribute__((aligned(16))) StagedSplat {
+    float4 a;  // x, y, conic.xx, conic.xy
+    float4 b;  // conic.yy, opacity, r, g
+    float2 c;  // b, z
+};
+
+// Conservative test: can the Gaussian reach α ≥ 1/255 anywhere in the pixel rect [x0,x1]×[y0,y1]?
+// power(d) = -½ dᵀ Q d with Q = [[cxx, cxy],[cxy, cyy]] (positive definite).  The maximum of
+// power over the rect is attained at the rect point closest to the mean in the Q-metric; we bound
+// it from above cheaply: clamp the mean into the rect (Euclidean closest point p*), and use
+// dᵀQd ≥ λmin·|d|² with λmin ≥ det/(cxx+cyy).  If even that bound gives α < 1/255·(1-ε) the entry
+// cannot contribute.  (Looser than the exact Q-metric distance, but never wrong.)
+__device__ __forceinline__ bool quad_may_contribute(float mx, float my, float cxx, float cxy, float cyy,
+                                                    float opacity, float x0, float y0, float x1, float y1) {
+    const float qx = fminf(fmaxf(mx, x0), x1), qy = fminf(fmaxf(my, y0), y1);
+    const float dx = mx - qx, dy = my - qy;
+    const float d2 = dx * dx + dy * dy;
+    if (d2 == 0.f) return true;
+    const float tr = cxx + cyy;
+    const float det = cxx * cyy - cxy * cxy;
+    const float lmin = det / tr;  // ≤ true λmin; (det, tr > 0 for a valid conic)
+    if (!(lmin > 0.f)) return true;
+    // α ≤ opacity·exp(-½ λmin d²).  keep unless opacity·exp(-½ λmin d²) < (1/255)(1 - 1e-3)
+    const float bound = opacity * __expf(-0.5f * lmin * d2 * 0.999f);
+    return bound >= GGR_ALPHA_MIN * 0.999f;
+}
+
+__global__ void __launch_bounds__(256)
+blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
+                 const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
+                 const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
+                 uint32_t* __restrict__ n_contrib, float* __restrict__ out_depth) {
+    __shared__ StagedSplat stage[BATCH];
+    __shared__ int wave_done[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const int qx0 = tile_x * GGR_TILE + (wave & 1) * 8, qy0 = tile_y * GGR_TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pixx = (float)px, pixy = (float)py;
+    // quadrant rect clipped to the image (pixels outside never contribute)
+    const float rx0 = (float)qx0, ry0 = (float)qy0;
+    const float rx1 = (float)min(qx0 + 7, W - 1), ry1 = (float)min(qy0 + 7, H - 1);
+    const bool quad_live = qx0 < W && qy0 < H;
+
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+    if (lane == 0) wave_done[wave] = quad_live ? 0 : 1;
+    bool wdone = !quad_live;
+
+    for (int b0 = 0; b0 < total; b0 += BATCH) {
+        __syncthreads();  // previous batch fully consumed; wave_done visible
+        if (wave_done[0] & wave_done[1] & wave_done[2] & wave_done[3]) break;
+        const int nb = min(BATCH, total - b0);
+        if (tid < nb) {
+            const uint32_t g = point_list[range.x + b0 + tid];
+            const float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1], c = splat[3 * (size_t)g + 2];
+            stage[tid].a = a;
+            stage[tid].b = b;
+            stage[tid].c = make_float2(c.x, c.y);
+        }
+        __syncthreads();
+        if (!wdone) {
+            for (int s0 = 0; s0 < nb; s0 += 64) {
+                // lane-per-entry cull against this wave's quadrant
+                const int e = s0 + lane;
+                bool keep = false;
+                if (e < nb) {
+                    const float4 a = stage[e].a;
+                    const float4 b = stage[e].b;
+                    keep = quad_may_contribute(a.x, a.y, a.z, a.w, b.x, b.y, rx0, ry0, rx1, ry1);
+                }
+                uint64_t m = __ballot(keep);
+                while (m) {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int e2 = s0 + j;
+                    const float4 a = stage[e2].a;
+                    const float4 b = stage[e2].b;
+                    const float2 c = stage[e2].c;
+                    const float dx = a.x - pixx, dy = a.y - pixy;
+                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                    const float alpha = fminf(GGR_ALPHA_MAX, b.y * __expf(power));
+                    bool ok = !done && power <= 0.0f && alpha >= GGR_ALPHA_MIN;
+                    const float test_T = T * (1.f - alpha);
+                    if (ok && test_T < GGR_T_MIN) { done = true; ok = false; }
+                    if (ok) {
+                        const float w = alpha * T;
+                        C0 += b.z * w; C1 += b.w * w; C2 += c.x * w; Dz += c.y * w;
+                        T = test_T;
+                        last = (uint32_t)(b0 + e2 + 1);
+                    }
+                }
+                if (__all(done)) { wdone = true; break; }
+            }
+            if (wdone && lane == 0) wave_done[wave] = 1;
+        }
+    }
+    if (inside) {
+        const size_t pid = (size_t)py * W + px;
+        const size_t hw = (size_t)H * W;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = C0 + T * bg[0];
+        out_color[hw + pid] = C1 + T * bg[1];
+        out_color[2 * hw + pid] = C2 + T * bg[2];
+        if (out_depth) out_depth[pid] = Dz;
+    }
+}
+
+void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
+                      const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
+                      float* out_depth, hipStream_t s) {
+    const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
+    if (gx * gy == 0) return;
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg,
+                       out_color, final_T, n_contrib, out_depth);
+}
+
+}  // namespace ggr

@@ -1,0 +1,219 @@
+// ggr_common.h — shared constants, HBM layouts and launch helpers for the gfx950 kernels.
+//
+// Data layout in HBM (all caller-owned, carved out of three opaque buffers; 256-B aligned sections)
+//
+//   geom buffer   (per Gaussian, P entries)
+//     splat[P]         3 × float4 = 48 B  {x, y, conic.xx, conic.xy | conic.yy, opacity, r, g | b, z, 0, 0}
+//                      one record = everything the blend kernels need for a list entry, so a tile-list
+//                      fetch is ONE 48-B gather instead of three gathers from three SoA arrays
+//     depth_key[P]     u32   float bits of view z (0xFFFFFFFF if culled)
+//     tiles_touched[P] u32
+//     rect[P]          u32×2 packed tile rect (minx | miny<<16, maxx | maxy<<16)
+//     clamped[P]       u32   bit c set ⇔ SH colour channel c was clamped at 0
+//     cov3D[P]         6 × f32 (scale/rot path only; otherwise the caller's cov3D_precomp is used)
+//     order[P]         u32   Gaussian ids sorted by (depth, id)
+//     offsets[P]       u32   inclusive scan of tiles_touched in that order
+//     sort scratch     keys/vals double buffers + per-block digit histograms
+//     counters         u32[64]  (num_rendered, …)
+//   binning buffer (per list entry, N = num_rendered)
+//     tile keys ×2, values ×2 (u32 each), per-block digit histograms; after the sort one of the
+//     value buffers is the final point_list
+//   image buffer
+//     ranges[tiles] (uint2), final_T[H·W] f32, n_contrib[H·W] u32
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define GGR_TILE 16
+#define GGR_TILE_PIX 256
+#define GGR_NEAR_CULL 0.2f
+#define GGR_DILATION 0.3f
+#define GGR_FRUSTUM_CLAMP 1.3f
+#define GGR_ALPHA_MIN (1.0f / 255.0f)
+#define GGR_ALPHA_MAX 0.99f
+#define GGR_T_MIN 0.0001f
+
+// radix sort geometry: 256 threads × 16 items
+#define GGR_SORT_THREADS 256
+#define GGR_SORT_ITEMS 16
+#define GGR_SORT_TILE (GGR_SORT_THREADS * GGR_SORT_ITEMS)
+#define GGR_RADIX_BITS 8
+#define GGR_RADIX 256
+
+static inline size_t ggr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) / GGR_SORT_TILE; }
+
+struct GeomLayout {
+    float4* splat;
+    uint32_t* depth_key;
+    uint32_t* tiles_touched;
+    uint2* rect;
+    uint32_t* clamped;
+    float* cov3D;
+    uint32_t* order;      // final sorted ids (aliases one of the sort value buffers)
+    uint32_t* offsets;
+    uint32_t* keys_a;
+    uint32_t* keys_b;
+    uint32_t* vals_a;
+    uint32_t* vals_b;
+    uint32_t* hist;       // [256 * blocks] digit-major + [256] totals
+    uint32_t* scan_tmp;   // block sums for the offsets scan
+    uint32_t* counters;   // [64]
+    size_t bytes;
+};
+
+static inline GeomLayout ggr_carve_geom(void* base, size_t P) {
+    GeomLayout L;
+    char* p = (char*)base;
+    size_t o = 0;
+    size_t Pp = P ? P : 1;
+    auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes); return r; };
+    L.splat = (float4*)take(Pp * 48);
+    L.depth_key = (uint32_t*)take(Pp * 4);
+    L.tiles_touched = (uint32_t*)take(Pp * 4);
+    L.rect = (uint2*)take(Pp * 8);
+    L.clamped = (uint32_t*)take(Pp * 4);
+    L.cov3D = (float*)take(Pp * 24);
+    L.offsets = (uint32_t*)take(Pp * 4);
+    L.keys_a = (uint32_t*)take(Pp * 4);
+    L.keys_b = (uint32_t*)take(Pp * 4);
+    L.vals_a = (uint32_t*)take(Pp * 4);
+    L.vals_b = (uint32_t*)take(Pp * 4);
+    L.hist = (uint32_t*)take((ggr_sort_blocks(Pp) * GGR_RADIX + GGR_RADIX) * 4);
+    L.scan_tmp = (uint32_t*)take((ggr_sort_blocks(Pp) + 1) * 4);
+    L.counters = (uint32_t*)take(64 * 4);
+    L.order = nullptr;
+    L.bytes = o;
+    return L;
+}
+
+struct BinLayout {
+    uint32_t* keys_a;
+    uint32_t* keys_b;
+    uint32_t* vals_a;
+    uint32_t* vals_b;
+    uint32_t* hist;
+    size_t bytes;
+};
+
+static inline BinLayout ggr_carve_bin(void* base, size_t N) {
+    BinLayout L;
+    char* p = (char*)base;
+    size_t o = 0;
+    size_t Np = N ? N : 1;
+    auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes); return r; };
+    L.keys_a = (uint32_t*)take(Np * 4);
+    L.keys_b = (uint32_t*)take(Np * 4);
+    L.vals_a = (uint32_t*)take(Np * 4);
+    L.vals_b = (uint32_t*)take(Np * 4);
+    L.hist = (uint32_t*)take((ggr_sort_blocks(Np) * GGR_RADIX + GGR_RADIX) * 4);
+    L.bytes = o;
+    return L;
+}
+
+struct ImageLayout {
+    uint2* ranges;
+    float* final_T;
+    uint32_t* n_contrib;
+    size_t bytes;
+};
+
+static inline ImageLayout ggr_carve_image(void* base, int W, int H) {
+    ImageLayout L;
+    char* p = (char*)base;
+    size_t o = 0;
+    size_t tiles = (size_t)((W + GGR_TILE - 1) / GGR_TILE) * ((H + GGR_TILE - 1) / GGR_TILE);
+    size_t pix = (size_t)W * H;
+    auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes ? bytes : 4); return r; };
+    L.ranges = (uint2*)take(tiles * 8);
+    L.final_T = (float*)take(pix * 4);
+    L.n_contrib = (uint32_t*)take(pix * 4);
+    L.bytes = o;
+    return L;
+}
+
+// backward scratch: per-Gaussian accumulators filled by the blend backward
+struct BwdScratch {
+    float* dL_dconic;  // [P,3]  (xx, xy[half convention], yy)
+    float* dL_drgb;    // [P,3]
+    float* dL_dz;      // [P]    depth-as-feature gradient (only with dL_dout_depth)
+    float* pose_acc;   // [64]: dL/dviewmatrix [0:16], dL/dprojmatrix [16:32], dL/dcampos [32:35]
+    size_t bytes;
+};
+
+static inline BwdScratch ggr_carve_bwd(void* base, size_t P) {
+    BwdScratch L;
+    char* p = (char*)base;
+    size_t o = 0;
+    size_t Pp = P ? P : 1;
+    auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes); return r; };
+    L.dL_dconic = (float*)take(Pp * 12);
+    L.dL_drgb = (float*)take(Pp * 12);
+    L.dL_dz = (float*)take(Pp * 4);
+    L.pose_acc = (float*)take(64 * 4);
+    L.bytes = o;
+    return L;
+}
+
+// ---- kernel launchers (defined in the .hip translation units) -------------------------------
+struct GgrSettings;
+struct GgrForwardIn;
+
+namespace ggr {
+
+void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, float scale_modifier, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* campos, int W,
+                           int H, float tanfovx, float tanfovy, int32_t* radii, GeomLayout g,
+                           hipStream_t s);
+
+// stable LSD radix sort of (u32 key, u32 val) pairs on bits [0, nbits); returns the buffers that
+// hold the result (either a or b)
+void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                      uint32_t* hist, size_t n, int nbits, uint32_t** keys_out, uint32_t** vals_out,
+                      hipStream_t s);
+
+void launch_iota(uint32_t* v, size_t n, hipStream_t s);
+
+// offsets[i] = inclusive scan of tiles_touched[order[i]]; total -> counters[0]
+void launch_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets,
+                       uint32_t* scan_tmp, uint32_t* total_out, size_t P, hipStream_t s);
+
+void launch_emit_pairs(size_t P, const uint32_t* order, const uint32_t* offsets,
+                       const uint32_t* tiles_touched, const uint2* rect, int grid_x, uint32_t* keys,
+                       uint32_t* vals, hipStream_t s);
+
+void launch_tile_ranges(const uint32_t* keys_sorted, size_t N, uint2* ranges, size_t tiles, hipStream_t s);
+
+void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
+                      const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
+                      float* out_depth, hipStream_t s);
+
+void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
+                      const float* bg, const float* final_T, const uint32_t* n_contrib,
+                      const float* dL_dpix, const float* dL_ddepth, float* dL_dmean2D /*[P,3]*/,
+                      float* dL_dconic /*[P,3]*/, float* dL_dopacity /*[P]*/, float* dL_drgb /*[P,3]*/,
+                      float* dL_dz /*[P] or null*/, hipStream_t s);
+
+void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs,
+                           int has_colors_precomp, const float* scales, const float* rotations,
+                           float scale_modifier, const float* cov3D, const float* viewmatrix,
+                           const float* projmatrix, const float* campos, int W, int H, float tanfovx,
+                           float tanfovy, const int32_t* radii, const uint32_t* clamped,
+                           const float* dL_dconic, const float* dL_drgb, const float* dL_dz,
+                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dsh,
+                           float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
+                           float* dL_drotations, float* pose_acc, hipStream_t s);
+
+void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                         hipStream_t s);
+
+void launch_unpack_geom(GeomLayout g, int P, float* depth, float* xy, float* conic_opacity, float* rgb,
+                        int32_t* tiles_touched, uint8_t* clamped, hipStream_t s);
+
+
+
+}  // namespace ggr

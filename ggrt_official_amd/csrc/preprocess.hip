@@ -1,0 +1,250 @@
+// preprocess.hip — per-Gaussian forward stage for gfx950.
+//
+// Replaces the `preprocessCUDA` stage of the third-party rasterizer that GGRt reaches through
+// reference ggrt/model/pixelsplat/decoder/cuda_splatting.py:114-125.
+// One lane per Gaussian; streaming, HBM-bound (algorithmic bytes: 12+24+4+12·K read, 48+20 written).
+//
+// Arithmetic follows the operation order of oracle/ggr_oracle.c with FMA contraction disabled, so
+// the discrete outputs (cull decision, radius, tile rect → num_rendered) are bit-identical to the
+// CPU restatement; gfx950 fp32 divide/sqrt are correctly rounded under hipcc's defaults.
+#include "ggr_common.h"
+
+#pragma clang fp contract(off)
+
+namespace ggr {
+
+__device__ __constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                           -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                           0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                           -0.5900435899266435f};
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, const float* q, float* cov6) {
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    const float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)};
+    const float sc[3] = {mod * s[0], mod * s[1], mod * s[2]};
+    float Mx[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Mx[3 * i + j] = R[3 * i + j] * sc[j];
+    float S[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) a += Mx[3 * i + k] * Mx[3 * j + k];
+            S[3 * i + j] = a;
+        }
+    cov6[0] = S[0]; cov6[1] = S[1]; cov6[2] = S[2]; cov6[3] = S[4]; cov6[4] = S[5]; cov6[5] = S[8];
+}
+
+// SH basis in the rasterizer's sign convention; B must hold 16 floats
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* B) {
+    B[0] = SH_C0;
+    if (deg > 0) {
+        B[1] = -SH_C1 * y; B[2] = SH_C1 * z; B[3] = -SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            B[4] = kSH_C2[0] * xy; B[5] = kSH_C2[1] * yz; B[6] = kSH_C2[2] * (2.0f * zz - xx - yy);
+            B[7] = kSH_C2[3] * xz; B[8] = kSH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                B[9] = kSH_C3[0] * y * (3.0f * xx - yy);
+                B[10] = kSH_C3[1] * xy * z;
+                B[11] = kSH_C3[2] * y * (4.0f * zz - xx - yy);
+                B[12] = kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                B[13] = kSH_C3[4] * x * (4.0f * zz - xx - yy);
+                B[14] = kSH_C3[5] * z * (xx - yy);
+                B[15] = kSH_C3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+                      const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                      const float* __restrict__ scales, const float* __restrict__ rotations,
+                      float scale_modifier, const float* __restrict__ cov3D_precomp,
+                      const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+                      const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
+                      int32_t* __restrict__ radii, float4* __restrict__ splat,
+                      uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles_touched,
+                      uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
+                      float* __restrict__ cov3D_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float V[16], PM[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PM[k] = projmatrix[k]; }
+
+    // defaults for a culled Gaussian
+    int rad_out = 0;
+    uint32_t key_out = 0xFFFFFFFFu, tiles_out = 0, clamp_bits = 0;
+    uint2 rect_out = make_uint2(0, 0);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+
+    const float p0 = means3D[3 * i], p1 = means3D[3 * i + 1], p2 = means3D[3 * i + 2];
+    float cov6[6];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov6[k] = cov3D_precomp[6 * (size_t)i + k];
+    } else {
+        float sc[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        cov3d_from_scale_rot(sc, scale_modifier, q, cov6);
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov3D_out[6 * (size_t)i + k] = cov6[k];
+    }
+
+    float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
+    float t1 = V[1] * p0 + V[5] * p1 + V[9] * p2 + V[13];
+    const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
+    if (t2 > GGR_NEAR_CULL) {
+        const float ph0 = PM[0] * p0 + PM[4] * p1 + PM[8] * p2 + PM[12];
+        const float ph1 = PM[1] * p0 + PM[5] * p1 + PM[9] * p2 + PM[13];
+        const float ph3 = PM[3] * p0 + PM[7] * p1 + PM[11] * p2 + PM[15];
+        const float pw = 1.0f / (ph3 + 0.0000001f);
+        const float ppx = ph0 * pw, ppy = ph1 * pw;
+
+        const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+        const float limx = GGR_FRUSTUM_CLAMP * tanfovx, limy = GGR_FRUSTUM_CLAMP * tanfovy;
+        const float txtz = t0 / t2, tytz = t1 / t2;
+        t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+        t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+        const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2);
+        const float J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
+        // A = J·R with R[i][j] = V[4*j+i]
+        float A0[3], A1[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            A0[j] = J00 * V[4 * j + 0] + J02 * V[4 * j + 2];
+            A1[j] = J11 * V[4 * j + 1] + J12 * V[4 * j + 2];
+        }
+        const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
+        float AS0[3], AS1[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { a0 += A0[k] * S[3 * k + j]; a1 += A1[k] * S[3 * k + j]; }
+            AS0[j] = a0; AS1[j] = a1;
+        }
+        float c00 = 0.f, c01 = 0.f, c11 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { c00 += AS0[k] * A0[k]; c01 += AS0[k] * A1[k]; c11 += AS1[k] * A1[k]; }
+        const float a = c00 + GGR_DILATION, b = c01, c = c11 + GGR_DILATION;
+        const float det = a * c - b * b;
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float con0 = c * det_inv, con1 = -b * det_inv, con2 = a * det_inv;
+            const float mid = 0.5f * (a + c);
+            const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float l1 = mid + sq, l2 = mid - sq;
+            const int rad = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+            const float px = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
+            const float py = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
+            const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
+            const int rminx = min(gx, max(0, (int)((px - (float)rad) / (float)GGR_TILE)));
+            const int rminy = min(gy, max(0, (int)((py - (float)rad) / (float)GGR_TILE)));
+            const int rmaxx = min(gx, max(0, (int)((px + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
+            const int rmaxy = min(gy, max(0, (int)((py + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
+            const int area = (rmaxx - rminx) * (rmaxy - rminy);
+            if (area != 0) {
+                float rgb[3];
+                if (colors_precomp) {
+                    rgb[0] = colors_precomp[3 * i]; rgb[1] = colors_precomp[3 * i + 1]; rgb[2] = colors_precomp[3 * i + 2];
+                } else {
+                    const int deg = D > 3 ? 3 : D;
+                    float d0 = p0 - campos[0], d1 = p1 - campos[1], d2 = p2 - campos[2];
+                    const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+                    d0 /= len; d1 /= len; d2 /= len;
+                    float B[16];
+                    sh_basis(deg, d0, d1, d2, B);
+                    const int K = (deg + 1) * (deg + 1);
+                    const float* sh = shs + (size_t)i * M * 3;
+                    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+                    for (int k = 0; k < K; k++) {
+                        r0 += B[k] * sh[3 * k]; r1 += B[k] * sh[3 * k + 1]; r2 += B[k] * sh[3 * k + 2];
+                    }
+                    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+                    clamp_bits = (r0 < 0.f ? 1u : 0u) | (r1 < 0.f ? 2u : 0u) | (r2 < 0.f ? 4u : 0u);
+                    rgb[0] = fmaxf(r0, 0.f); rgb[1] = fmaxf(r1, 0.f); rgb[2] = fmaxf(r2, 0.f);
+                }
+                rad_out = rad;
+                key_out = __float_as_uint(t2);
+                tiles_out = (uint32_t)area;
+                rect_out = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
+                s0 = make_float4(px, py, con0, con1);
+                s1 = make_float4(con2, opacities[i], rgb[0], rgb[1]);
+                s2 = make_float4(rgb[2], t2, 0.f, 0.f);
+            }
+        }
+    }
+    radii[i] = rad_out;
+    depth_key[i] = key_out;
+    tiles_touched[i] = tiles_out;
+    rect[i] = rect_out;
+    clamped_out[i] = clamp_bits;
+    splat[3 * (size_t)i] = s0;
+    splat[3 * (size_t)i + 1] = s1;
+    splat[3 * (size_t)i + 2] = s2;
+}
+
+void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, float scale_modifier, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* campos, int W,
+                           int H, float tanfovx, float tanfovy, int32_t* radii, GeomLayout g,
+                           hipStream_t s) {
+    if (P <= 0) return;
+    const int threads = 256;
+    const int blocks = (P + threads - 1) / threads;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), 0, s, P, D, M, means3D, shs,
+                       colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+                       viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.depth_key,
+                       g.tiles_touched, g.rect, g.clamped, g.cov3D);
+}
+
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                    const float* __restrict__ V, uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float p0 = means3D[3 * i], p1 = means3D[3 * i + 1], p2 = means3D[3 * i + 2];
+    const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
+    present[i] = t2 > GGR_NEAR_CULL ? 1 : 0;
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+}
+
+__global__ void unpack_geom_kernel(int P, const float4* __restrict__ splat, const uint32_t* __restrict__ tt,
+                                   const uint32_t* __restrict__ cl, float* depth, float* xy, float* co,
+                                   float* rgb, int32_t* tiles, uint8_t* clamped) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 s0 = splat[3 * (size_t)i], s1 = splat[3 * (size_t)i + 1], s2 = splat[3 * (size_t)i + 2];
+    if (depth) depth[i] = s2.y;
+    if (xy) { xy[2 * i] = s0.x; xy[2 * i + 1] = s0.y; }
+    if (co) { co[4 * i] = s0.z; co[4 * i + 1] = s0.w; co[4 * i + 2] = s1.x; co[4 * i + 3] = s1.y; }
+    if (rgb) { rgb[3 * i] = s1.z; rgb[3 * i + 1] = s1.w; rgb[3 * i + 2] = s2.x; }
+    if (tiles) tiles[i] = (int32_t)tt[i];
+    if (clamped) { const uint32_t c = cl[i]; clamped[3 * i] = c & 1; clamped[3 * i + 1] = (c >> 1) & 1; clamped[3 * i + 2] = (c >> 2) & 1; }
+}
+
+void launch_unpack_geom(GeomLayout g, int P, float* depth, float* xy, float* conic_opacity, float* rgb,
+                        int32_t* tiles_touched, uint8_t* clamped, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(unpack_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.splat, g.tiles_touched,
+                       g.clamped, depth, xy, conic_opacity, rgb, tiles_touched, clamped);
+}
+
+}  // namespace ggr

@@ -1,0 +1,329 @@
+// preprocess_bwd.hip — per-Gaussian backward for gfx950 (one lane per Gaussian, streaming).
+//
+// Fuses the `computeCov2DCUDA` (backward) and `preprocessCUDA` (backward) stages of the rasterizer
+// behind reference cuda_splatting.py:114-125 / train_ggrt_stable.py:143 (SURVEY.md §2.2, Appendix
+// A.4-A.5): conic → cov2D → cov3D[6] and mean3D (through J, frozen on frustum-clamped axes),
+// mean2D → mean3D through the perspective divide, SH backward (+ view-direction term), optional
+// scale/rotation backward.  Optionally accumulates the camera gradients (viewmatrix, projmatrix,
+// campos) — an extension beyond the reference.
+#include "ggr_common.h"
+
+namespace ggr {
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+__device__ __constant__ float bSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                           -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                           0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                           -0.5900435899266435f};
+
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <bool POSE>
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+                      int has_colors_precomp, const float* __restrict__ scales,
+                      const float* __restrict__ rotations, float scale_modifier,
+                      const float* __restrict__ cov3D, const float* __restrict__ viewmatrix,
+                      const float* __restrict__ projmatrix, const float* __restrict__ campos, int W, int H,
+                      float tanfovx, float tanfovy, const int32_t* __restrict__ radii,
+                      const uint32_t* __restrict__ clamped, const float* __restrict__ dL_dconic,
+                      const float* __restrict__ dL_drgb, const float* __restrict__ dL_dz,
+                      float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+                      float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
+                      float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
+                      float* __restrict__ dL_drotations, float* __restrict__ pose_acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = i < P;
+    const bool live = in_range && radii[i] > 0;
+    float V[16], PM[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PM[k] = projmatrix[k]; }
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dV[16], dPM[16], dcam[3] = {0.f, 0.f, 0.f};
+    if (POSE) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) { dV[k] = 0.f; dPM[k] = 0.f; }
+    }
+    const int deg = D > 3 ? 3 : D;
+    const int K = (deg + 1) * (deg + 1);
+
+    if (live) {
+        const float p0 = means3D[3 * i], p1 = means3D[3 * i + 1], p2 = means3D[3 * i + 2];
+        float cov6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov6[k] = cov3D[6 * (size_t)i + k];
+        const float dcon0 = dL_dconic[3 * i], dcon1 = dL_dconic[3 * i + 1], dcon2 = dL_dconic[3 * i + 2];
+
+        const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+        float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
+        float t1 = V[1] * p0 + V[5] * p1 + V[9] * p2 + V[13];
+        const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
+        const float limx = GGR_FRUSTUM_CLAMP * tanfovx, limy = GGR_FRUSTUM_CLAMP * tanfovy;
+        const float txtz = t0 / t2, tytz = t1 / t2;
+        const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+        t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+        const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2);
+        const float J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
+        float A0[3], A1[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            A0[j] = J00 * V[4 * j + 0] + J02 * V[4 * j + 2];
+            A1[j] = J11 * V[4 * j + 1] + J12 * V[4 * j + 2];
+        }
+        const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
+        float SA0[3], SA1[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            SA0[j] = A0[0] * S[j] + A0[1] * S[3 + j] + A0[2] * S[6 + j];
+            SA1[j] = A1[0] * S[j] + A1[1] * S[3 + j] + A1[2] * S[6 + j];
+        }
+        const float a = SA0[0] * A0[0] + SA0[1] * A0[1] + SA0[2] * A0[2] + GGR_DILATION;
+        const float b = SA0[0] * A1[0] + SA0[1] * A1[1] + SA0[2] * A1[2];
+        const float c = SA1[0] * A1[0] + SA1[1] * A1[1] + SA1[2] * A1[2] + GGR_DILATION;
+        const float denom = a * c - b * b;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-c * c * dcon0 + 2.f * b * c * dcon1 + (denom - a * c) * dcon2);
+            dL_dc = denom2inv * (-a * a * dcon2 + 2.f * a * b * dcon1 + (denom - a * c) * dcon0);
+            dL_db = denom2inv * 2.f * (b * c * dcon0 - (denom + 2.f * b * b) * dcon1 + a * b * dcon2);
+            dcov[0] = A0[0] * A0[0] * dL_da + A0[0] * A1[0] * dL_db + A1[0] * A1[0] * dL_dc;
+            dcov[3] = A0[1] * A0[1] * dL_da + A0[1] * A1[1] * dL_db + A1[1] * A1[1] * dL_dc;
+            dcov[5] = A0[2] * A0[2] * dL_da + A0[2] * A1[2] * dL_db + A1[2] * A1[2] * dL_dc;
+            dcov[1] = 2.f * A0[0] * A0[1] * dL_da + (A0[0] * A1[1] + A0[1] * A1[0]) * dL_db + 2.f * A1[0] * A1[1] * dL_dc;
+            dcov[2] = 2.f * A0[0] * A0[2] * dL_da + (A0[0] * A1[2] + A0[2] * A1[0]) * dL_db + 2.f * A1[0] * A1[2] * dL_dc;
+            dcov[4] = 2.f * A0[2] * A0[1] * dL_da + (A0[1] * A1[2] + A0[2] * A1[1]) * dL_db + 2.f * A1[1] * A1[2] * dL_dc;
+        }
+        float dA0[3], dA1[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            dA0[j] = 2.f * SA0[j] * dL_da + SA1[j] * dL_db;
+            dA1[j] = 2.f * SA1[j] * dL_dc + SA0[j] * dL_db;
+        }
+        // A = J·R, R[k][j] = V[4*j+k]
+        const float dJ00 = dA0[0] * V[0] + dA0[1] * V[4] + dA0[2] * V[8];
+        const float dJ02 = dA0[0] * V[2] + dA0[1] * V[6] + dA0[2] * V[10];
+        const float dJ11 = dA1[0] * V[1] + dA1[1] * V[5] + dA1[2] * V[9];
+        const float dJ12 = dA1[0] * V[2] + dA1[1] * V[6] + dA1[2] * V[10];
+        const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = xmul * -fx * tz2 * dJ02;
+        const float dty = ymul * -fy * tz2 * dJ12;
+        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * t0) * tz3 * dJ02 + (2.f * fy * t1) * tz3 * dJ12;
+        // t = [p 1]·V → dL/dp = R^T dt  (R row k = V[4*j+k] over j)
+        dmean[0] = V[0] * dtx + V[1] * dty + V[2] * dtz;
+        dmean[1] = V[4] * dtx + V[5] * dty + V[6] * dtz;
+        dmean[2] = V[8] * dtx + V[9] * dty + V[10] * dtz;
+        if (POSE) {
+            // through t: dL/dV[4*j+k] += p_j * dt_k (j<3), dL/dV[12+k] += dt_k
+            const float dt[3] = {dtx, dty, dtz};
+            const float pp[3] = {p0, p1, p2};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) dV[4 * j + k] += pp[j] * dt[k];
+                dV[12 + k] += dt[k];
+            }
+            // through R in A = J·R: dL/dR[k][j] = Σ_i J[i][k] dA[i][j];  R[k][j] = V[4*j+k]
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                dV[4 * j + 0] += J00 * dA0[j];
+                dV[4 * j + 1] += J11 * dA1[j];
+                dV[4 * j + 2] += J02 * dA0[j] + J12 * dA1[j];
+            }
+        }
+
+        // mean2D (NDC units) → mean3D through the perspective divide
+        const float d2x = dL_dmeans2D[3 * i], d2y = dL_dmeans2D[3 * i + 1];
+        const float mh0 = PM[0] * p0 + PM[4] * p1 + PM[8] * p2 + PM[12];
+        const float mh1 = PM[1] * p0 + PM[5] * p1 + PM[9] * p2 + PM[13];
+        const float mh3 = PM[3] * p0 + PM[7] * p1 + PM[11] * p2 + PM[15];
+        const float mw = 1.0f / (mh3 + 0.0000001f);
+        const float mul1 = mh0 * mw * mw, mul2 = mh1 * mw * mw;
+        dmean[0] += (PM[0] * mw - PM[3] * mul1) * d2x + (PM[1] * mw - PM[3] * mul2) * d2y;
+        dmean[1] += (PM[4] * mw - PM[7] * mul1) * d2x + (PM[5] * mw - PM[7] * mul2) * d2y;
+        dmean[2] += (PM[8] * mw - PM[11] * mul1) * d2x + (PM[9] * mw - PM[11] * mul2) * d2y;
+        if (POSE) {
+            // ndc_x = mh0*mw, ndc_y = mh1*mw:  d/dmh0 = mw·d2x, d/dmh1 = mw·d2y, d/dmh3 = -(mul1·d2x + mul2·d2y)
+            const float g0 = mw * d2x, g1 = mw * d2y, g3 = -(mul1 * d2x + mul2 * d2y);
+            const float pp[4] = {p0, p1, p2, 1.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                dPM[4 * j + 0] += pp[j] * g0;
+                dPM[4 * j + 1] += pp[j] * g1;
+                dPM[4 * j + 3] += pp[j] * g3;
+            }
+        }
+
+        // depth-as-feature gradient: z = t2 = [p 1]·V[:,2]
+        if (dL_dz) {
+            const float gz = dL_dz[i];
+            dmean[0] += V[2] * gz; dmean[1] += V[6] * gz; dmean[2] += V[10] * gz;
+            if (POSE) { dV[2] += p0 * gz; dV[6] += p1 * gz; dV[10] += p2 * gz; dV[14] += gz; }
+        }
+
+        // colour
+        float dc0 = dL_drgb[3 * i], dc1 = dL_drgb[3 * i + 1], dc2 = dL_drgb[3 * i + 2];
+        if (has_colors_precomp) {
+            dL_dcolors_precomp[3 * i] = dc0; dL_dcolors_precomp[3 * i + 1] = dc1; dL_dcolors_precomp[3 * i + 2] = dc2;
+        } else {
+            const uint32_t cl = clamped[i];
+            if (cl & 1u) dc0 = 0.f;
+            if (cl & 2u) dc1 = 0.f;
+            if (cl & 4u) dc2 = 0.f;
+            const float vx = p0 - campos[0], vy = p1 - campos[1], vz = p2 - campos[2];
+            const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+            const float x = vx / len, y = vy / len, z = vz / len;
+            const float* sh = shs + (size_t)i * M * 3;
+            float* dsh = dL_dsh + (size_t)i * M * 3;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            // helper: coefficient k with basis value Bk and basis gradient (bx,by,bz)
+#define SH_TERM(k, Bk, bx, by, bz)                                                                     \
+    {                                                                                                  \
+        const float s0 = sh[3 * (k)], s1 = sh[3 * (k) + 1], s2 = sh[3 * (k) + 2];                      \
+        dsh[3 * (k)] = (Bk) * dc0; dsh[3 * (k) + 1] = (Bk) * dc1; dsh[3 * (k) + 2] = (Bk) * dc2;      \
+        const float sd = s0 * dc0 + s1 * dc1 + s2 * dc2;                                               \
+        ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                          \
+    }
+            SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)
+            if (deg > 0) {
+                SH_TERM(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)
+                SH_TERM(2, SH_C1 * z, 0.f, 0.f, SH_C1)
+                SH_TERM(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)
+                if (deg > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    SH_TERM(4, bSH_C2[0] * xy, bSH_C2[0] * y, bSH_C2[0] * x, 0.f)
+                    SH_TERM(5, bSH_C2[1] * yz, 0.f, bSH_C2[1] * z, bSH_C2[1] * y)
+                    SH_TERM(6, bSH_C2[2] * (2.f * zz - xx - yy), bSH_C2[2] * -2.f * x, bSH_C2[2] * -2.f * y, bSH_C2[2] * 4.f * z)
+                    SH_TERM(7, bSH_C2[3] * xz, bSH_C2[3] * z, 0.f, bSH_C2[3] * x)
+                    SH_TERM(8, bSH_C2[4] * (xx - yy), bSH_C2[4] * 2.f * x, bSH_C2[4] * -2.f * y, 0.f)
+                    if (deg > 2) {
+                        SH_TERM(9, bSH_C3[0] * y * (3.f * xx - yy), bSH_C3[0] * 6.f * xy, bSH_C3[0] * 3.f * (xx - yy), 0.f)
+                        SH_TERM(10, bSH_C3[1] * xy * z, bSH_C3[1] * yz, bSH_C3[1] * xz, bSH_C3[1] * xy)
+                        SH_TERM(11, bSH_C3[2] * y * (4.f * zz - xx - yy), bSH_C3[2] * -2.f * xy,
+                                bSH_C3[2] * (-3.f * yy + 4.f * zz - xx), bSH_C3[2] * 8.f * yz)
+                        SH_TERM(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), bSH_C3[3] * -6.f * xz,
+                                bSH_C3[3] * -6.f * yz, bSH_C3[3] * 3.f * (2.f * zz - xx - yy))
+                        SH_TERM(13, bSH_C3[4] * x * (4.f * zz - xx - yy), bSH_C3[4] * (-3.f * xx + 4.f * zz - yy),
+                                bSH_C3[4] * -2.f * xy, bSH_C3[4] * 8.f * xz)
+                        SH_TERM(14, bSH_C3[5] * z * (xx - yy), bSH_C3[5] * 2.f * xz, bSH_C3[5] * -2.f * yz,
+                                bSH_C3[5] * (xx - yy))
+                        SH_TERM(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)
+                    }
+                }
+            }
+#undef SH_TERM
+            for (int k = 3 * K; k < 3 * M; k++) dsh[k] = 0.f;
+            const float sum2 = vx * vx + vy * vy + vz * vz;
+            const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            const float gx_ = ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
+            const float gy_ = (-vx * vy * ddx + (sum2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
+            const float gz_ = (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * inv32;
+            dmean[0] += gx_; dmean[1] += gy_; dmean[2] += gz_;
+            if (POSE) { dcam[0] -= gx_; dcam[1] -= gy_; dcam[2] -= gz_; }
+        }
+
+        if (scales && dL_dscales) {
+            const float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
+            const float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                                2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                                2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)};
+            const float sc[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1], scale_modifier * scales[3 * i + 2]};
+            float Mx[9];
+#pragma unroll
+            for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) Mx[3 * ii + j] = R[3 * ii + j] * sc[j];
+            const float dS[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
+                                 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+            float dR[9], ds[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < 3; ii++) {
+                    float dMij = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) dMij += dS[3 * ii + k] * Mx[3 * k + j];
+                    dMij *= 2.f;
+                    acc += dMij * R[3 * ii + j];
+                    dR[3 * ii + j] = dMij * sc[j];
+                }
+                ds[j] = acc * scale_modifier;
+            }
+            dL_dscales[3 * i] = ds[0]; dL_dscales[3 * i + 1] = ds[1]; dL_dscales[3 * i + 2] = ds[2];
+            dL_drotations[4 * i] = 2.f * (z * (dR[3] - dR[1]) + y * (dR[2] - dR[6]) + x * (dR[7] - dR[5]));
+            dL_drotations[4 * i + 1] = 2.f * (y * (dR[1] + dR[3]) + z * (dR[2] + dR[6]) + r * (dR[7] - dR[5])) - 4.f * x * (dR[4] + dR[8]);
+            dL_drotations[4 * i + 2] = 2.f * (x * (dR[1] + dR[3]) + r * (dR[2] - dR[6]) + z * (dR[5] + dR[7])) - 4.f * y * (dR[0] + dR[8]);
+            dL_drotations[4 * i + 3] = 2.f * (r * (dR[3] - dR[1]) + x * (dR[2] + dR[6]) + y * (dR[5] + dR[7])) - 4.f * z * (dR[0] + dR[4]);
+        }
+    } else if (in_range) {
+        // culled Gaussian: all gradients are zero
+        if (!has_colors_precomp && dL_dsh) {
+            float* dsh = dL_dsh + (size_t)i * M * 3;
+            for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
+        }
+        if (has_colors_precomp) { dL_dcolors_precomp[3 * i] = 0.f; dL_dcolors_precomp[3 * i + 1] = 0.f; dL_dcolors_precomp[3 * i + 2] = 0.f; }
+        if (scales && dL_dscales) {
+            dL_dscales[3 * i] = dL_dscales[3 * i + 1] = dL_dscales[3 * i + 2] = 0.f;
+            dL_drotations[4 * i] = dL_drotations[4 * i + 1] = dL_drotations[4 * i + 2] = dL_drotations[4 * i + 3] = 0.f;
+        }
+    }
+    if (in_range) {
+        dL_dmeans3D[3 * i] = dmean[0]; dL_dmeans3D[3 * i + 1] = dmean[1]; dL_dmeans3D[3 * i + 2] = dmean[2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+    }
+    if (POSE) {
+        // wave reduction, then one atomic per wave per component (35 components)
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float sv = wave_sum_all(dV[k]);
+            const float sp = wave_sum_all(dPM[k]);
+            if (lane == 0) {
+                if (sv != 0.f) atomicAdd(&pose_acc[k], sv);
+                if (sp != 0.f) atomicAdd(&pose_acc[16 + k], sp);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float sc = wave_sum_all(dcam[k]);
+            if (lane == 0 && sc != 0.f) atomicAdd(&pose_acc[32 + k], sc);
+        }
+    }
+}
+
+void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs,
+                           int has_colors_precomp, const float* scales, const float* rotations,
+                           float scale_modifier, const float* cov3D, const float* viewmatrix,
+                           const float* projmatrix, const float* campos, int W, int H, float tanfovx,
+                           float tanfovy, const int32_t* radii, const uint32_t* clamped,
+                           const float* dL_dconic, const float* dL_drgb, const float* dL_dz,
+                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dsh,
+                           float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
+                           float* dL_drotations, float* pose_acc, hipStream_t s) {
+    if (P <= 0) return;
+    const int blocks = (P + 255) / 256;
+    if (pose_acc)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, P, D, M, means3D, shs,
+                           has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
+                           campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,
+                           dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, pose_acc);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, P, D, M, means3D, shs,
+                           has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
+                           campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,
+                           dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, pose_acc);
+}
+
+}  // namespace ggr

@@ -1,0 +1,283 @@
+"""PyTorch front-end of the MI355X rasterizer — same surface as ``diff_gaussian_rasterization``.
+
+Mirrors what GGRt imports and calls at
+``ggrt/model/pixelsplat/decoder/cuda_splatting.py:6-9,101-125`` of the reference:
+
+    settings   = GaussianRasterizationSettings(image_height=…, image_width=…, tanfovx=…, tanfovy=…,
+                     bg=…, scale_modifier=…, viewmatrix=…, projmatrix=…, sh_degree=…, campos=…,
+                     prefiltered=False)                      # `debug` optional, as at :101-113
+    rasterizer = GaussianRasterizer(settings)
+    image, radii, depth = rasterizer(means3D=…, means2D=…, shs=… | colors_precomp=…, opacities=…,
+                                     cov3D_precomp=… | scales=…, rotations=…)
+
+Same names, argument meaning, error behaviour (``Exception`` with the upstream messages when both /
+neither of ``shs``/``colors_precomp`` or of ``scales+rotations``/``cov3D_precomp`` are given) and
+gradient order.  The arithmetic runs in hand-written HIP kernels behind the C ABI of
+``include/ggr_raster.h``; PyTorch only provides device memory, the stream and autograd plumbing.
+There is no CPU path: tensors must live on a ROCm device and the HIP library must be built.
+
+Extension beyond the reference: if ``viewmatrix`` / ``projmatrix`` / ``campos`` of
+the settings require grad, their gradients are produced too (the reference's extension cannot:
+it receives them inside a NamedTuple).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool = False
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _none_if_empty(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor) and t.numel() == 0 and t.dim() <= 1:
+        return None
+    return t
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {_lib.last_error()}")
+
+
+def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view, proj, campos) -> _lib.GgrSettings:
+    return _lib.GgrSettings(
+        image_height=int(rs.image_height), image_width=int(rs.image_width), sh_degree=int(rs.sh_degree),
+        sh_stride=int(M), num_points=int(P), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
+        scale_modifier=float(rs.scale_modifier), bg=_ptr(bg), viewmatrix=_ptr(view), projmatrix=_ptr(proj),
+        campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)))
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                viewmatrix, projmatrix, campos, raster_settings):
+        lib = _lib.load()
+        rs = raster_settings
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                "ggrt_official_amd rasterizer needs tensors on a ROCm GPU (device 'cuda'); there is no CPU path")
+        ctx.set_materialize_grads(False)
+        means3D_c = _f32c(means3D)
+        P = means3D_c.shape[0]
+        sh_c, cp_c = _f32c(sh), _f32c(colors_precomp)
+        op_c = _f32c(opacities)
+        sc_c, rot_c, cov_c = _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
+        M = 0 if sh_c is None else int(sh_c.shape[1])
+        bg = _f32c(rs.bg.to(dev))
+        view, proj, cam = _f32c(viewmatrix.to(dev)), _f32c(projmatrix.to(dev)), _f32c(campos.to(dev))
+        H, W = int(rs.image_height), int(rs.image_width)
+
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            depth = torch.empty((H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            geom = torch.empty((lib.ggr_geom_bytes(P),), dtype=torch.uint8, device=dev)
+            img = torch.empty((lib.ggr_image_bytes(W, H),), dtype=torch.uint8, device=dev)
+            holder = {}
+
+            def _alloc(_ctx, nbytes):
+                try:
+                    holder["bin"] = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+                    return holder["bin"].data_ptr()
+                except Exception:  # pragma: no cover - out of memory
+                    return None
+
+            cb = _lib.ALLOC_FN(_alloc)
+            st = _settings_struct(rs, P, M, bg, view, proj, cam)
+            fin = _lib.GgrForwardIn(means3D=_ptr(means3D_c), shs=_ptr(sh_c), colors_precomp=_ptr(cp_c),
+                                    opacities=_ptr(op_c), scales=_ptr(sc_c), rotations=_ptr(rot_c),
+                                    cov3D_precomp=_ptr(cov_c))
+            fout = _lib.GgrForwardOut(out_color=color.data_ptr(), radii=_ptr(radii), out_depth=depth.data_ptr(),
+                                      geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
+                                      binning_buffer=None, num_rendered=0)
+            _check(lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream), "ggr_forward")
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(fout.num_rendered)
+        ctx.dims = (P, M, H, W)
+        ctx.in_shapes = (means3D.shape, None if sh is None else sh.shape, opacities.shape)
+        ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
+        ctx.save_for_backward(means3D_c, sh_c, cp_c, op_c, sc_c, rot_c, cov_c, bg, view, proj, cam, radii, geom,
+                              img, holder.get("bin"))
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, grad_depth):
+        lib = _lib.load()
+        rs = ctx.raster_settings
+        (means3D, sh, cp, op, sc, rot, cov, bg, view, proj, cam, radii, geom, img, binb) = ctx.saved_tensors
+        P, M, H, W = ctx.dims
+        dev = means3D.device
+        need_pose = any(ctx.needs_input_grad[8:11])
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if grad_color is None:
+                grad_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+            grad_color = _f32c(grad_color)
+            grad_depth = _f32c(grad_depth)
+            d_means3D = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            d_means2D = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            d_op = torch.empty((P,), dtype=torch.float32, device=dev)
+            d_cov = torch.empty((P, 6), dtype=torch.float32, device=dev)
+            d_sh = torch.empty((P, M, 3), dtype=torch.float32, device=dev) if sh is not None else None
+            d_cp = torch.empty((P, 3), dtype=torch.float32, device=dev) if cp is not None else None
+            d_sc = torch.empty((P, 3), dtype=torch.float32, device=dev) if sc is not None else None
+            d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev) if rot is not None else None
+            d_view = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pose else None
+            d_proj = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pose else None
+            d_cam = torch.empty((3,), dtype=torch.float32, device=dev) if need_pose else None
+            scratch = torch.empty((lib.ggr_backward_scratch_bytes(P),), dtype=torch.uint8, device=dev)
+
+            st = _settings_struct(rs, P, M, bg, view, proj, cam)
+            bin_ = _lib.GgrBackwardIn(
+                fwd=_lib.GgrForwardIn(means3D=_ptr(means3D), shs=_ptr(sh), colors_precomp=_ptr(cp), opacities=_ptr(op),
+                                      scales=_ptr(sc), rotations=_ptr(rot), cov3D_precomp=_ptr(cov)),
+                radii=_ptr(radii), geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
+                binning_buffer=_ptr(binb), num_rendered=ctx.num_rendered, dL_dout_color=grad_color.data_ptr(),
+                dL_dout_depth=_ptr(grad_depth), scratch=scratch.data_ptr())
+            bout = _lib.GgrBackwardOut(
+                dL_dmeans3D=d_means3D.data_ptr(), dL_dmeans2D=d_means2D.data_ptr(), dL_dshs=_ptr(d_sh),
+                dL_dcolors_precomp=_ptr(d_cp), dL_dopacities=d_op.data_ptr(), dL_dcov3D=d_cov.data_ptr(),
+                dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot), dL_dviewmatrix=_ptr(d_view),
+                dL_dprojmatrix=_ptr(d_proj), dL_dcampos=_ptr(d_cam))
+            _check(lib.ggr_backward(C.byref(st), C.byref(bin_), C.byref(bout), stream), "ggr_backward")
+
+        means_shape, sh_shape, op_shape = ctx.in_shapes
+        has_sh, has_cp, has_sc, has_cov = ctx.has
+        return (
+            d_means3D.reshape(means_shape),
+            d_means2D,
+            d_sh.reshape(sh_shape) if has_sh else None,
+            d_cp if has_cp else None,
+            d_op.reshape(op_shape),
+            d_sc if has_sc else None,
+            d_rot if has_sc else None,
+            d_cov if has_cov else None,
+            d_view if ctx.needs_input_grad[8] else None,
+            d_proj if ctx.needs_input_grad[9] else None,
+            d_cam.reshape(ctx.saved_tensors[10].shape) if ctx.needs_input_grad[10] else None,
+            None,
+        )
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    """Function form, argument order of upstream's ``rasterize_gaussians``."""
+    rs = raster_settings
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.campos, rs)
+
+
+class GaussianRasterizer(nn.Module):
+    """Drop-in for ``diff_gaussian_rasterization.GaussianRasterizer`` (call site:
+    reference ``cuda_splatting.py:114-125``).  Returns the 3-tuple ``(color[3,H,W], radii[P],
+    depth[H,W])`` that the live call site unpacks at ``:118``."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        rs = self.raster_settings
+        dev = positions.device
+        if dev.type != "cuda":
+            raise RuntimeError("markVisible needs a ROCm GPU tensor; there is no CPU path")
+        with torch.no_grad(), torch.cuda.device(dev):
+            pos = _f32c(positions)
+            view, proj = _f32c(rs.viewmatrix.to(dev)), _f32c(rs.projmatrix.to(dev))
+            present = torch.empty((pos.shape[0],), dtype=torch.uint8, device=dev)
+            _check(lib.ggr_mark_visible(pos.shape[0], pos.data_ptr(), view.data_ptr(), proj.data_ptr(),
+                                        present.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                   "ggr_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        shs, colors_precomp = _none_if_empty(shs), _none_if_empty(colors_precomp)
+        scales, rotations, cov3D_precomp = _none_if_empty(scales), _none_if_empty(rotations), _none_if_empty(cov3D_precomp)
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)
+
+
+def debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_precomp=None, cov3D_precomp=None,
+                        scales=None, rotations=None):
+    """Test helper: runs forward once and returns the kernel intermediates (device tensors) unpacked
+    from the opaque buffers through ``ggr_debug_unpack_*`` — used by the stage-by-stage parity tests."""
+    lib = _lib.load()
+    # call the raw Function with a stand-in ctx to get hold of the saved buffers
+    class _Ctx:  # minimal stand-in for the autograd ctx
+        def set_materialize_grads(self, v): pass
+        def save_for_backward(self, *t): self.saved = t
+        def mark_non_differentiable(self, *t): pass
+    ctx = _Ctx()
+    rs = raster_settings
+    with torch.no_grad():
+        color, radii, depth = _RasterizeGaussians.forward(ctx, means3D, torch.zeros_like(means3D), shs, colors_precomp,
+                                                          opacities, scales, rotations, cov3D_precomp, rs.viewmatrix,
+                                                          rs.projmatrix, rs.campos, rs)
+    P, M, H, W = ctx.dims
+    dev = means3D.device
+    geom, img, binb = ctx.saved[12], ctx.saved[13], ctx.saved[14]
+    N = ctx.num_rendered
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    out = dict(color=color, radii=radii, out_depth=depth, num_rendered=N,
+               depth=torch.empty(P, device=dev), xy=torch.empty(P, 2, device=dev),
+               conic_opacity=torch.empty(P, 4, device=dev), rgb=torch.empty(P, 3, device=dev),
+               tiles_touched=torch.empty(P, dtype=torch.int32, device=dev),
+               clamped=torch.empty(P, 3, dtype=torch.uint8, device=dev),
+               point_list=torch.empty(max(N, 1), dtype=torch.int32, device=dev),
+               ranges=torch.empty(max(tiles, 1), 2, dtype=torch.int32, device=dev),
+               final_T=torch.empty(H, W, device=dev), n_contrib=torch.empty(H, W, dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(lib.ggr_debug_unpack_geom(geom.data_ptr(), P, out["depth"].data_ptr(), out["xy"].data_ptr(),
+                                         out["conic_opacity"].data_ptr(), out["rgb"].data_ptr(),
+                                         out["tiles_touched"].data_ptr(), out["clamped"].data_ptr(), stream),
+               "ggr_debug_unpack_geom")
+        _check(lib.ggr_debug_unpack_binning(_ptr(binb), img.data_ptr(), N, W, H, out["point_list"].data_ptr(),
+                                            out["ranges"].data_ptr(), out["final_T"].data_ptr(),
+                                            out["n_contrib"].data_ptr(), stream), "ggr_debug_unpack_binning")
+    out["point_list"] = out["point_list"][:N]
+    out["ranges"] = out["ranges"][:tiles]
+    return out

@@ -1,0 +1,157 @@
+/*
+ * ggr_raster.h — C ABI of the MI355X-native differentiable Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the ONE native call GGRt makes on its render hot path:
+ *
+ *   reference  ggrt/model/pixelsplat/decoder/cuda_splatting.py:6-9      (import of the extension)
+ *   reference  ggrt/model/pixelsplat/decoder/cuda_splatting.py:101-113  (GaussianRasterizationSettings)
+ *   reference  ggrt/model/pixelsplat/decoder/cuda_splatting.py:114-125  (GaussianRasterizer.forward)
+ *   reference  train_ggrt_stable.py:143                                 (loss.backward() → rasterizer backward)
+ *
+ * In the reference those lines bind (through pybind11) to the third-party CUDA extension
+ * `diff_gaussian_rasterization._C` with the two entry points `rasterize_gaussians` and
+ * `rasterize_gaussians_backward` (+ `mark_visible`, never called by GGRt).  The functions below
+ * replace exactly those entry points; everything is plain C (pointers, sizes, POD structs), no
+ * torch / C++ types, no exceptions across the boundary, no global mutable state (autograd calls
+ * backward from a different thread — SURVEY.md §8b).
+ *
+ * Ownership: every buffer is owned by the caller (in the PyTorch binding: torch tensors).  The
+ * library never hipMalloc's.  The only dynamically sized buffer (binning) is obtained through the
+ * caller's GgrAllocFn after the 4-byte num_rendered readback (the single host sync of forward).
+ *
+ * All device pointers must be valid on the device that `stream` belongs to; fp32 unless noted;
+ * arrays are dense row-major.  All work is enqueued on `stream` (a hipStream_t passed as void*).
+ *
+ * Return value: 0 on success, a GGR_E_* code otherwise; ggr_last_error() returns a thread-local
+ * message.
+ */
+#ifndef GGR_RASTER_H
+#define GGR_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGR_ABI_VERSION 1
+
+enum {
+    GGR_OK = 0,
+    GGR_E_INVALID = 1,   /* bad argument combination (e.g. both/neither of shs & colors_precomp) */
+    GGR_E_HIP = 2,       /* a HIP runtime call or kernel launch failed */
+    GGR_E_ALLOC = 3,     /* the allocator callback returned NULL */
+    GGR_E_LIMIT = 4      /* size beyond what the kernels index (P, N ≥ 2^31, > 65536 tiles) */
+};
+
+/* Mirrors the NamedTuple built at cuda_splatting.py:101-113 (field meaning identical). */
+typedef struct GgrSettings {
+    int32_t image_height;
+    int32_t image_width;
+    int32_t sh_degree;      /* D; bands 0..min(D,3) are evaluated (GGRt passes D=4, M=25) */
+    int32_t sh_stride;      /* M = coefficients per Gaussian in `shs` (0 with colors_precomp) */
+    int32_t num_points;     /* P */
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    const float* bg;         /* device [3] */
+    const float* viewmatrix; /* device [4,4]  = (extrinsics^-1)^T, row-vector convention */
+    const float* projmatrix; /* device [4,4]  = viewmatrix @ P^T */
+    const float* campos;     /* device [3] */
+    int32_t prefiltered;     /* accepted, unused (as at the call site: False) */
+    int32_t debug;           /* 1: synchronise + check after every kernel */
+} GgrSettings;
+
+/* Inputs of GaussianRasterizer.forward (cuda_splatting.py:118-125).
+ * Exactly one of {shs, colors_precomp} and one of {cov3D_precomp, (scales, rotations)}. */
+typedef struct GgrForwardIn {
+    const float* means3D;        /* [P,3] */
+    const float* shs;            /* [P,M,3] or NULL */
+    const float* colors_precomp; /* [P,3]   or NULL */
+    const float* opacities;      /* [P] (the [P,1] tensor of the call site) */
+    const float* scales;         /* [P,3]   or NULL */
+    const float* rotations;      /* [P,4] (r,x,y,z) or NULL */
+    const float* cov3D_precomp;  /* [P,6] (00,01,02,11,12,22) or NULL */
+} GgrForwardIn;
+
+typedef struct GgrForwardOut {
+    float* out_color;      /* [3,H,W] */
+    int32_t* radii;        /* [P] */
+    float* out_depth;      /* [H,W]  Σ z·α·T (third value of the 3-tuple unpacked at :118); may be NULL */
+    void* geom_buffer;     /* ggr_geom_bytes(P) bytes, caller-allocated, kept for backward */
+    void* image_buffer;    /* ggr_image_bytes(W,H) bytes, caller-allocated, kept for backward */
+    void* binning_buffer;  /* OUT: what the allocator returned (kept by the caller for backward) */
+    int64_t num_rendered;  /* OUT: Σ tiles touched = length of the sorted (tile, Gaussian) list */
+} GgrForwardOut;
+
+/* Called once per forward, after num_rendered is known, with ggr_binning_bytes(num_rendered,…).
+ * Must return device memory (256-byte aligned) or NULL. */
+typedef void* (*GgrAllocFn)(void* ctx, size_t bytes);
+
+typedef struct GgrBackwardIn {
+    GgrForwardIn fwd;            /* the same input pointers forward saw */
+    const int32_t* radii;        /* [P] from forward */
+    const void* geom_buffer;
+    const void* image_buffer;
+    const void* binning_buffer;
+    int64_t num_rendered;
+    const float* dL_dout_color;  /* [3,H,W] */
+    const float* dL_dout_depth;  /* [H,W] or NULL (GGRt discards out_depth) */
+    void* scratch;               /* ggr_backward_scratch_bytes(P) bytes, caller-allocated */
+} GgrBackwardIn;
+
+/* Gradients in the order autograd returns them.  Buffers are overwritten
+ * (no need to pre-zero).  NULL = not wanted / not applicable. */
+typedef struct GgrBackwardOut {
+    float* dL_dmeans3D;        /* [P,3] */
+    float* dL_dmeans2D;        /* [P,3] (x,y in NDC units, z = 0) — the `mean_gradients` sink of :95 */
+    float* dL_dshs;            /* [P,M,3] (zero for coefficients ≥ 16) or NULL */
+    float* dL_dcolors_precomp; /* [P,3] or NULL */
+    float* dL_dopacities;      /* [P] */
+    float* dL_dcov3D;          /* [P,6]; always required (scratch for the scale/rot path too) */
+    float* dL_dscales;         /* [P,3] or NULL */
+    float* dL_drotations;      /* [P,4] or NULL */
+    /* Extension beyond the reference: camera gradients.  The reference passes
+     * the matrices inside a NamedTuple, which autograd does not differentiate; these three let
+     * the host chain dL/d(extrinsics) = f(dL/dviewmatrix, dL/dprojmatrix, dL/dcampos).
+     * All three NULL, or all three non-NULL. */
+    float* dL_dviewmatrix;     /* [4,4] or NULL */
+    float* dL_dprojmatrix;     /* [4,4] or NULL */
+    float* dL_dcampos;         /* [3]   or NULL */
+} GgrBackwardOut;
+
+int ggr_abi_version(void);
+const char* ggr_last_error(void);
+
+size_t ggr_geom_bytes(int32_t num_points);
+size_t ggr_image_bytes(int32_t width, int32_t height);
+size_t ggr_binning_bytes(int64_t num_rendered, int32_t width, int32_t height);
+size_t ggr_backward_scratch_bytes(int32_t num_points);
+
+/* replaces diff_gaussian_rasterization._C.rasterize_gaussians */
+int ggr_forward(const GgrSettings* settings, const GgrForwardIn* in, GgrForwardOut* out,
+                GgrAllocFn alloc, void* alloc_ctx, void* stream);
+
+/* replaces diff_gaussian_rasterization._C.rasterize_gaussians_backward */
+int ggr_backward(const GgrSettings* settings, const GgrBackwardIn* in, GgrBackwardOut* out,
+                 void* stream);
+
+/* replaces diff_gaussian_rasterization._C.mark_visible: present[P] (uint8) = view z > 0.2 */
+int ggr_mark_visible(int32_t num_points, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* present, void* stream);
+
+/* Introspection for tests: copies of forward intermediates out of the opaque buffers
+ * (device → device on `stream`).  Any destination may be NULL. */
+int ggr_debug_unpack_geom(const void* geom_buffer, int32_t num_points, float* depth /*[P]*/,
+                          float* xy /*[P,2]*/, float* conic_opacity /*[P,4]*/, float* rgb /*[P,3]*/,
+                          int32_t* tiles_touched /*[P]*/, uint8_t* clamped /*[P,3]*/, void* stream);
+int ggr_debug_unpack_binning(const void* binning_buffer, const void* image_buffer, int64_t num_rendered,
+                             int32_t width, int32_t height, uint32_t* point_list /*[N]*/,
+                             int32_t* ranges /*[tiles,2]*/, float* final_T /*[H,W]*/,
+                             int32_t* n_contrib /*[H,W]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGR_RASTER_H */
