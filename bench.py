@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — Gaussian raster fwd+bwd Mpix/s (BASELINE.json metric) on MI355X.
+
+A "step" = one forward + one backward of the rasterizer over one synthetic frame whose inputs are
+already resident in HBM (BASELINE.json config 3: 1 M Gaussians, 1920×1080, SH degree 3, profile A —
+``ggrt_official_amd/synthetic.py``).  With N > 1 ranks every rank renders its OWN frame (frames shard
+one-per-GPU) and the step ends with the one exchange GGRt's data-parallel training has:
+an RCCL all-reduce of a flat fp32 parameter-gradient buffer sized like GGRt's encoder + pose network
+(≈65 M floats) — the rasterizer's own gradients are per-frame and are not exchanged.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying two extra objects:
+  "roofline":     the dominant kernel's algorithmic bytes / its live HIP-event duration vs 8 TB/s
+  "cpu_baseline": the PyTorch-CPU restatement (oracle/torch_raster.py) timed on this host on a bounded
+                  sample of the same workload (rank 0, N = 1 only)
+
+Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+                 --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (≈6.3 TB/s achievable)
+
+
+def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int) -> dict:
+    """SURVEY.md §8(d) per-unit figures × the units one launch processes."""
+    return {
+        # per-stage split of B_fwd = P(12+24+4+12K) + N(12+12) + N·40 + W·H·20
+        "fwd_preprocess": P * (12 + 24 + 4 + 12 * K),
+        "fwd_binning": N * 24,
+        "fwd_blend": N * 40 + W * H * 20,
+        # B_bwd = W·H·20 + N·40 + P(12+24+4+12K) + P(12+12+24+4+12M)
+        "bwd_blend": W * H * 20 + N * 40,
+        "bwd_preprocess": P * (12 + 24 + 4 + 12 * K) + P * (12 + 12 + 24 + 4 + 12 * M),
+    }
+
+
+def cpu_baseline(cfg: dict, seed: int, budget_s: float = 25.0) -> dict:
+    """Times the PyTorch-CPU restatement (fwd + autograd bwd) on a bounded sample: the full
+    preprocess + binning of the SAME scene, and the blend on every k-th tile row only; the per-frame
+    time is t_pre+bin + k·t_blend(sample) and is reported as such."""
+    from ggrt_official_amd.synthetic import make_scene, upstream_gradient
+    from oracle import torch_raster as tr
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sc = make_scene(seed=seed, **cfg)
+    W, H = sc.width, sc.height
+    gy = (H + 15) // 16
+    leaf = lambda t: t.clone().requires_grad_(True)
+    m, cov, op, sh = leaf(sc.means3D), leaf(sc.cov3D), leaf(sc.opacities), leaf(sc.shs)
+    t0 = time.perf_counter()
+    pre = tr.preprocess(m, op, sc.viewmatrix, sc.projmatrix, sc.campos, W, H, sc.tanfovx, sc.tanfovy,
+                        sc.sh_degree, shs=sh, cov3D_precomp=cov)
+    point_list, ranges, keys, N = tr.bin_tiles(pre, W, H)
+    t_prebin = time.perf_counter() - t0
+    # choose the tile-row stride so that the blend sample fits the budget: probe one row first
+    dL = upstream_gradient(W, H)
+    probe_row = gy // 2
+    t0 = time.perf_counter()
+    color, *_ = tr.blend(pre, point_list, ranges, sc.bg, W, H, tile_filter=lambda tx, ty: ty == probe_row)
+    (color * dL).sum().backward(retain_graph=True)
+    t_row = time.perf_counter() - t0
+    rows = max(1, min(gy, int(budget_s / max(t_row, 1e-3))))
+    stride = max(1, gy // rows)
+    sample_rows = [r for r in range(gy) if r % stride == 0]
+    for t in (m, cov, op, sh):
+        t.grad = None
+    t0 = time.perf_counter()
+    color, *_ = tr.blend(pre, point_list, ranges, sc.bg, W, H, tile_filter=lambda tx, ty: ty % stride == 0)
+    t_blend_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    (color * dL).sum().backward()
+    t_bwd = time.perf_counter() - t0
+    frac = len(sample_rows) / gy
+    t_frame = t_prebin + (t_blend_fwd + t_bwd) / frac
+    return {
+        "value": round(W * H / t_frame / 1e6, 6), "unit": "Mpix/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle/torch_raster.py (PyTorch CPU, fp32, autograd bwd) on the same scene: full preprocess+"
+                   f"sort of P={cfg['num_points']} / N={N} ({t_prebin:.2f}s) + blend fwd+bwd on {len(sample_rows)}/{gy} "
+                   f"tile rows ({t_blend_fwd:.2f}s + {t_bwd:.2f}s, bwd includes the per-Gaussian autograd), "
+                   f"scaled by {1 / frac:.2f} to one frame"),
+        "frame_s_estimated": round(t_frame, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C3", help="key of ggrt_official_amd.synthetic.CONFIGS")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-buffer-floats", type=int, default=65_000_000,
+                    help="size of the all-reduced parameter-gradient stand-in (N>1 only)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="extra untimed steps with per-stage HIP events")
+    args = ap.parse_args()
+
+    from ggrt_official_amd import GaussianRasterizer
+    from ggrt_official_amd.rasterizer import profile_stages
+    from ggrt_official_amd.synthetic import CONFIGS, make_scene, upstream_gradient
+    from ggrt_official_amd import parallel
+
+    rank, world, local = parallel.init_from_env(args.gpus)
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    cfg = CONFIGS[args.config]
+    sc = make_scene(seed=rank, **cfg).to(dev)       # one frame per rank, inputs resident in HBM
+    W, H = sc.width, sc.height
+    dL = upstream_gradient(W, H, seed=1234 + rank, device=dev)
+    rs = sc.settings()
+    rast = GaussianRasterizer(rs)
+    means = sc.means3D.clone().requires_grad_(True)
+    cov = sc.cov3D.clone().requires_grad_(True)
+    op = sc.opacities.clone().requires_grad_(True)
+    shs = sc.shs.clone().requires_grad_(True)
+    means2D = torch.zeros_like(means, requires_grad=True)
+    leaves = (means, cov, op, shs, means2D)
+    grad_buf = torch.zeros(args.grad_buffer_floats, device=dev) if world > 1 else None
+    num_rendered = {}
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        color, radii, depth = rast(means3D=means, means2D=means2D, opacities=op, shs=shs, cov3D_precomp=cov)
+        (color * dL).sum().backward()
+        if world > 1:
+            parallel.allreduce_mean_(grad_buf)
+        return color
+
+    for _ in range(args.warmup):
+        step()
+    parallel.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(elapsed, dev)
+
+    # per-stage HIP-event timing on the launch stream (untimed extra steps)
+    with profile_stages() as prof:
+        for _ in range(max(args.profile_steps, 1)):
+            step()
+    torch.cuda.synchronize(dev)
+    stages = prof.as_dict()
+    # num_rendered of this rank's frame
+    from ggrt_official_amd.rasterizer import debug_forward_state
+    N = debug_forward_state(sc.means3D, sc.opacities, rs, shs=sc.shs, cov3D_precomp=sc.cov3D)["num_rendered"]
+
+    if rank == 0:
+        P = cfg["num_points"]
+        D = cfg["sh_degree"]
+        K = (min(D, 3) + 1) ** 2
+        M = sc.shs.shape[1]
+        ab = algorithmic_bytes(P, N, W, H, K, M)
+        kernel_ms = {"fwd_preprocess": stages["fwd_preprocess_ms"], "fwd_blend": stages["fwd_blend_ms"],
+                     "bwd_blend": stages["bwd_blend_ms"], "bwd_preprocess": stages["bwd_preprocess_ms"]}
+        dom = max(kernel_ms, key=kernel_ms.get)
+        achieved = ab[dom] / (kernel_ms[dom] * 1e-3) / 1e9
+        t_fwd = sum(v for k, v in stages.items() if k.startswith("fwd_"))
+        t_bwd = sum(v for k, v in stages.items() if k.startswith("bwd_"))
+        b_fwd = ab["fwd_preprocess"] + ab["fwd_binning"] + ab["fwd_blend"]
+        b_bwd = ab["bwd_blend"] + ab["bwd_preprocess"]
+        ms_per_step = elapsed / args.steps * 1e3
+        rec = {
+            "metric": "Gaussian raster fwd+bwd Mpix/s @1M Gaussians 1080p",
+            "value": round(world * W * H * args.steps / elapsed / 1e6, 3),
+            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH deg {D}, profile {cfg['profile']}, "
+                                   f"fwd+bwd, 1 frame per GPU" + (f", + RCCL all-reduce of {args.grad_buffer_floats} "
+                                                                 f"fp32 grads" if world > 1 else ""),
+                       "num_rendered": N, "parallelism": f"frames x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes": ab[dom], "kernel_ms": round(kernel_ms[dom], 4),
+                         "note": "blend kernels are fp32-VALU/exp-bound (≈160 flop per list-entry byte), not "
+                                 "HBM-bound; see DESIGN.md §4"},
+            "render_forward": {"ms": round(t_fwd, 4), "algorithmic_bytes": b_fwd,
+                               "hbm_frac": round(b_fwd / (t_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "render_backward": {"ms": round(t_bwd, 4), "algorithmic_bytes": b_bwd,
+                                "hbm_frac": round(b_bwd / (t_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(cfg, seed=0)
+        print(json.dumps(rec), flush=True)
+    parallel.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,7 @@ class GgrForwardOut(C.Structure):
     _fields_ = [
         ("out_color", C.c_void_p), ("radii", C.c_void_p), ("out_depth", C.c_void_p), ("geom_buffer", C.c_void_p),
         ("image_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("num_rendered", C.c_int64),
+        ("stage_ms", C.c_void_p),
     ]
 
 
@@ -52,8 +53,11 @@ class GgrBackwardOut(C.Structure):
         ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
         ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dcov3D", C.c_void_p),
         ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("dL_dviewmatrix", C.c_void_p),
-        ("dL_dprojmatrix", C.c_void_p), ("dL_dcampos", C.c_void_p),
+        ("dL_dprojmatrix", C.c_void_p), ("dL_dcampos", C.c_void_p), ("stage_ms", C.c_void_p),
     ]
+
+FWD_STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend"]
+BWD_STAGES = ["clear", "blend", "preprocess"]
 
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

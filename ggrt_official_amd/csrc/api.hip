@@ -35,6 +35,28 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(GGR_E_HIP, "%s: %s", what, hipGetErrorString(e_));    \
     } while (0)
 
+// Optional per-stage HIP-event timing (profiling mode only: stage_ms != NULL).
+struct StageTimer {
+    hipStream_t s;
+    float* out;
+    int n;
+    hipEvent_t ev[16];
+    int used = 0;
+    StageTimer(hipStream_t s_, float* out_, int n_) : s(s_), out(out_), n(n_) {
+        if (out) for (int i = 0; i <= n; i++) (void)hipEventCreate(&ev[i]);
+        mark();
+    }
+    void mark() { if (out && used <= n) { (void)hipEventRecord(ev[used], s); used++; } }
+    void finish() {
+        if (!out) return;
+        (void)hipStreamSynchronize(s);
+        for (int i = 0; i + 1 < used; i++) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); out[i] += ms; }
+        for (int i = 0; i <= n; i++) (void)hipEventDestroy(ev[i]);
+        out = nullptr;
+    }
+    ~StageTimer() { finish(); }
+};
+
 int ceil_log2(uint32_t v) {
     int b = 0;
     while ((1ull << b) < v) b++;
@@ -88,6 +110,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
 
     GeomLayout g = ggr_carve_geom(out->geom_buffer, (size_t)P);
     ImageLayout im = ggr_carve_image(out->image_buffer, W, H);
+    StageTimer tm(s, out->stage_ms, GGR_FWD_STAGES);
 
     // 1. per-Gaussian projection
     ggr::launch_preprocess_fwd(P, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
@@ -95,6 +118,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
                                st->viewmatrix, st->projmatrix, st->campos, W, H, st->tanfovx, st->tanfovy,
                                out->radii, g, s);
     KCHECK(dbg, s, "preprocess_fwd");
+    tm.mark();
 
     // 2. stable sort of the Gaussians by depth bits (ties keep ascending id)
     uint32_t *dk = nullptr, *order = nullptr;
@@ -104,6 +128,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
         ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, 32, &dk, &order, s);
         KCHECK(dbg, s, "depth sort");
     }
+    tm.mark();
 
     // 3. offsets (inclusive scan of tiles_touched in depth order) and num_rendered
     ggr::launch_scan_tiles(g.tiles_touched, order, g.offsets, g.scan_tmp, g.counters, (size_t)P, s);
@@ -113,6 +138,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     HIP_TRY(hipStreamSynchronize(s));  // the single host sync of forward
     if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
     out->num_rendered = (int64_t)num_rendered;
+    tm.mark();
 
     void* bin_mem = alloc(alloc_ctx, ggr_carve_bin(nullptr, num_rendered).bytes);
     if (!bin_mem) return fail(GGR_E_ALLOC, "binning allocator returned NULL");
@@ -124,6 +150,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     if (num_rendered > 0) {
         ggr::launch_emit_pairs((size_t)P, order, g.offsets, g.tiles_touched, g.rect, gx, b.keys_a, b.vals_a, s);
         KCHECK(dbg, s, "emit_pairs");
+        tm.mark();
         ggr::radix_sort_pairs(b.keys_a, b.keys_b, b.vals_a, b.vals_b, b.hist, num_rendered,
                               ceil_log2((uint32_t)tiles), &tk, &pl, s);
         KCHECK(dbg, s, "tile sort");
@@ -133,13 +160,18 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
         HIP_TRY(hipMemcpyAsync(b.vals_a, pl, (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(b.keys_a, tk, (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, s));
     }
+    if (num_rendered == 0) tm.mark();  // keep stage indices aligned when nothing was emitted
+    tm.mark();
     ggr::launch_tile_ranges(b.keys_a, num_rendered, im.ranges, tiles, s);
     KCHECK(dbg, s, "tile_ranges");
+    tm.mark();
 
     // 7. blend
     ggr::launch_blend_fwd(W, H, im.ranges, b.vals_a, g.splat, st->bg, out->out_color, im.final_T, im.n_contrib,
                           out->out_depth, s);
     KCHECK(dbg, s, "blend_fwd");
+    tm.mark();
+    tm.finish();
     return GGR_OK;
 }
 
@@ -148,7 +180,15 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     if (!in) return fail(GGR_E_INVALID, "null inputs");
     int rc = validate(st, &in->fwd);
     if (rc) return rc;
-    if (!out || !out->dL_dmeans3D || !out->dL_dmeans2D || !out->dL_dopacities || !out->dL_dcov3D)
+    if (!out) return fail(GGR_E_INVALID, "null gradient output struct");
+    if (st->num_points == 0) {  // nothing to differentiate; camera gradients are zero
+        hipStream_t s0 = (hipStream_t)stream;
+        if (out->dL_dviewmatrix) HIP_TRY(hipMemsetAsync(out->dL_dviewmatrix, 0, 64, s0));
+        if (out->dL_dprojmatrix) HIP_TRY(hipMemsetAsync(out->dL_dprojmatrix, 0, 64, s0));
+        if (out->dL_dcampos) HIP_TRY(hipMemsetAsync(out->dL_dcampos, 0, 12, s0));
+        return GGR_OK;
+    }
+    if (!out->dL_dmeans3D || !out->dL_dmeans2D || !out->dL_dopacities || !out->dL_dcov3D)
         return fail(GGR_E_INVALID, "null gradient output");
     if (!in->geom_buffer || !in->image_buffer || !in->scratch || !in->dL_dout_color)
         return fail(GGR_E_INVALID, "null saved buffer / scratch / upstream gradient");
@@ -161,14 +201,6 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     hipStream_t s = (hipStream_t)stream;
     const int P = st->num_points, W = st->image_width, H = st->image_height;
     const bool dbg = st->debug != 0;
-    if (P == 0) {
-        if (npose) {
-            HIP_TRY(hipMemsetAsync(out->dL_dviewmatrix, 0, 64, s));
-            HIP_TRY(hipMemsetAsync(out->dL_dprojmatrix, 0, 64, s));
-            HIP_TRY(hipMemsetAsync(out->dL_dcampos, 0, 12, s));
-        }
-        return GGR_OK;
-    }
     if (in->num_rendered > 0 && !in->binning_buffer) return fail(GGR_E_INVALID, "null binning buffer");
 
     GeomLayout g = ggr_carve_geom((void*)in->geom_buffer, (size_t)P);
@@ -176,16 +208,19 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     BinLayout b = ggr_carve_bin((void*)in->binning_buffer, (size_t)in->num_rendered);
     BwdScratch sc = ggr_carve_bwd(in->scratch, (size_t)P);
 
+    StageTimer tm(s, out->stage_ms, GGR_BWD_STAGES);
     HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));
     HIP_TRY(hipMemsetAsync(out->dL_dmeans2D, 0, (size_t)P * 12, s));
     HIP_TRY(hipMemsetAsync(out->dL_dopacities, 0, (size_t)P * 4, s));
 
+    tm.mark();
     if (in->num_rendered > 0) {
         ggr::launch_blend_bwd(W, H, im.ranges, b.vals_a, g.splat, st->bg, im.final_T, im.n_contrib,
                               in->dL_dout_color, in->dL_dout_depth, out->dL_dmeans2D, sc.dL_dconic,
                               out->dL_dopacities, sc.dL_drgb, in->dL_dout_depth ? sc.dL_dz : nullptr, s);
         KCHECK(dbg, s, "blend_bwd");
     }
+    tm.mark();
     const float* cov = in->fwd.cov3D_precomp ? in->fwd.cov3D_precomp : g.cov3D;
     ggr::launch_preprocess_bwd(P, st->sh_degree, st->sh_stride, in->fwd.means3D, in->fwd.shs, has_cp ? 1 : 0,
                                in->fwd.scales, in->fwd.rotations, st->scale_modifier, cov, st->viewmatrix,
@@ -194,6 +229,7 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
                                out->dL_dmeans2D, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
                                out->dL_dscales, out->dL_drotations, npose ? sc.pose_acc : nullptr, s);
     KCHECK(dbg, s, "preprocess_bwd");
+    tm.mark();
     if (npose) {
         HIP_TRY(hipMemcpyAsync(out->dL_dviewmatrix, sc.pose_acc, 64, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(out->dL_dprojmatrix, sc.pose_acc + 16, 64, hipMemcpyDeviceToDevice, s));

@@ -1,0 +1,91 @@
+"""One-frame-per-GPU data parallelism for the rasterizer hot path.
+
+GGRt's intended (but dead, reference ``train_ggrt_stable.py:322-328``) multi-GPU mode is plain data
+parallelism: ``batch_size = 1`` per process, "use distributed parallel on multiple GPUs to train
+multiple target views per batch" (reference ``ggrt/base/trainer.py:115-117``).  Frames are independent, so
+nothing of the rasterizer's data path is exchanged; the single collective per iteration is the mean
+all-reduce of the parameter gradients of the encoder + pose network.  On MI355X that is one RCCL
+all-reduce over xGMI on a flat fp32 buffer (backend "nccl" IS RCCL on ROCm); on CPU tests it is gloo.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(expected_world: int | None = None, backend: str | None = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run contract) and, for
+    world > 1, creates the process group (RCCL on GPU, gloo on CPU).  Returns (rank, world, local_rank)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if expected_world is not None and expected_world != world:
+        if world == 1 and expected_world > 1:
+            raise RuntimeError(f"--gpus {expected_world} needs a torch.distributed.run launch (WORLD_SIZE={world})")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device(f"cuda:{local}")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def shard_frames(num_frames: int, rank: int, world: int) -> List[int]:
+    """Frame indices owned by `rank`: frame f goes to rank f % world (an 8-frame iteration on 8 GPUs
+    gives one frame each — BASELINE.json config 5)."""
+    return [f for f in range(num_frames) if f % world == rank]
+
+
+def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
+    """In-place mean all-reduce of a flat gradient buffer (one large message: xGMI rings are per-link
+    bound, so one 260 MB collective beats many small ones)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+    return flat
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter]) -> None:
+    """Flatten → one all-reduce → scatter back, for the modules that stay on stock PyTorch
+    (encoder, pose network) and for the camera-pose gradients the rasterizer produces."""
+    ps: Sequence[torch.nn.Parameter] = [p for p in params if p.grad is not None]
+    if not ps or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    allreduce_mean_(flat)
+    o = 0
+    for p in ps:
+        n = p.grad.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -22,7 +22,9 @@ it receives them inside a NamedTuple).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -44,6 +46,50 @@ class GaussianRasterizationSettings(NamedTuple):
     campos: torch.Tensor
     prefiltered: bool
     debug: bool = False
+
+
+class StageProfile:
+    """Per-stage HIP-event timings (ms, accumulated over calls) filled by the library when a
+    ``profile_stages()`` context is active.  Profiling synchronises the stream — never use it inside a
+    timed region."""
+
+    def __init__(self):
+        self.fwd = (C.c_float * len(_lib.FWD_STAGES))()
+        self.bwd = (C.c_float * len(_lib.BWD_STAGES))()
+        self.fwd_calls = 0
+        self.bwd_calls = 0
+
+    def as_dict(self):
+        d = {f"fwd_{n}_ms": self.fwd[i] / max(self.fwd_calls, 1) for i, n in enumerate(_lib.FWD_STAGES)}
+        d.update({f"bwd_{n}_ms": self.bwd[i] / max(self.bwd_calls, 1) for i, n in enumerate(_lib.BWD_STAGES)})
+        return d
+
+
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def profile_stages():
+    prof = StageProfile()
+    prev = getattr(_tls, "prof", None)
+    _tls.prof = prof
+    _active_profiles.append(prof)
+    try:
+        yield prof
+    finally:
+        _tls.prof = prev
+        _active_profiles.remove(prof)
+
+
+_active_profiles: list = []
+
+
+def _current_profile():
+    # autograd runs backward on a worker thread: fall back to the most recent active profile
+    prof = getattr(_tls, "prof", None)
+    if prof is None and _active_profiles:
+        prof = _active_profiles[-1]
+    return prof
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -123,7 +169,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                                     cov3D_precomp=_ptr(cov_c))
             fout = _lib.GgrForwardOut(out_color=color.data_ptr(), radii=_ptr(radii), out_depth=depth.data_ptr(),
                                       geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
-                                      binning_buffer=None, num_rendered=0)
+                                      binning_buffer=None, num_rendered=0, stage_ms=None)
+            prof = _current_profile()
+            if prof is not None:
+                fout.stage_ms = C.cast(prof.fwd, C.c_void_p)
+                prof.fwd_calls += 1
             _check(lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream), "ggr_forward")
 
         ctx.raster_settings = rs
@@ -174,7 +224,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 dL_dmeans3D=d_means3D.data_ptr(), dL_dmeans2D=d_means2D.data_ptr(), dL_dshs=_ptr(d_sh),
                 dL_dcolors_precomp=_ptr(d_cp), dL_dopacities=d_op.data_ptr(), dL_dcov3D=d_cov.data_ptr(),
                 dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot), dL_dviewmatrix=_ptr(d_view),
-                dL_dprojmatrix=_ptr(d_proj), dL_dcampos=_ptr(d_cam))
+                dL_dprojmatrix=_ptr(d_proj), dL_dcampos=_ptr(d_cam), stage_ms=None)
+            prof = _current_profile()
+            if prof is not None:
+                bout.stage_ms = C.cast(prof.bwd, C.c_void_p)
+                prof.bwd_calls += 1
             _check(lib.ggr_backward(C.byref(st), C.byref(bin_), C.byref(bout), stream), "ggr_backward")
 
         means_shape, sh_shape, op_shape = ctx.in_shapes

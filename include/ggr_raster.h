@@ -83,7 +83,17 @@ typedef struct GgrForwardOut {
     void* image_buffer;    /* ggr_image_bytes(W,H) bytes, caller-allocated, kept for backward */
     void* binning_buffer;  /* OUT: what the allocator returned (kept by the caller for backward) */
     int64_t num_rendered;  /* OUT: Σ tiles touched = length of the sorted (tile, Gaussian) list */
+    float* stage_ms;       /* HOST float[GGR_FWD_STAGES] or NULL.  When given, every stage is bracketed
+                              with hipEvents on `stream`, the call synchronises at the end and ADDS the
+                              elapsed milliseconds per stage (profiling only; costs a sync). */
 } GgrForwardOut;
+
+/* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */
+enum {
+    GGR_FWD_PREPROCESS = 0, GGR_FWD_DEPTH_SORT = 1, GGR_FWD_SCAN = 2, GGR_FWD_EMIT = 3,
+    GGR_FWD_TILE_SORT = 4, GGR_FWD_RANGES = 5, GGR_FWD_BLEND = 6, GGR_FWD_STAGES = 7
+};
+enum { GGR_BWD_CLEAR = 0, GGR_BWD_BLEND = 1, GGR_BWD_PREPROCESS = 2, GGR_BWD_STAGES = 3 };
 
 /* Called once per forward, after num_rendered is known, with ggr_binning_bytes(num_rendered,…).
  * Must return device memory (256-byte aligned) or NULL. */
@@ -119,6 +129,7 @@ typedef struct GgrBackwardOut {
     float* dL_dviewmatrix;     /* [4,4] or NULL */
     float* dL_dprojmatrix;     /* [4,4] or NULL */
     float* dL_dcampos;         /* [3]   or NULL */
+    float* stage_ms;           /* HOST float[GGR_BWD_STAGES] or NULL (see GgrForwardOut.stage_ms) */
 } GgrBackwardOut;
 
 int ggr_abi_version(void);

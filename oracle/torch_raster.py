@@ -161,7 +161,7 @@ def bin_tiles(pre, W, H):
     return point_list, ranges, keys, N
 
 
-def blend(pre, point_list, ranges, bg, W, H, want_depth=True):
+def blend(pre, point_list, ranges, bg, W, H, want_depth=True, tile_filter=None):
     """Per-tile front-to-back compositing with the exact skip/stop rules (Appendix A.3),
     vectorised over the tile's pixels × its list."""
     dt = pre["xy"].dtype
@@ -177,7 +177,7 @@ def blend(pre, point_list, ranges, bg, W, H, want_depth=True):
         y0, y1 = tyi * TILE, min(tyi * TILE + TILE, H)
         for txi in range(gx):
             r0, r1 = int(ranges[tyi * gx + txi, 0]), int(ranges[tyi * gx + txi, 1])
-            if r1 <= r0:
+            if r1 <= r0 or (tile_filter is not None and not tile_filter(txi, tyi)):
                 continue
             x0, x1 = txi * TILE, min(txi * TILE + TILE, W)
             ids = point_list[r0:r1]
@@ -235,12 +235,14 @@ def blend(pre, point_list, ranges, bg, W, H, want_depth=True):
 
 def rasterize(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, sh_degree=0,
               shs=None, colors_precomp=None, cov3D_precomp=None, scales=None, rotations=None,
-              scale_modifier=1.0, return_state=False):
-    """Full forward.  Returns (color[3,H,W], radii[P], depth[H,W]) like the boundary's 3-tuple."""
+              scale_modifier=1.0, return_state=False, tile_filter=None):
+    """Full forward.  Returns (color[3,H,W], radii[P], depth[H,W]) like the boundary's 3-tuple.
+    ``tile_filter(tx, ty) -> bool`` restricts the blend to a subset of tiles (bounded CPU-baseline
+    samples only; the other tiles are left at the background colour)."""
     pre = preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh_degree,
                      shs, colors_precomp, cov3D_precomp, scales, rotations, scale_modifier)
     point_list, ranges, keys, N = bin_tiles(pre, W, H)
-    color, final_T, n_contrib, depth_img = blend(pre, point_list, ranges, bg, W, H)
+    color, final_T, n_contrib, depth_img = blend(pre, point_list, ranges, bg, W, H, tile_filter=tile_filter)
     if return_state:
         return color, pre["radii"].to(torch.int32), depth_img, dict(
             pre=pre, point_list=point_list, ranges=ranges, keys=keys, num_rendered=N, final_T=final_T,
