@@ -29,6 +29,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (≈6.3 TB/s achievable)
 
 
@@ -45,18 +50,22 @@ def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int) -> dict:
     }
 
 
-def cpu_baseline(cfg: dict, seed: int, budget_s: float = 25.0) -> dict:
-    """Times the PyTorch-CPU restatement (fwd + autograd bwd) on a bounded sample: the full
-    preprocess + binning of the SAME scene, and the blend on every k-th tile row only; the per-frame
-    time is t_pre+bin + k·t_blend(sample) and is reported as such."""
+def cpu_baseline(cfg: dict, seed: int, budget_s: float = 20.0) -> dict:
+    """Times the PyTorch-CPU restatement (fwd + autograd bwd) on a bounded sample of the SAME scene:
+    the full preprocess + key sort, and the blend fwd+bwd on an evenly strided subset of tiles sized
+    from a 4-tile probe so the whole leg stays within ~budget_s.  The per-frame time is
+    t_pre+sort + t_blend(sample)·tiles/sample and is reported as such (``sample``)."""
     from ggrt_official_amd.synthetic import make_scene, upstream_gradient
     from oracle import torch_raster as tr
 
-    cores = os.cpu_count() or 1
+    # per-tile tensors are small ([list, 256]); beyond a few dozen threads torch's intra-op
+    # parallelism only adds synchronisation cost, so cap the thread count and report what was used
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     sc = make_scene(seed=seed, **cfg)
     W, H = sc.width, sc.height
-    gy = (H + 15) // 16
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ntiles = gx * gy
     leaf = lambda t: t.clone().requires_grad_(True)
     m, cov, op, sh = leaf(sc.means3D), leaf(sc.cov3D), leaf(sc.opacities), leaf(sc.shs)
     t0 = time.perf_counter()
@@ -64,32 +73,37 @@ def cpu_baseline(cfg: dict, seed: int, budget_s: float = 25.0) -> dict:
                         sc.sh_degree, shs=sh, cov3D_precomp=cov)
     point_list, ranges, keys, N = tr.bin_tiles(pre, W, H)
     t_prebin = time.perf_counter() - t0
-    # choose the tile-row stride so that the blend sample fits the budget: probe one row first
+    log(f"cpu_baseline: threads={cores} preprocess+sort {t_prebin:.2f}s N={N}")
     dL = upstream_gradient(W, H)
-    probe_row = gy // 2
-    t0 = time.perf_counter()
-    color, *_ = tr.blend(pre, point_list, ranges, sc.bg, W, H, tile_filter=lambda tx, ty: ty == probe_row)
-    (color * dL).sum().backward(retain_graph=True)
-    t_row = time.perf_counter() - t0
-    rows = max(1, min(gy, int(budget_s / max(t_row, 1e-3))))
-    stride = max(1, gy // rows)
-    sample_rows = [r for r in range(gy) if r % stride == 0]
+
+    def run(stride, offset):
+        sel = lambda tx, ty: (ty * gx + tx) % stride == offset
+        n = len([t for t in range(ntiles) if t % stride == offset])
+        t0 = time.perf_counter()
+        color, *_ = tr.blend(pre, point_list, ranges, sc.bg, W, H, tile_filter=sel)
+        t_f = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        (color * dL).sum().backward(retain_graph=True)
+        return n, t_f, time.perf_counter() - t0
+
+    # probe: ~4 tiles spread over the image (the backward includes the per-Gaussian autograd pass)
+    n_p, tf_p, tb_p = run(max(1, ntiles // 4), (ntiles // 8) % max(1, ntiles // 4))
+    per_tile = (tf_p + max(tb_p - 0.0, 0.0)) / max(n_p, 1)
+    log(f"cpu_baseline: probe {n_p} tiles fwd {tf_p:.2f}s bwd {tb_p:.2f}s")
+    n_target = int(max(4, min(ntiles, budget_s / max(per_tile, 1e-4))))
+    stride = max(1, ntiles // n_target)
     for t in (m, cov, op, sh):
         t.grad = None
-    t0 = time.perf_counter()
-    color, *_ = tr.blend(pre, point_list, ranges, sc.bg, W, H, tile_filter=lambda tx, ty: ty % stride == 0)
-    t_blend_fwd = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    (color * dL).sum().backward()
-    t_bwd = time.perf_counter() - t0
-    frac = len(sample_rows) / gy
-    t_frame = t_prebin + (t_blend_fwd + t_bwd) / frac
+    n_s, t_f, t_b = run(stride, 0)
+    frac = n_s / ntiles
+    t_frame = t_prebin + (t_f + t_b) / frac
+    log(f"cpu_baseline: sample {n_s}/{ntiles} tiles fwd {t_f:.2f}s bwd {t_b:.2f}s -> frame {t_frame:.1f}s")
     return {
         "value": round(W * H / t_frame / 1e6, 6), "unit": "Mpix/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle/torch_raster.py (PyTorch CPU, fp32, autograd bwd) on the same scene: full preprocess+"
-                   f"sort of P={cfg['num_points']} / N={N} ({t_prebin:.2f}s) + blend fwd+bwd on {len(sample_rows)}/{gy} "
-                   f"tile rows ({t_blend_fwd:.2f}s + {t_bwd:.2f}s, bwd includes the per-Gaussian autograd), "
-                   f"scaled by {1 / frac:.2f} to one frame"),
+        "sample": (f"oracle/torch_raster.py (PyTorch CPU fp32, {cores} threads, autograd bwd) on the same scene: "
+                   f"full preprocess+sort of P={cfg['num_points']} / N={N} ({t_prebin:.2f}s) + blend fwd+bwd on "
+                   f"{n_s}/{ntiles} tiles (every {stride}th; {t_f:.2f}s + {t_b:.2f}s, bwd includes the per-Gaussian "
+                   f"autograd), scaled by {1 / frac:.1f} to one frame"),
         "frame_s_estimated": round(t_frame, 3),
     }
 
@@ -138,8 +152,12 @@ def main():
             parallel.allreduce_mean_(grad_buf)
         return color
 
-    for _ in range(args.warmup):
+    log(f"scene {args.config} resident on {dev}; warmup {args.warmup}")
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
         step()
+        torch.cuda.synchronize(dev)
+        log(f"warmup step {i}: {(time.perf_counter() - t_w) * 1e3:.2f} ms")
     parallel.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -149,6 +167,7 @@ def main():
     parallel.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(elapsed, dev)
+    log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.3f} ms/step")
 
     # per-stage HIP-event timing on the launch stream (untimed extra steps)
     with profile_stages() as prof:
@@ -156,6 +175,7 @@ def main():
             step()
     torch.cuda.synchronize(dev)
     stages = prof.as_dict()
+    log("stages: " + ", ".join(f"{k}={v:.3f}" for k, v in stages.items()))
     # num_rendered of this rank's frame
     from ggrt_official_amd.rasterizer import debug_forward_state
     N = debug_forward_state(sc.means3D, sc.opacities, rs, shs=sc.shs, cov3D_precomp=sc.cov3D)["num_rendered"]
