@@ -4,53 +4,55 @@
 // Replaces the backward `renderCUDA` stage of the rasterizer behind reference
 // cuda_splatting.py:114-125 / train_ggrt_stable.py:143.
 //
-// The upstream kernel issues ~9 atomicAdds per (pixel, Gaussian) pair — 64 lanes hitting the
-// same address.  Here each wave64 (an 8×8 pixel quadrant of the tile) reduces its 64 per-pixel
-// partials with DPP row shifts / row broadcasts (no LDS traffic) and issues ONE set of atomics per
-// (wave, Gaussian); entries that cannot reach α ≥ 1/255 anywhere in the quadrant, or that lie
-// behind every pixel's last contributor, are skipped wave-wide before any per-pixel work.
-#include "ggr_common.h"
+// The upstream kernel issues ~9 atomicAdds per (pixel, Gaussian) pair — 64 lanes hitting the same
+// address.  Here each wave64 owns an 8×8 pixel quadrant of the tile and
+//   * drops, wave-wide, every list entry that cannot reach α ≥ 1/255 anywhere in its quadrant (exact
+//     ellipse-vs-box test, lane-per-entry + ballot) or that lies behind every pixel's last contributor;
+//   * processes the survivors in batches of 8: the 9 per-pixel partial sums of the 8 entries (72
+//     registers) are reduced across the 64 lanes with a TRANSPOSING tree — v_permlane32_swap,
+//     v_permlane16_swap, then DPP row_ror:8 / row_half_mirror / quad_perm adds — that costs ≈2.3
+//     VALU ops per (entry, value) instead of 12 for nine independent butterflies;
+//   * ends with lane l holding the wave total of value (l & 7 | 8) of batch slot l >> 3, so the whole
+//     batch is committed with two vector atomic instructions (72 atomics, 64 + 8 lanes).
+#include "blend_common.h"
 
 namespace ggr {
 
-#define BATCH 256
+#define BATCH GGR_BATCH
+#define RB 8  // entries per reduction batch
 
-struct __attribute__((aligned(16))) StagedSplatB {
-    float4 a;  // x, y, conic.xx, conic.xy
-    float4 b;  // conic.yy, opacity, r, g
-    float2 c;  // b, z
-    uint32_t id;
-    uint32_t pad;
-};
-
-template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
-__device__ __forceinline__ float dpp_get(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-// Sum over the 64 lanes of a wave; the total is valid in lane 63.
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v += dpp_get<0x111>(v);              // row_shr:1
-    v += dpp_get<0x112>(v);              // row_shr:2
-    v += dpp_get<0x114>(v);              // row_shr:4
-    v += dpp_get<0x118>(v);              // row_shr:8   → lane 15 of every row holds the row sum
-    v += dpp_get<0x142, 0xa>(v);         // row_bcast:15 into rows 1 and 3
-    v += dpp_get<0x143, 0xc>(v);         // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-__device__ __forceinline__ bool quad_may_contribute_b(float mx, float my, float cxx, float cxy, float cyy,
-                                                      float opacity, float x0, float y0, float x1, float y1) {
-    const float qx = fminf(fmaxf(mx, x0), x1), qy = fminf(fmaxf(my, y0), y1);
-    const float dx = mx - qx, dy = my - qy;
-    const float d2 = dx * dx + dy * dy;
-    if (d2 == 0.f) return true;
-    const float tr = cxx + cyy;
-    const float det = cxx * cyy - cxy * cxy;
-    const float lmin = det / tr;
-    if (!(lmin > 0.f)) return true;
-    const float bound = opacity * __expf(-0.5f * lmin * d2 * 0.999f);
-    return bound >= GGR_ALPHA_MIN * 0.999f;
+// Transposing reduction of v[0..7] over the 64 lanes.  Returns, in every lane l, the sum over all 64
+// lanes of v[l >> 3]  (all 8 lanes of a group hold the same total).
+__device__ __forceinline__ float transpose_reduce8(float (&v)[RB], int lane) {
+    // level 32: lanes 0-31 keep slots 0-3, lanes 32-63 keep slots 4-7
+    float w4[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        w4[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    // level 16: even 16-lane rows keep the lower half of their slots, odd rows the upper half
+    float w2[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w4[i]), __float_as_uint(w4[i + 2]), false, false);
+        w2[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    // level 8: lanes with bit 3 clear keep slot 0 of the pair, the others slot 1 (row_ror:8 = lane ^ 8)
+    const bool hi = (lane & 8) != 0;
+    const float keep = hi ? w2[1] : w2[0];
+    const float send = hi ? w2[0] : w2[1];
+    float s = keep + dpp_mov<0x128>(send);
+    // plain butterflies inside the 8-lane group
+    s += dpp_mov<0xB1>(s);   // quad_perm [1,0,3,2]
+    s += dpp_mov<0x4E>(s);   // quad_perm [2,3,0,1]
+    s += dpp_mov<0x141>(s);  // row_half_mirror
+    return s;
 }
 
 template <bool HAS_DEPTH>
@@ -62,7 +64,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const float* __restrict__ dL_ddepth, float* __restrict__ dL_dmean2D,
                  float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_drgb,
                  float* __restrict__ dL_dz) {
-    __shared__ StagedSplatB stage[BATCH];
+    __shared__ StagedSplat stage[BATCH];
     __shared__ uint32_t wave_last_sh[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,96 +104,119 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accz = 0.f;
     float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lcz = 0.f, last_alpha = 0.f;
 
-    for (int hi = top; hi > 0; hi -= BATCH) {
-        const int nb = min(BATCH, hi);
+    // which of the 9 (10) values this lane commits: value index vi = lane & 7 for the first atomic
+    // instruction; lanes with (lane & 7) == 0 also commit value 8 (opacity) and 9 (depth) afterwards
+    const int vi = lane & 7;
+    const int my_slot = lane >> 3;
+
+    for (int hi_ = top; hi_ > 0; hi_ -= BATCH) {
+        const int nb = min(BATCH, hi_);
         __syncthreads();
         if (tid < nb) {
-            const uint32_t g = point_list[range.x + hi - 1 - tid];
-            const float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1], c = splat[3 * (size_t)g + 2];
+            const uint32_t g = point_list[range.x + hi_ - 1 - tid];
+            const float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1];
+            float4 c = splat[3 * (size_t)g + 2];
+            c.w = __uint_as_float(g);
             stage[tid].a = a;
             stage[tid].b = b;
-            stage[tid].c = make_float2(c.x, c.y);
-            stage[tid].id = g;
+            stage[tid].c = c;
         }
         __syncthreads();
         for (int s0 = 0; s0 < nb; s0 += 64) {
             const int e = s0 + lane;
             bool keep = false;
-            if (e < nb && (uint32_t)(hi - 1 - e) < wl) {
+            if (e < nb && (uint32_t)(hi_ - 1 - e) < wl) {
                 const float4 a = stage[e].a;
                 const float4 b = stage[e].b;
-                keep = quad_may_contribute_b(a.x, a.y, a.z, a.w, b.x, b.y, rx0, ry0, rx1, ry1);
+                keep = box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
             }
             uint64_t m = __ballot(keep);
             while (m) {
-                const int j = __builtin_ctzll(m);
-                m &= m - 1;
-                const int e2 = s0 + j;
-                const uint32_t idx = (uint32_t)(hi - 1 - e2);  // position in the tile list
-                const float4 a = stage[e2].a;
-                const float4 b = stage[e2].b;
-                const float2 c = stage[e2].c;
-                const float dx = a.x - pixx, dy = a.y - pixy;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float G = __expf(power);
-                const float alpha = fminf(GGR_ALPHA_MAX, b.y * G);
-                const bool valid = idx < last && power <= 0.0f && alpha >= GGR_ALPHA_MIN;
-                if (__ballot(valid) == 0ull) continue;
-
-                float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_z = 0.f, g_mx = 0.f, g_my = 0.f, g_cxx = 0.f, g_cxy = 0.f,
-                      g_cyy = 0.f, g_op = 0.f;
-                if (valid) {
-                    const float inv = __frcp_rn(1.f - alpha);
-                    T = T * inv;
-                    const float w = alpha * T;
-                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                    lc0 = b.z; lc1 = b.w; lc2 = c.x;
-                    float dL_dalpha = (b.z - acc0) * dp0 + (b.w - acc1) * dp1 + (c.x - acc2) * dp2;
-                    g_r = w * dp0; g_g = w * dp1; g_b = w * dp2;
-                    if (HAS_DEPTH) {
-                        accz = last_alpha * lcz + (1.f - last_alpha) * accz;
-                        lcz = c.y;
-                        dL_dalpha += (c.y - accz) * dpz;
-                        g_z = w * dpz;
+                // ---- one reduction batch: up to RB surviving entries ---------------------------------
+                float g_r[RB], g_g[RB], g_b[RB], g_mx[RB], g_my[RB], g_cxx[RB], g_cxy[RB], g_cyy[RB], g_op[RB], g_z[RB];
+                uint32_t my_id = 0xFFFFFFFFu;  // Gaussian id of slot `my_slot` (0xFFFFFFFF = empty slot)
+#pragma unroll
+                for (int sl = 0; sl < RB; sl++) {
+                    g_r[sl] = g_g[sl] = g_b[sl] = g_mx[sl] = g_my[sl] = g_cxx[sl] = g_cxy[sl] = g_cyy[sl] = g_op[sl] = 0.f;
+                    g_z[sl] = 0.f;
+                    if (m) {
+                        const int j = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const int e2 = s0 + j;
+                        const uint32_t idx = (uint32_t)(hi_ - 1 - e2);  // position in the tile list
+                        const float4 a = stage[e2].a;
+                        const float4 b = stage[e2].b;
+                        const float4 c = stage[e2].c;
+                        if (my_slot == sl) my_id = __float_as_uint(c.w);
+                        const float dx = a.x - pixx, dy = a.y - pixy;
+                        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                        const float G = __expf(power);
+                        const float alpha = fminf(GGR_ALPHA_MAX, b.y * G);
+                        const bool valid = idx < last && power <= 0.0f && alpha >= GGR_ALPHA_MIN;
+                        if (valid) {
+                            const float inv = __frcp_rn(1.f - alpha);
+                            T = T * inv;
+                            const float w = alpha * T;
+                            acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                            acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                            acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                            lc0 = b.z; lc1 = b.w; lc2 = c.x;
+                            float dL_dalpha = (b.z - acc0) * dp0 + (b.w - acc1) * dp1 + (c.x - acc2) * dp2;
+                            g_r[sl] = w * dp0; g_g[sl] = w * dp1; g_b[sl] = w * dp2;
+                            if (HAS_DEPTH) {
+                                accz = last_alpha * lcz + (1.f - last_alpha) * accz;
+                                lcz = c.y;
+                                dL_dalpha += (c.y - accz) * dpz;
+                                g_z[sl] = w * dpz;
+                            }
+                            dL_dalpha *= T;
+                            last_alpha = alpha;
+                            dL_dalpha += (-T_final * inv) * bg_dot;
+                            const float dL_dG = b.y * dL_dalpha;
+                            const float gdx = G * dx, gdy = G * dy;
+                            const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                            const float dG_ddely = -gdy * b.x - gdx * a.w;
+                            g_mx[sl] = dL_dG * dG_ddelx * ddelx_dx;
+                            g_my[sl] = dL_dG * dG_ddely * ddely_dy;
+                            g_cxx[sl] = -0.5f * gdx * dx * dL_dG;
+                            g_cxy[sl] = -0.5f * gdx * dy * dL_dG;
+                            g_cyy[sl] = -0.5f * gdy * dy * dL_dG;
+                            g_op[sl] = G * dL_dalpha;
+                        }
                     }
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * inv) * bg_dot;
-                    const float dL_dG = b.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                    const float dG_ddely = -gdy * b.x - gdx * a.w;
-                    g_mx = dL_dG * dG_ddelx * ddelx_dx;
-                    g_my = dL_dG * dG_ddely * ddely_dy;
-                    g_cxx = -0.5f * gdx * dx * dL_dG;
-                    g_cxy = -0.5f * gdx * dy * dL_dG;
-                    g_cyy = -0.5f * gdy * dy * dL_dG;
-                    g_op = G * dL_dalpha;
                 }
-                g_r = wave_sum_to_lane63(g_r);
-                g_g = wave_sum_to_lane63(g_g);
-                g_b = wave_sum_to_lane63(g_b);
-                g_mx = wave_sum_to_lane63(g_mx);
-                g_my = wave_sum_to_lane63(g_my);
-                g_cxx = wave_sum_to_lane63(g_cxx);
-                g_cxy = wave_sum_to_lane63(g_cxy);
-                g_cyy = wave_sum_to_lane63(g_cyy);
-                g_op = wave_sum_to_lane63(g_op);
-                if (HAS_DEPTH) g_z = wave_sum_to_lane63(g_z);
-                if (lane == 63) {
-                    const size_t g = stage[e2].id;
-                    atomicAdd(&dL_drgb[3 * g], g_r);
-                    atomicAdd(&dL_drgb[3 * g + 1], g_g);
-                    atomicAdd(&dL_drgb[3 * g + 2], g_b);
-                    atomicAdd(&dL_dmean2D[3 * g], g_mx);
-                    atomicAdd(&dL_dmean2D[3 * g + 1], g_my);
-                    atomicAdd(&dL_dconic[3 * g], g_cxx);
-                    atomicAdd(&dL_dconic[3 * g + 1], g_cxy);
-                    atomicAdd(&dL_dconic[3 * g + 2], g_cyy);
-                    atomicAdd(&dL_dopacity[g], g_op);
-                    if (HAS_DEPTH) atomicAdd(&dL_dz[g], g_z);
+                // ---- transposing reductions: afterwards lane l holds the wave totals of slot l>>3 ----
+                const float t_r = transpose_reduce8(g_r, lane);
+                const float t_g = transpose_reduce8(g_g, lane);
+                const float t_b = transpose_reduce8(g_b, lane);
+                const float t_mx = transpose_reduce8(g_mx, lane);
+                const float t_my = transpose_reduce8(g_my, lane);
+                const float t_cxx = transpose_reduce8(g_cxx, lane);
+                const float t_cxy = transpose_reduce8(g_cxy, lane);
+                const float t_cyy = transpose_reduce8(g_cyy, lane);
+                const float t_op = transpose_reduce8(g_op, lane);
+                float t_z = 0.f;
+                if (HAS_DEPTH) t_z = transpose_reduce8(g_z, lane);
+                // ---- commit: lane (slot, vi) adds value vi of its slot ---------------------------------
+                if (my_id != 0xFFFFFFFFu) {
+                    const size_t g = my_id;
+                    float val;
+                    float* dst;
+                    switch (vi) {
+                        case 0: val = t_r; dst = dL_drgb + 3 * g; break;
+                        case 1: val = t_g; dst = dL_drgb + 3 * g + 1; break;
+                        case 2: val = t_b; dst = dL_drgb + 3 * g + 2; break;
+                        case 3: val = t_mx; dst = dL_dmean2D + 3 * g; break;
+                        case 4: val = t_my; dst = dL_dmean2D + 3 * g + 1; break;
+                        case 5: val = t_cxx; dst = dL_dconic + 3 * g; break;
+                        case 6: val = t_cxy; dst = dL_dconic + 3 * g + 1; break;
+                        default: val = t_cyy; dst = dL_dconic + 3 * g + 2; break;
+                    }
+                    if (val != 0.f) atomicAdd(dst, val);
+                    if (vi == 0 && t_op != 0.f) atomicAdd(dL_dopacity + g, t_op);
+                    if (HAS_DEPTH) {
+                        if (vi == 1 && t_z != 0.f) atomicAdd(dL_dz + g, t_z);
+                    }
                 }
             }
         }

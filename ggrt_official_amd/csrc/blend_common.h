@@ -1,0 +1,41 @@
+// blend_common.h — pieces shared by the forward and backward blend kernels (gfx950).
+#pragma once
+#include "ggr_common.h"
+
+namespace ggr {
+
+#define GGR_BATCH 256
+
+// One staged list entry in LDS: 3 × 16 B, read back as wave-uniform (broadcast) ds_read_b128.
+struct __attribute__((aligned(16))) StagedSplat {
+    float4 a;  // x, y, conic.xx, conic.xy
+    float4 b;  // conic.yy, opacity, r, g
+    float4 c;  // b, z, qmax = 2·ln(255·opacity), id (bits)
+};
+
+// Exact minimum of q(d) = cxx·dx² + 2·cxy·dx·dy + cyy·dy² (d = mean − pixel) over the pixel box
+// [x0,x1]×[y0,y1].  q is convex (the conic is positive definite), so the minimum is 0 if the mean
+// lies in the box and otherwise sits on one of the four edges, where it is a clamped 1-D quadratic.
+__device__ __forceinline__ float box_min_q(float mx, float my, float cxx, float cxy, float cyy, float x0,
+                                           float y0, float x1, float y1) {
+    const float dxl = mx - x1, dxh = mx - x0, dyl = my - y1, dyh = my - y0;
+    if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return 0.f;
+    const float ry = -cxy / cyy, rx = -cxy / cxx;
+    auto qf = [&](float dx, float dy) { return cxx * dx * dx + 2.f * cxy * dx * dy + cyy * dy * dy; };
+    const float q1 = qf(dxl, fminf(fmaxf(ry * dxl, dyl), dyh));
+    const float q2 = qf(dxh, fminf(fmaxf(ry * dxh, dyl), dyh));
+    const float q3 = qf(fminf(fmaxf(rx * dyl, dxl), dxh), dyl);
+    const float q4 = qf(fminf(fmaxf(rx * dyh, dxl), dxh), dyh);
+    return fminf(fminf(q1, q2), fminf(q3, q4));
+}
+
+// Can this entry reach α ≥ 1/255 on any pixel of the box?  α = opacity·exp(−q/2) ≥ 1/255 ⇔
+// q ≤ qmax = 2·ln(255·opacity).  Conservative by a 1e-3 relative + absolute margin, i.e. an entry is
+// dropped only if every pixel of the box would take the reference's `α < 1/255 → continue` branch.
+__device__ __forceinline__ bool box_may_contribute(const float4 a, const float4 b, float qmax, float x0,
+                                                   float y0, float x1, float y1) {
+    const float qmin = box_min_q(a.x, a.y, a.z, a.w, b.x, x0, y0, x1, y1);
+    return qmin * 0.999f <= qmax + 1e-3f;
+}
+
+}  // namespace ggr

@@ -15,38 +15,11 @@
 // quadrant only if α < 1/255 (or power > 0 is impossible) for every pixel of the quadrant, i.e.
 // only entries the per-pixel rule would `continue` past anyway; their list positions are still
 // counted, so n_contrib is unchanged.
-#include "ggr_common.h"
+#include "blend_common.h"
 
 namespace ggr {
 
-#define BATCH 256
-
-struct __attribute__((aligned(16))) StagedSplat {
-    float4 a;  // x, y, conic.xx, conic.xy
-    float4 b;  // conic.yy, opacity, r, g
-    float2 c;  // b, z
-};
-
-// Conservative test: can the Gaussian reach α ≥ 1/255 anywhere in the pixel rect [x0,x1]×[y0,y1]?
-// power(d) = -½ dᵀ Q d with Q = [[cxx, cxy],[cxy, cyy]] (positive definite).  The maximum of
-// power over the rect is attained at the rect point closest to the mean in the Q-metric; we bound
-// it from above cheaply: clamp the mean into the rect (Euclidean closest point p*), and use
-// dᵀQd ≥ λmin·|d|² with λmin ≥ det/(cxx+cyy).  If even that bound gives α < 1/255·(1-ε) the entry
-// cannot contribute.  (Looser than the exact Q-metric distance, but never wrong.)
-__device__ __forceinline__ bool quad_may_contribute(float mx, float my, float cxx, float cxy, float cyy,
-                                                    float opacity, float x0, float y0, float x1, float y1) {
-    const float qx = fminf(fmaxf(mx, x0), x1), qy = fminf(fmaxf(my, y0), y1);
-    const float dx = mx - qx, dy = my - qy;
-    const float d2 = dx * dx + dy * dy;
-    if (d2 == 0.f) return true;
-    const float tr = cxx + cyy;
-    const float det = cxx * cyy - cxy * cxy;
-    const float lmin = det / tr;  // ≤ true λmin; (det, tr > 0 for a valid conic)
-    if (!(lmin > 0.f)) return true;
-    // α ≤ opacity·exp(-½ λmin d²).  keep unless opacity·exp(-½ λmin d²) < (1/255)(1 - 1e-3)
-    const float bound = opacity * __expf(-0.5f * lmin * d2 * 0.999f);
-    return bound >= GGR_ALPHA_MIN * 0.999f;
-}
+#define BATCH GGR_BATCH
 
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
@@ -86,7 +59,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             const float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1], c = splat[3 * (size_t)g + 2];
             stage[tid].a = a;
             stage[tid].b = b;
-            stage[tid].c = make_float2(c.x, c.y);
+            stage[tid].c = c;
         }
         __syncthreads();
         if (!wdone) {
@@ -97,7 +70,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 if (e < nb) {
                     const float4 a = stage[e].a;
                     const float4 b = stage[e].b;
-                    keep = quad_may_contribute(a.x, a.y, a.z, a.w, b.x, b.y, rx0, ry0, rx1, ry1);
+                    keep = box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
                 }
                 uint64_t m = __ballot(keep);
                 while (m) {
@@ -106,7 +79,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                     const int e2 = s0 + j;
                     const float4 a = stage[e2].a;
                     const float4 b = stage[e2].b;
-                    const float2 c = stage[e2].c;
+                    const float4 c = stage[e2].c;
                     const float dx = a.x - pixx, dy = a.y - pixy;
                     const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                     const float alpha = fminf(GGR_ALPHA_MAX, b.y * __expf(power));

@@ -3,7 +3,8 @@
 // Data layout in HBM (all caller-owned, carved out of three opaque buffers; 256-B aligned sections)
 //
 //   geom buffer   (per Gaussian, P entries)
-//     splat[P]         3 × float4 = 48 B  {x, y, conic.xx, conic.xy | conic.yy, opacity, r, g | b, z, 0, 0}
+//     splat[P]         3 × float4 = 48 B  {x, y, conic.xx, conic.xy | conic.yy, opacity, r, g | b, z, qmax, 0}
+//                      (qmax = 2·ln(255·opacity): the largest dᵀ·conic·d at which α still reaches 1/255)
 //                      one record = everything the blend kernels need for a list entry, so a tile-list
 //                      fetch is ONE 48-B gather instead of three gathers from three SoA arrays
 //     depth_key[P]     u32   float bits of view z (0xFFFFFFFF if culled)

@@ -183,7 +183,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 rect_out = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
                 s0 = make_float4(px, py, con0, con1);
                 s1 = make_float4(con2, opacities[i], rgb[0], rgb[1]);
-                s2 = make_float4(rgb[2], t2, 0.f, 0.f);
+                s2 = make_float4(rgb[2], t2, 2.f * logf(255.f * opacities[i]), 0.f);  // .z = qmax for the box cull
             }
         }
     }
