@@ -10,90 +10,111 @@
 //   stable sort by tile id alone (⌈log2 tiles⌉ ≤ 16 bits → 2 passes over N·8 B) yields exactly the
 //   (tile, depth, id) order of the 64-bit sort.
 //
-// The radix sort is hand-written for wave64: per 8-bit digit pass a histogram kernel, a row-scan
-// kernel, and a scatter kernel that ranks stably with ballot-based digit matching (8 ballots per
-// 64 keys) and per-wave digit counters in LDS.
+// The radix sort is hand-written for wave64: one upfront histogram of all digits, then per 8-bit digit
+// ONE kernel ("onesweep") that ranks stably with ballot-based digit matching (8 ballots per 64 keys)
+// + per-wave digit counters in LDS and obtains its tile's global offsets by decoupled look-back.
 #include "ggr_common.h"
 
 namespace ggr {
 
 // ---------------------------------------------------------------------------------------------
-// radix sort
+// radix sort ("onesweep": one kernel per 8-bit digit, decoupled look-back)
 // ---------------------------------------------------------------------------------------------
-// block b owns keys [b*4096, (b+1)*4096); wave w of the block owns a contiguous 1024-key slice,
-// round r of the wave covers 64 consecutive keys → order inside the block is (wave, round, lane).
+// tile t owns keys [t*4096, (t+1)*4096); wave w of the workgroup owns a contiguous 1024-key slice,
+// round r of the wave covers 64 consecutive keys → order inside the tile is (wave, round, lane).
+//
+// Work area `hist` (u32 words):
+//   [0, 1024)                       digit totals of every pass            (global_hist kernel)
+//   [1024, 2048)                    exclusive digit bases of every pass   (global_scan kernel)
+//   [2048, 2048+64)                 tile tickets, one per pass; [2048+8] = spin-timeout flag
+//   [2112 + p*ntiles*256 ...)       look-back status words of pass p: status[tile][digit]
+// Every word that is polled or atomically incremented is zeroed by ONE hipMemsetAsync per sort
+// (MI355X guide §6 G16: re-initialise every call).
+//
+// Look-back protocol (guide §6 G16, recipe R2 — "the data IS the flag"): a status word is
+// (flag << 30) | count with flag 1 = tile aggregate, 2 = inclusive prefix; it is written with ONE
+// relaxed agent-scope atomic store (write-through, leaves the XCD's L2) and polled with relaxed
+// agent-scope atomic loads (bypass the reader's L1), so no fence is needed and no ordering between
+// different words is assumed.  Tiles take their index from an atomic ticket, so a tile only ever
+// waits for tiles whose workgroups are already running: no dispatch-order assumption.
 
-__global__ void __launch_bounds__(GGR_SORT_THREADS)
-radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int shift, uint32_t nblocks,
-                  uint32_t* __restrict__ block_hist /*[256][nblocks]*/, uint32_t* __restrict__ totals /*[256]*/) {
-    __shared__ uint32_t h[GGR_RADIX];
+#define GGR_HIST_TOTALS 0
+#define GGR_HIST_BASES 1024
+#define GGR_HIST_TICKETS 2048
+#define GGR_HIST_STATUS 2112
+#define GGR_FLAG_AGG 1u
+#define GGR_FLAG_INCL 2u
+#define GGR_COUNT_MASK 0x3FFFFFFFu
+#define GGR_SPIN_LIMIT (1u << 24)
+
+// digit totals of all passes in one read of the keys
+__global__ void __launch_bounds__(256)
+radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int npasses, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[4][GGR_RADIX];
     const int tid = threadIdx.x;
-    h[tid] = 0;
-    __syncthreads();
-    const size_t base = (size_t)blockIdx.x * GGR_SORT_TILE;
-    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int r = 0; r < GGR_SORT_ITEMS; r++) {
-        const size_t idx = base + (size_t)wave * (64 * GGR_SORT_ITEMS) + r * 64 + lane;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & (GGR_RADIX - 1)], 1u);
+    for (int p = 0; p < 4; p++) h[p][tid] = 0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + tid; idx < ((n + 255) & ~(size_t)255); idx += stride) {
+        const bool valid = idx < n;
+        const uint32_t k = valid ? keys[idx] : 0u;
+        for (int p = 0; p < npasses; p++) {
+            const uint32_t d = (k >> (8 * p)) & 255u;
+            // wave-aggregate the (very common) case of a digit shared by the whole wave
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            const uint64_t act = __ballot(valid);
+            if (__ballot(valid && d == d0) == act) {
+                if (valid && (uint32_t)__builtin_ctzll(act) == (uint32_t)(tid & 63)) atomicAdd(&h[p][d0], (uint32_t)__popcll(act));
+            } else if (valid) {
+                atomicAdd(&h[p][d], 1u);
+            }
+        }
     }
     __syncthreads();
-    const uint32_t c = h[tid];
-    block_hist[(size_t)tid * nblocks + blockIdx.x] = c;
-    if (c) atomicAdd(&totals[tid], c);
+    for (int p = 0; p < npasses; p++) {
+        const uint32_t c = h[p][tid];
+        if (c) atomicAdd(&hist[GGR_HIST_TOTALS + p * GGR_RADIX + tid], c);
+    }
 }
 
-// one block per digit: exclusive scan of that digit's row over blocks, plus the digit's global base
+// exclusive scan of each pass's 256 totals → digit bases (one block, thread d = digit d)
 __global__ void __launch_bounds__(256)
-radix_scan_kernel(uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ totals, uint32_t nblocks) {
+radix_global_scan_kernel(int npasses, uint32_t* __restrict__ hist) {
     __shared__ uint32_t sh[256];
-    __shared__ uint32_t carry;
     const int tid = threadIdx.x;
-    const int digit = blockIdx.x;
-    // digit base = Σ totals[d' < digit]
-    sh[tid] = tid < digit ? totals[tid] : 0u;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] += sh[tid + s];
-        __syncthreads();
-    }
-    if (tid == 0) carry = sh[0];
-    __syncthreads();
-    uint32_t* row = block_hist + (size_t)digit * nblocks;
-    for (uint32_t start = 0; start < nblocks; start += 256) {
-        const uint32_t i = start + tid;
-        const uint32_t v = i < nblocks ? row[i] : 0u;
-        __syncthreads();
+    for (int p = 0; p < npasses; p++) {
+        const uint32_t v = hist[GGR_HIST_TOTALS + p * GGR_RADIX + tid];
         sh[tid] = v;
         __syncthreads();
-        // Hillis–Steele inclusive scan over 256
         for (int off = 1; off < 256; off <<= 1) {
             const uint32_t t = tid >= off ? sh[tid - off] : 0u;
             __syncthreads();
             sh[tid] += t;
             __syncthreads();
         }
-        const uint32_t incl = sh[tid];
-        const uint32_t c = carry;
-        if (i < nblocks) row[i] = c + incl - v;
-        __syncthreads();
-        if (tid == 255) carry = c + incl;
+        hist[GGR_HIST_BASES + p * GGR_RADIX + tid] = sh[tid] - v;
         __syncthreads();
     }
 }
 
 __global__ void __launch_bounds__(GGR_SORT_THREADS)
-radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
-                     uint32_t nblocks, const uint32_t* __restrict__ block_offs /*[256][nblocks]*/) {
-    __shared__ uint32_t wcount[4][GGR_RADIX];  // per-wave running digit counters, then per-wave bases
+radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int pass,
+                      uint32_t ntiles, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t wcount[4][GGR_RADIX];  // per-wave digit counters, later per-wave output bases
+    __shared__ uint32_t tile_sh;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    const int shift = pass * GGR_RADIX_BITS;
+    if (tid == 0) tile_sh = atomicAdd(&hist[GGR_HIST_TICKETS + pass], 1u);
 #pragma unroll
     for (int w = 0; w < 4; w++) wcount[w][tid] = 0;
     __syncthreads();
+    const uint32_t tile = tile_sh;
+    uint32_t* status = hist + GGR_HIST_STATUS + (size_t)pass * ntiles * GGR_RADIX;
 
-    const size_t base = (size_t)blockIdx.x * GGR_SORT_TILE + (size_t)wave * (64 * GGR_SORT_ITEMS);
+    const size_t base = (size_t)tile * GGR_SORT_TILE + (size_t)wave * (64 * GGR_SORT_ITEMS);
     uint32_t key[GGR_SORT_ITEMS], val[GGR_SORT_ITEMS], rank[GGR_SORT_ITEMS];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -116,7 +137,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
             const uint64_t bal = __ballot(bit);
             m &= bit ? bal : ~bal;
         }
-        // m = valid lanes of this round holding the same digit (meaningful only when valid)
+        // m = valid lanes of this round holding the same digit
         const uint32_t before = (uint32_t)__popcll(m & lt_mask);
         const uint32_t cnt = (uint32_t)__popcll(m);
         uint32_t prev = 0;
@@ -127,10 +148,33 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
         rank[r] = prev + before;
     }
     __syncthreads();
-    // per-digit: turn the 4 per-wave counts into bases (global block offset + prefix over waves)
+    // thread d owns digit d: publish the tile aggregate, look back, publish the inclusive prefix
     {
-        const uint32_t g = block_offs[(size_t)tid * nblocks + blockIdx.x];
-        const uint32_t c0 = wcount[0][tid], c1 = wcount[1][tid], c2 = wcount[2][tid];
+        const uint32_t c0 = wcount[0][tid], c1 = wcount[1][tid], c2 = wcount[2][tid], c3 = wcount[3][tid];
+        const uint32_t total = c0 + c1 + c2 + c3;
+        uint32_t* mine = status + (size_t)tile * GGR_RADIX + tid;
+        __hip_atomic_store(mine, ((tile == 0 ? GGR_FLAG_INCL : GGR_FLAG_AGG) << 30) | total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (tile > 0) {
+            uint32_t t = tile - 1, spins = 0;
+            for (;;) {
+                const uint32_t v = __hip_atomic_load(status + (size_t)t * GGR_RADIX + tid, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t flag = v >> 30;
+                if (flag == 0) {
+                    if (++spins > GGR_SPIN_LIMIT) { hist[GGR_HIST_TICKETS + 8] = 1u; break; }  // never hang
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += v & GGR_COUNT_MASK;
+                if (flag == GGR_FLAG_INCL || t == 0) break;
+                t--;
+            }
+            __hip_atomic_store(mine, (GGR_FLAG_INCL << 30) | ((excl + total) & GGR_COUNT_MASK), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t g = hist[GGR_HIST_BASES + pass * GGR_RADIX + tid] + excl;
         __syncthreads();
         wcount[0][tid] = g;
         wcount[1][tid] = g + c0;
@@ -150,20 +194,22 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     }
 }
 
+size_t radix_hist_words(size_t n) { return GGR_HIST_STATUS + 4 * ggr_sort_blocks(n ? n : 1) * GGR_RADIX; }
+
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                       uint32_t* hist, size_t n, int nbits, uint32_t** keys_out, uint32_t** vals_out,
                       hipStream_t s) {
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
-    if (n > 0) {
-        const uint32_t nblocks = (uint32_t)ggr_sort_blocks(n);
-        uint32_t* totals = hist + (size_t)nblocks * GGR_RADIX;
-        for (int shift = 0; shift < nbits; shift += GGR_RADIX_BITS) {
-            hipMemsetAsync(totals, 0, GGR_RADIX * sizeof(uint32_t), s);
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(GGR_SORT_THREADS), 0, s, kin, n, shift,
-                               nblocks, hist, totals);
-            hipLaunchKernelGGL(radix_scan_kernel, dim3(GGR_RADIX), dim3(256), 0, s, hist, totals, nblocks);
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
-                               kout, vout, n, shift, nblocks, hist);
+    const int npasses = (nbits + GGR_RADIX_BITS - 1) / GGR_RADIX_BITS;
+    if (n > 0 && npasses > 0) {
+        const uint32_t ntiles = (uint32_t)ggr_sort_blocks(n);
+        (void)hipMemsetAsync(hist, 0, (GGR_HIST_STATUS + (size_t)npasses * ntiles * GGR_RADIX) * sizeof(uint32_t), s);
+        const unsigned hist_blocks = (unsigned)min((size_t)2048, (n + 255) / 256);
+        hipLaunchKernelGGL(radix_global_hist_kernel, dim3(hist_blocks), dim3(256), 0, s, kin, n, npasses, hist);
+        hipLaunchKernelGGL(radix_global_scan_kernel, dim3(1), dim3(256), 0, s, npasses, hist);
+        for (int p = 0; p < npasses; p++) {
+            hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(GGR_SORT_THREADS), 0, s, kin, vin, kout,
+                               vout, n, p, ntiles, hist);
             uint32_t* t = kin; kin = kout; kout = t;
             t = vin; vin = vout; vout = t;
         }

@@ -45,6 +45,8 @@
 static inline size_t ggr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) / GGR_SORT_TILE; }
+// words of sort work area: totals + bases + tickets (2112) + 4 passes of look-back status words
+static inline size_t ggr_sort_hist_words(size_t n) { return 2112 + 4 * ggr_sort_blocks(n ? n : 1) * GGR_RADIX; }
 
 struct GeomLayout {
     float4* splat;
@@ -59,7 +61,7 @@ struct GeomLayout {
     uint32_t* keys_b;
     uint32_t* vals_a;
     uint32_t* vals_b;
-    uint32_t* hist;       // [256 * blocks] digit-major + [256] totals
+    uint32_t* hist;       // sort work area (ggr_sort_hist_words)
     uint32_t* scan_tmp;   // block sums for the offsets scan
     uint32_t* counters;   // [64]
     size_t bytes;
@@ -82,7 +84,7 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P) {
     L.keys_b = (uint32_t*)take(Pp * 4);
     L.vals_a = (uint32_t*)take(Pp * 4);
     L.vals_b = (uint32_t*)take(Pp * 4);
-    L.hist = (uint32_t*)take((ggr_sort_blocks(Pp) * GGR_RADIX + GGR_RADIX) * 4);
+    L.hist = (uint32_t*)take(ggr_sort_hist_words(Pp) * 4);
     L.scan_tmp = (uint32_t*)take((ggr_sort_blocks(Pp) + 1) * 4);
     L.counters = (uint32_t*)take(64 * 4);
     L.order = nullptr;
@@ -109,7 +111,7 @@ static inline BinLayout ggr_carve_bin(void* base, size_t N) {
     L.keys_b = (uint32_t*)take(Np * 4);
     L.vals_a = (uint32_t*)take(Np * 4);
     L.vals_b = (uint32_t*)take(Np * 4);
-    L.hist = (uint32_t*)take((ggr_sort_blocks(Np) * GGR_RADIX + GGR_RADIX) * 4);
+    L.hist = (uint32_t*)take(ggr_sort_hist_words(Np) * 4);
     L.bytes = o;
     return L;
 }

@@ -78,7 +78,33 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles_touched,
                       uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
                       float* __restrict__ cov3D_out) {
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_row_stride]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // Cooperative, coalesced staging of the block's SH rows (the per-Gaussian row is 12·K bytes: read
+    // lane-per-Gaussian it would touch 64 different cache lines per load instruction).
+    const int sh_deg = D > 3 ? 3 : D;
+    const int sh_rowf = 3 * (sh_deg + 1) * (sh_deg + 1);
+    const int sh_stride = sh_rowf | 1;  // odd stride → conflict-free per-lane row reads
+    if (shs) {
+        const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+        const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
+        const size_t row = (size_t)M * 3;
+        if ((row & 3) == 0 && (sh_rowf & 3) == 0) {
+            const int q_per = sh_rowf >> 2;
+            for (int j = threadIdx.x; j < nG * q_per; j += blockDim.x) {
+                const int g = j / q_per, q = j - g * q_per;
+                const float4 v = *reinterpret_cast<const float4*>(shs + (g0 + g) * row + 4 * q);
+                float* d = sh_lds + g * sh_stride + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int j = threadIdx.x; j < nG * sh_rowf; j += blockDim.x) {
+                const int g = j / sh_rowf, k = j - g * sh_rowf;
+                sh_lds[g * sh_stride + k] = shs[(g0 + g) * row + k];
+            }
+        }
+        __syncthreads();
+    }
     if (i >= P) return;
     float V[16], PM[16];
 #pragma unroll
@@ -168,7 +194,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     float B[16];
                     sh_basis(deg, d0, d1, d2, B);
                     const int K = (deg + 1) * (deg + 1);
-                    const float* sh = shs + (size_t)i * M * 3;
+                    const float* sh = sh_lds + threadIdx.x * sh_stride;
                     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
                     for (int k = 0; k < K; k++) {
                         r0 += B[k] * sh[3 * k]; r1 += B[k] * sh[3 * k + 1]; r2 += B[k] * sh[3 * k + 2];
@@ -206,7 +232,9 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     if (P <= 0) return;
     const int threads = 256;
     const int blocks = (P + threads - 1) / threads;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), 0, s, P, D, M, means3D, shs,
+    const int deg = D > 3 ? 3 : D;
+    const size_t lds = shs ? (size_t)threads * ((3 * (deg + 1) * (deg + 1)) | 1) * sizeof(float) : 0;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                        viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.depth_key,
                        g.tiles_touched, g.rect, g.clamped, g.cov3D);

@@ -38,9 +38,34 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ pose_acc) {
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_stride]: SH in, dL/dSH out
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
     const bool live = in_range && radii[i] > 0;
+    // coalesced staging of the block's SH rows (same reason as in preprocess_fwd)
+    const int sh_rowf = 3 * ((D > 3 ? 3 : D) + 1) * ((D > 3 ? 3 : D) + 1);
+    const int sh_stride = sh_rowf | 1;
+    const bool use_sh = !has_colors_precomp && shs != nullptr;
+    const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+    const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
+    const size_t sh_row = (size_t)M * 3;
+    if (use_sh) {
+        if ((sh_row & 3) == 0 && (sh_rowf & 3) == 0) {
+            const int q_per = sh_rowf >> 2;
+            for (int j = threadIdx.x; j < nG * q_per; j += blockDim.x) {
+                const int g = j / q_per, q = j - g * q_per;
+                const float4 v = *reinterpret_cast<const float4*>(shs + (g0 + g) * sh_row + 4 * q);
+                float* d = sh_lds + g * sh_stride + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int j = threadIdx.x; j < nG * sh_rowf; j += blockDim.x) {
+                const int g = j / sh_rowf, k = j - g * sh_rowf;
+                sh_lds[g * sh_stride + k] = shs[(g0 + g) * sh_row + k];
+            }
+        }
+        __syncthreads();
+    }
     float V[16], PM[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PM[k] = projmatrix[k]; }
@@ -183,8 +208,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             const float vx = p0 - campos[0], vy = p1 - campos[1], vz = p2 - campos[2];
             const float len = sqrtf(vx * vx + vy * vy + vz * vz);
             const float x = vx / len, y = vy / len, z = vz / len;
-            const float* sh = shs + (size_t)i * M * 3;
-            float* dsh = dL_dsh + (size_t)i * M * 3;
+            float* sh = sh_lds + threadIdx.x * sh_stride;  // read the coefficient, then overwrite it
+            float* dsh = sh;                                // with its gradient (written out below)
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
             // helper: coefficient k with basis value Bk and basis gradient (bx,by,bz)
 #define SH_TERM(k, Bk, bx, by, bz)                                                                     \
@@ -222,7 +247,6 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 }
             }
 #undef SH_TERM
-            for (int k = 3 * K; k < 3 * M; k++) dsh[k] = 0.f;
             const float sum2 = vx * vx + vy * vy + vz * vz;
             const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
             const float gx_ = ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
@@ -268,14 +292,35 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
     } else if (in_range) {
         // culled Gaussian: all gradients are zero
-        if (!has_colors_precomp && dL_dsh) {
-            float* dsh = dL_dsh + (size_t)i * M * 3;
-            for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
+        if (use_sh) {
+            float* dsh = sh_lds + threadIdx.x * sh_stride;
+            for (int k = 0; k < sh_rowf; k++) dsh[k] = 0.f;
         }
         if (has_colors_precomp) { dL_dcolors_precomp[3 * i] = 0.f; dL_dcolors_precomp[3 * i + 1] = 0.f; dL_dcolors_precomp[3 * i + 2] = 0.f; }
         if (scales && dL_dscales) {
             dL_dscales[3 * i] = dL_dscales[3 * i + 1] = dL_dscales[3 * i + 2] = 0.f;
             dL_drotations[4 * i] = dL_drotations[4 * i + 1] = dL_drotations[4 * i + 2] = dL_drotations[4 * i + 3] = 0.f;
+        }
+    }
+    if (use_sh) {
+        // coalesced write-out of dL/dSH: the first 3K floats of every row from LDS, the rest zero
+        __syncthreads();
+        if ((sh_row & 3) == 0 && (sh_rowf & 3) == 0) {
+            const int q_row = (int)(sh_row >> 2), q_used = sh_rowf >> 2;
+            for (int j = threadIdx.x; j < nG * q_row; j += blockDim.x) {
+                const int g = j / q_row, q = j - g * q_row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < q_used) {
+                    const float* d = sh_lds + g * sh_stride + 4 * q;
+                    v = make_float4(d[0], d[1], d[2], d[3]);
+                }
+                *reinterpret_cast<float4*>(dL_dsh + (g0 + g) * sh_row + 4 * q) = v;
+            }
+        } else {
+            for (int j = threadIdx.x; j < nG * (int)sh_row; j += blockDim.x) {
+                const int g = j / (int)sh_row, k = j - g * (int)sh_row;
+                dL_dsh[(g0 + g) * sh_row + k] = k < sh_rowf ? sh_lds[g * sh_stride + k] : 0.f;
+            }
         }
     }
     if (in_range) {
@@ -314,13 +359,15 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            float* dL_drotations, float* pose_acc, hipStream_t s) {
     if (P <= 0) return;
     const int blocks = (P + 255) / 256;
+    const int deg = D > 3 ? 3 : D;
+    const size_t lds = (!has_colors_precomp && shs) ? (size_t)256 * ((3 * (deg + 1) * (deg + 1)) | 1) * sizeof(float) : 0;
     if (pose_acc)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, P, D, M, means3D, shs,
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
                            campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,
                            dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, pose_acc);
     else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, P, D, M, means3D, shs,
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
                            campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,
                            dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, pose_acc);
