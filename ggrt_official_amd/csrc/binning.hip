@@ -204,7 +204,9 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
     if (n > 0 && npasses > 0) {
         const uint32_t ntiles = (uint32_t)ggr_sort_blocks(n);
         (void)hipMemsetAsync(hist, 0, (GGR_HIST_STATUS + (size_t)npasses * ntiles * GGR_RADIX) * sizeof(uint32_t), s);
-        const unsigned hist_blocks = (unsigned)min((size_t)2048, (n + 255) / 256);
+        // one block per CU: the kernel ends with 256·npasses global atomics per block, and at 2048
+        // blocks those ≈2 M contended atomics cost more (≈45 µs) than reading the keys
+        const unsigned hist_blocks = (unsigned)min((size_t)256, (n + 255) / 256);
         hipLaunchKernelGGL(radix_global_hist_kernel, dim3(hist_blocks), dim3(256), 0, s, kin, n, npasses, hist);
         hipLaunchKernelGGL(radix_global_scan_kernel, dim3(1), dim3(256), 0, s, npasses, hist);
         for (int p = 0; p < npasses; p++) {

@@ -1,0 +1,204 @@
+"""Call-site layer: what GGRt wraps around the rasterizer.
+
+Mirrors, with the same names / argument meaning / results, the reference's
+``ggrt/model/pixelsplat/decoder/cuda_splatting.py`` (``get_projection_matrix`` :18-46,
+``render_cuda`` :49-128, ``render_depth_cuda`` :227-269) and
+``decoder/decoder_splatting_cuda.py`` (``DecoderSplattingCUDA`` :19-85), so that GGRt's ``PixelSplat``
+(``pixelsplat.py:144,230``) can use this module unchanged.  Written from the behaviour of those
+functions (pinned by the golden vectors under ``tests/golden/``), not from their text:
+no einops / jaxtyping, all per-view quantities computed batched, no ``.item()`` syncs in the loop
+(``tan(fov/2)`` is derived on the host side once for the whole batch).
+
+Reference quirks kept on purpose (drop-in parity):
+  * the projection matrix uses ``intrinsics[0]`` for EVERY batch element (``cuda_splatting.py:39-42``);
+  * ``scale_invariant`` divides translations / means by ``near`` and covariances by ``near²`` (:66-73);
+  * the depth pass feeds depth as a degree-0 SH coefficient, so the rasterizer returns
+    ``0.5 + C0·z`` per channel and the result is the channel mean (:256-269);
+  * ``sh_degree = isqrt(d_sh) - 1`` (GGRt: d_sh = 25 → 4; bands 0..3 are evaluated).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from math import isqrt
+from typing import Literal, Optional
+
+import torch
+from torch import Tensor, nn
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+DepthRenderingMode = Literal["depth", "disparity", "relative_disparity", "log"]
+
+
+@dataclass
+class Gaussians:
+    """Same fields as reference ``ggrt/model/pixelsplat/types.py:7-12``."""
+    means: Tensor        # [b, g, 3]
+    covariances: Tensor  # [b, g, 3, 3]
+    harmonics: Tensor    # [b, g, 3, d_sh]
+    opacities: Tensor    # [b, g]
+
+
+@dataclass
+class DecoderOutput:
+    color: Tensor            # [b, v, 3, h, w]
+    depth: Optional[Tensor]  # [b, v, h, w]
+
+
+def get_fov(intrinsics: Tensor) -> Tensor:
+    """[b,3,3] normalised intrinsics → [b,2] (fov_x, fov_y): angle between the rays through the
+    mid-points of opposite image edges (reference ``ggrt/geometry/projection.py:233-247``)."""
+    inv = torch.linalg.inv(intrinsics)
+
+    def ray(u, v):
+        p = torch.tensor([u, v, 1.0], dtype=torch.float32, device=intrinsics.device)
+        d = inv @ p
+        return d / d.norm(dim=-1, keepdim=True)
+
+    fov_x = (ray(0.0, 0.5) * ray(1.0, 0.5)).sum(-1).acos()
+    fov_y = (ray(0.5, 0.0) * ray(0.5, 1.0)).sum(-1).acos()
+    return torch.stack((fov_x, fov_y), dim=-1)
+
+
+def get_projection_matrix(near: Tensor, far: Tensor, fov_x: Tensor, fov_y: Tensor, intrinsics: Tensor) -> Tensor:
+    """GGRt-modified perspective matrix [b,4,4] (reference ``cuda_splatting.py:18-46``): X/Y → (-1,1)
+    with an off-centre principal point, Z → (0,1).  ``fov_*`` are accepted for signature parity but,
+    as in the reference, only ``intrinsics[0]`` determines the X/Y rows."""
+    b = near.shape[0]
+    P = torch.zeros((b, 4, 4), dtype=torch.float32, device=near.device)
+    k0 = intrinsics[0]
+    P[:, 0, 0] = 2 * near * k0[0, 0]
+    P[:, 1, 1] = 2 * near * k0[1, 1]
+    P[:, 0, 2] = 2 * k0[0, 2] - 1
+    P[:, 1, 2] = 2 * k0[1, 2] - 1
+    P[:, 3, 2] = 1
+    P[:, 2, 2] = far / (far - near)
+    P[:, 2, 3] = -(far * near) / (far - near)
+    return P
+
+
+_TRIU = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+
+
+def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
+                       gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant=True,
+                       use_sh=True):
+    """Everything ``render_cuda`` hands to the rasterizer, batched: a list of
+    (GaussianRasterizationSettings, kwargs) per view.  Split out so the golden-vector tests can
+    compare it with what the reference's call site produces."""
+    assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
+    if scale_invariant:
+        scale = 1 / near
+        extrinsics = extrinsics.clone()
+        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
+        gaussian_covariances = gaussian_covariances * (scale[:, None, None, None] ** 2)
+        gaussian_means = gaussian_means * scale[:, None, None]
+        near = near * scale
+        far = far * scale
+    d_sh = gaussian_sh_coefficients.shape[-1]
+    degree = isqrt(d_sh) - 1
+    shs = gaussian_sh_coefficients.permute(0, 1, 3, 2).contiguous()  # [b, g, d_sh, 3]
+    b = extrinsics.shape[0]
+    h, w = image_shape
+    fov = get_fov(intrinsics)
+    tan_half = (0.5 * fov).tan()
+    tan_host = tan_half.detach().cpu().tolist()  # ONE device→host copy for the whole batch
+    proj = get_projection_matrix(near, far, fov[:, 0], fov[:, 1], intrinsics).transpose(1, 2)
+    view = torch.linalg.inv(extrinsics).transpose(1, 2)
+    full = view @ proj
+    cov6 = torch.stack([gaussian_covariances[:, :, i, j] for i, j in _TRIU], dim=-1)  # [b, g, 6]
+    out = []
+    for i in range(b):
+        settings = GaussianRasterizationSettings(
+            image_height=h, image_width=w, tanfovx=tan_host[i][0], tanfovy=tan_host[i][1],
+            bg=background_color[i], scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i],
+            sh_degree=degree, campos=extrinsics[i, :3, 3], prefiltered=False)
+        kwargs = dict(means3D=gaussian_means[i], shs=shs[i] if use_sh else None,
+                      colors_precomp=None if use_sh else shs[i, :, 0, :],
+                      opacities=gaussian_opacities[i, ..., None], cov3D_precomp=cov6[i])
+        out.append((settings, kwargs))
+    return out
+
+
+def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape, background_color: Tensor,
+                gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
+                gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True) -> Tensor:
+    """[batch] views → [batch,3,h,w] (reference ``cuda_splatting.py:49-128``)."""
+    images = []
+    for settings, kw in boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color,
+                                           gaussian_means, gaussian_covariances, gaussian_sh_coefficients,
+                                           gaussian_opacities, scale_invariant, use_sh):
+        mean_gradients = torch.zeros_like(kw["means3D"], requires_grad=True)  # the `means2D` gradient sink
+        image, radii, _ = GaussianRasterizer(settings)(means2D=mean_gradients, **kw)
+        images.append(image)
+    return torch.stack(images)
+
+
+def depth_to_relative_disparity(depth, near, far, eps: float = 1e-10):
+    """0 at near, 1 at far (reference ``encoder/epipolar/conversions.py:17-27``)."""
+    disp_near, disp_far, disp = 1 / (near + eps), 1 / (far + eps), 1 / (depth + eps)
+    return 1 - (disp - disp_far) / (disp_near - disp_far + eps)
+
+
+def depth_feature(extrinsics: Tensor, gaussian_means: Tensor, near: Tensor, far: Tensor, mode: DepthRenderingMode):
+    """Camera-space z of every Gaussian, mapped as reference ``cuda_splatting.py:240-252`` maps it."""
+    w2c = torch.linalg.inv(extrinsics)
+    z = (gaussian_means @ w2c[:, 2, :3, None]).squeeze(-1) + w2c[:, 2, 3, None]
+    if mode == "disparity":
+        z = 1 / z
+    elif mode == "relative_disparity":
+        z = depth_to_relative_disparity(z, near[:, None], far[:, None])
+    elif mode == "log":
+        z = z.minimum(near[:, None]).maximum(far[:, None]).log()
+    return z
+
+
+def render_depth_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape,
+                      gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_opacities: Tensor,
+                      scale_invariant: bool = True, mode: DepthRenderingMode = "depth") -> Tensor:
+    """Depth as colour, black background, channel mean → [batch,h,w] (reference ``cuda_splatting.py:227-269``)."""
+    fake_color = depth_feature(extrinsics, gaussian_means, near, far, mode)
+    b = fake_color.shape[0]
+    result = render_cuda(extrinsics, intrinsics, near, far, image_shape,
+                         torch.zeros((b, 3), dtype=fake_color.dtype, device=fake_color.device), gaussian_means,
+                         gaussian_covariances, fake_color[:, :, None, None].expand(-1, -1, 3, 1), gaussian_opacities,
+                         scale_invariant=scale_invariant)
+    return result.mean(dim=1)
+
+
+class DecoderSplattingCUDA(nn.Module):
+    """Same call contract as reference ``decoder_splatting_cuda.py:19-85``:
+    ``forward(gaussians, extrinsics[b,v,4,4], intrinsics[b,v,3,3], near[b,v], far[b,v], image_shape,
+    depth_mode) -> DecoderOutput(color[b,v,3,h,w], depth[b,v,h,w] | None)``."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.cfg = cfg
+        self.register_buffer("background_color", torch.zeros(3, dtype=torch.float32), persistent=False)
+
+    @staticmethod
+    def _per_view(t: Tensor, v: int) -> Tensor:
+        """[b, ...] → [(b v), ...] (every view sees the same Gaussians; the rasterizer only reads them)."""
+        return t[:, None].expand(-1, v, *t.shape[1:]).reshape(-1, *t.shape[1:])
+
+    def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                image_shape, depth_mode: Optional[DepthRenderingMode] = None) -> DecoderOutput:
+        b, v = extrinsics.shape[:2]
+        bg = self.background_color.to(far.device)[None].expand(b * v, 3)
+        color = render_cuda(extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(),
+                            image_shape, bg, self._per_view(gaussians.means, v),
+                            self._per_view(gaussians.covariances, v), self._per_view(gaussians.harmonics, v),
+                            self._per_view(gaussians.opacities, v))
+        color = color.reshape(b, v, *color.shape[1:])
+        depth = None if depth_mode is None else self.render_depth(gaussians, extrinsics, intrinsics, near, far,
+                                                                  image_shape, depth_mode)
+        return DecoderOutput(color, depth)
+
+    def render_depth(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                     image_shape, mode: DepthRenderingMode = "depth") -> Tensor:
+        b, v = extrinsics.shape[:2]
+        result = render_depth_cuda(extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(),
+                                   image_shape, self._per_view(gaussians.means, v),
+                                   self._per_view(gaussians.covariances, v), self._per_view(gaussians.opacities, v),
+                                   mode=mode)
+        return result.reshape(b, v, *result.shape[1:])

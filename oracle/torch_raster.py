@@ -251,11 +251,13 @@ def rasterize(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanf
 
 
 def rasterize_global_sort(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy,
-                          sh_degree=0, shs=None, colors_precomp=None, cov3D_precomp=None):
-    """Deliberately different formulation used as a cross-check: no tiles —
-    every pixel blends ALL visible Gaussians in global (depth, index) order.  Equal to
-    ``rasterize`` wherever the 3σ-radius / tile-rect culling does not bite (a Gaussian outside
-    its rect would have been skipped by the α<1/255 rule anyway when opacity·e^{-4.5} < 1/255)."""
+                          sh_degree=0, shs=None, colors_precomp=None, cov3D_precomp=None, respect_rect=True):
+    """Deliberately different formulation used as a cross-check: no key emission,
+    no per-tile lists, no ranges — every pixel walks ALL visible Gaussians in global (depth, index)
+    order.  With ``respect_rect`` a Gaussian only touches pixels of the tiles in its rect (upstream's
+    `getRect` is not a strict superset of the 3σ disc: its upper bound truncates, so a pixel up to
+    one pixel inside the radius can lie in an excluded tile); without it the result differs from
+    ``rasterize`` exactly on those pixels."""
     pre = preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh_degree,
                      shs, colors_precomp, cov3D_precomp)
     dt = means3D.dtype
@@ -275,6 +277,10 @@ def rasterize_global_sort(means3D, opacities, viewmatrix, projmatrix, campos, bg
         power = -0.5 * (con[0] * dx * dx + con[2] * dy * dy) - con[1] * dx * dy
         alpha = (pre["opacity"][g] * torch.exp(power)).clamp(max=ALPHA_MAX)
         ok = (power <= 0) & (alpha >= ALPHA_MIN) & ~done
+        if respect_rect:
+            rminx, rminy, rmaxx, rmaxy = [int(r[g]) for r in pre["rect"]]
+            tx_, ty_ = (pixx / TILE).floor(), (pixy / TILE).floor()
+            ok = ok & (tx_ >= rminx) & (tx_ < rmaxx) & (ty_ >= rminy) & (ty_ < rmaxy)
         testT = T * (1 - alpha)
         stop = ok & (testT < T_MIN)
         done = done | stop

@@ -1,0 +1,219 @@
+"""Pins the oracle itself (it is the spec here: parity is unpinned by the reference — SURVEY.md §8c).
+
+Two independently written restatements (sequential C with an analytic backward, oracle/ggr_oracle.c;
+vectorised PyTorch with autograd, oracle/torch_raster.py) must agree with each other, with a third
+tile-free formulation, with closed-form known answers and with finite
+differences.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from ggrt_official_amd.synthetic import camera_matrices, make_scene, upstream_gradient
+from oracle import c_oracle, torch_raster as tr
+from tests.helpers import oracle_forward, rel_l2
+
+C0 = 0.28209479177387814
+
+
+def _cam(W=64, H=64, **kw):
+    view, full, campos, tfx, tfy, fx_n, fy_n = camera_matrices(W, H, **kw)
+    return dict(viewmatrix=view.numpy(), projmatrix=full.numpy(), campos=campos.numpy(), W=W, H=H, tanfovx=tfx,
+                tanfovy=tfy), fx_n * W
+
+
+def _iso_cov(sigma_world, n=1):
+    c = np.zeros((n, 6), np.float32)
+    c[:, 0] = c[:, 3] = c[:, 5] = sigma_world ** 2
+    return c
+
+
+def _centre_point(W, H, fpx, z, u=None, v=None):
+    """World point projecting onto pixel centre (u, v) (pixel coordinates are integer-valued)."""
+    u = (W - 1) / 2 if u is None else u
+    v = (H - 1) / 2 if v is None else v
+    return np.array([[(u + 0.5 - W / 2) / fpx * z, (v + 0.5 - H / 2) / fpx * z, z]], np.float32)
+
+
+def test_single_centred_gaussian_closed_form():
+    cam, fpx = _cam(65, 65)
+    z = 5.0
+    for o in (0.3, 0.999):
+        st = c_oracle.forward(_centre_point(65, 65, fpx, z), [[o]], bg=[0.1, 0.2, 0.3], sh_degree=0,
+                              colors_precomp=[[0.9, 0.5, 0.25]], cov3D_precomp=_iso_cov(2.0 * z / fpx), **cam)
+        a = min(0.99, o)
+        np.testing.assert_allclose(st.xy[0], [32.0, 32.0], atol=1e-4)
+        got = st.color[:, 32, 32]
+        want = a * np.array([0.9, 0.5, 0.25]) + (1 - a) * np.array([0.1, 0.2, 0.3])
+        np.testing.assert_allclose(got, want, atol=1e-6)
+        np.testing.assert_allclose(st.final_T[32, 32], 1 - a, atol=1e-7)
+        assert st.n_contrib[32, 32] == 1
+        # σ_screen = 2 px (+0.3 dilation): radius = ceil(3·sqrt(4.3)) = 7
+        assert st.radii[0] == 7
+        np.testing.assert_allclose(st.out_depth[32, 32], a * z, rtol=1e-6)
+
+
+def test_alpha_threshold_skip():
+    cam, fpx = _cam(33, 33)
+    z = 4.0
+    for o, hit in ((1.0 / 255.0 * 0.999, False), (1.0 / 255.0 * 1.01, True)):
+        st = c_oracle.forward(_centre_point(33, 33, fpx, z), [[o]], bg=[0, 0, 0], sh_degree=0,
+                              colors_precomp=[[1, 1, 1]], cov3D_precomp=_iso_cov(1.0 * z / fpx), **cam)
+        assert (st.n_contrib[16, 16] == 1) == hit
+        assert (st.color[0, 16, 16] > 0) == hit
+
+
+def test_transmittance_stop_excludes_the_stopping_entry():
+    cam, fpx = _cam(33, 33)
+    n = 6
+    pts = np.concatenate([_centre_point(33, 33, fpx, 3.0 + i) for i in range(n)])
+    cov = np.concatenate([_iso_cov(3.0 * (3.0 + i) / fpx) for i in range(n)])
+    st = c_oracle.forward(pts, np.full((n, 1), 0.99, np.float32), bg=[0, 0, 0], sh_degree=0,
+                          colors_precomp=np.ones((n, 3), np.float32), cov3D_precomp=cov, **cam)
+    # T after k opaque hits = 0.01^k: 1e-2, 1e-4 (not < 1e-4 in fp32? 0.01f*0.01f = 9.9999994e-05 < 1e-4 → stop)
+    T1 = np.float32(1) * (np.float32(1) - np.float32(0.99))
+    T2 = T1 * (np.float32(1) - np.float32(0.99))
+    expected = 1 if T2 < np.float32(1e-4) else 2
+    assert st.n_contrib[16, 16] == expected
+    np.testing.assert_allclose(st.final_T[16, 16], T1 if expected == 1 else T2, rtol=1e-6)
+
+
+def test_depth_order_and_index_tie_break():
+    cam, fpx = _cam(33, 33)
+    col = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    def run(z0, z1):
+        pts = np.concatenate([_centre_point(33, 33, fpx, z0), _centre_point(33, 33, fpx, z1)])
+        cov = np.concatenate([_iso_cov(2.0 * z0 / fpx), _iso_cov(2.0 * z1 / fpx)])
+        return c_oracle.forward(pts, [[0.6], [0.6]], bg=[0, 0, 0], sh_degree=0, colors_precomp=col, cov3D_precomp=cov, **cam)
+    near_first = run(4.0, 6.0).color[:, 16, 16]
+    far_first = run(6.0, 4.0).color[:, 16, 16]
+    np.testing.assert_allclose(near_first, [0.6, 0.4 * 0.6, 0], atol=1e-6)
+    np.testing.assert_allclose(far_first, [0.4 * 0.6, 0.6, 0], atol=1e-6)
+    st = run(5.0, 5.0)  # equal depth: ascending Gaussian index wins
+    np.testing.assert_allclose(st.color[:, 16, 16], [0.6, 0.4 * 0.6, 0], atol=1e-6)
+    assert list(st.point_list[:2]) == [0, 1]
+
+
+def test_culls_and_empty():
+    cam, fpx = _cam(48, 32)
+    pts = np.array([[0, 0, 0.19], [0, 0, -3.0], [100.0, 0, 5.0], [0, 0, 5.0]], np.float32)
+    st = c_oracle.forward(pts, np.full((4, 1), 0.5), bg=[0.3, 0.3, 0.3], sh_degree=0,
+                          colors_precomp=np.ones((4, 3), np.float32), cov3D_precomp=_iso_cov(0.05, 4), **cam)
+    assert list(st.radii[:3]) == [0, 0, 0] and st.radii[3] > 0
+    assert list(st.tiles_touched[:3]) == [0, 0, 0]
+    st0 = c_oracle.forward(np.zeros((0, 3), np.float32), np.zeros((0, 1), np.float32), bg=[0.3, 0.2, 0.1],
+                           sh_degree=0, colors_precomp=np.zeros((0, 3), np.float32),
+                           cov3D_precomp=np.zeros((0, 6), np.float32), **cam)
+    assert st0.num_rendered == 0
+    np.testing.assert_allclose(st0.color, np.broadcast_to(np.array([0.3, 0.2, 0.1], np.float32)[:, None, None], (3, 32, 48)))
+
+
+def test_principal_point_shift_moves_the_splat():
+    W = H = 64
+    cam0, fpx = _cam(W, H)
+    cam1, _ = _cam(W, H, cx=0.5 + 4 / W, cy=0.5 - 2 / H)
+    p = np.array([[0.0, 0.0, 5.0]], np.float32)
+    kw = dict(bg=[0, 0, 0], sh_degree=0, colors_precomp=[[1, 1, 1]], cov3D_precomp=_iso_cov(0.1))
+    a = c_oracle.forward(p, [[0.5]], **kw, **cam0)
+    b = c_oracle.forward(p, [[0.5]], **kw, **cam1)
+    np.testing.assert_allclose(b.xy[0] - a.xy[0], [4.0, -2.0], atol=1e-4)
+
+
+def test_sh_dc_and_degree4_stride25():
+    sc = make_scene(400, 48, 40, sh_degree=3, seed=3)
+    st3 = oracle_forward(sc)
+    sh25 = torch.zeros(400, 25, 3)
+    sh25[:, :16] = sc.shs
+    sh25[:, 16:] = 123.0  # must be ignored
+    n = lambda t: t.numpy()
+    st4 = c_oracle.forward(n(sc.means3D), n(sc.opacities), n(sc.viewmatrix), n(sc.projmatrix), n(sc.campos), n(sc.bg),
+                           sc.width, sc.height, sc.tanfovx, sc.tanfovy, sh_degree=4, shs=n(sh25), cov3D_precomp=n(sc.cov3D))
+    assert np.array_equal(st3.color, st4.color)
+    g4 = c_oracle.backward(st4, upstream_gradient(48, 40).numpy())
+    assert np.all(g4["shs"][:, 16:] == 0)
+    # degree 0: rgb = max(0, 0.5 + C0·sh0)
+    sc0 = make_scene(50, 32, 32, sh_degree=0, seed=1)
+    st0 = oracle_forward(sc0)
+    vis = st0.radii > 0
+    np.testing.assert_allclose(st0.rgb[vis], np.maximum(0.5 + C0 * sc0.shs[:, 0].numpy()[vis], 0), atol=1e-6)
+
+
+@pytest.mark.parametrize("D,use_cov,seed", [(3, True, 0), (1, False, 1), (0, True, 2)])
+def test_c_oracle_matches_torch_autograd(D, use_cov, seed):
+    sc = make_scene(1500, 80, 64, sh_degree=D, profile="A", seed=seed)
+    dL = upstream_gradient(80, 64, seed=seed)
+    st = oracle_forward(sc, use_cov=use_cov)
+    ref = c_oracle.backward(st, dL.numpy())
+    leaf = lambda t: t.double().clone().requires_grad_(True)
+    m, op, sh = leaf(sc.means3D), leaf(sc.opacities), leaf(sc.shs)
+    kw = dict(cov3D_precomp=leaf(sc.cov3D)) if use_cov else dict(scales=leaf(sc.scales), rotations=leaf(sc.rotations))
+    color, radii, depth, state = tr.rasterize(m, op, sc.viewmatrix.double(), sc.projmatrix.double(), sc.campos.double(),
+                                              sc.bg, 80, 64, sc.tanfovx, sc.tanfovy, D, shs=sh, return_state=True, **kw)
+    assert np.array_equal(radii.numpy(), st.radii)
+    assert np.array_equal(state["point_list"].numpy().astype(np.uint32), st.point_list)
+    assert np.array_equal(state["ranges"].numpy(), st.ranges)
+    np.testing.assert_allclose(color.detach().numpy(), st.color, atol=5e-6)
+    np.testing.assert_allclose(depth.numpy(), st.out_depth, rtol=1e-5, atol=1e-5)
+    assert (state["n_contrib"].numpy() != st.n_contrib).mean() < 1e-3
+    (color * dL.double()).sum().backward()
+    assert rel_l2(ref["means3D"], m.grad.numpy()) < 1e-4
+    assert rel_l2(ref["opacities"], op.grad.numpy()) < 1e-4
+    assert rel_l2(ref["shs"], sh.grad.numpy()) < 1e-4
+    if use_cov:
+        assert rel_l2(ref["cov3D_precomp"], kw["cov3D_precomp"].grad.numpy()) < 1e-4
+    else:
+        assert rel_l2(ref["scales"], kw["scales"].grad.numpy()) < 1e-4
+        assert rel_l2(ref["rotations"], kw["rotations"].grad.numpy()) < 1e-4
+
+
+def test_tile_formulation_equals_global_sort_formulation():
+    sc = make_scene(120, 48, 32, sh_degree=2, profile="A", seed=7)
+    args = (sc.means3D.double(), sc.opacities.double(), sc.viewmatrix.double(), sc.projmatrix.double(),
+            sc.campos.double(), sc.bg, 48, 32, sc.tanfovx, sc.tanfovy, 2)
+    a, _, _ = tr.rasterize(*args, shs=sc.shs.double(), cov3D_precomp=sc.cov3D.double())
+    b = tr.rasterize_global_sort(*args, shs=sc.shs.double(), cov3D_precomp=sc.cov3D.double())
+    np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-9)
+    # without the rect mask the two differ only on the few pixels upstream's truncating getRect drops
+    c = tr.rasterize_global_sort(*args, shs=sc.shs.double(), cov3D_precomp=sc.cov3D.double(), respect_rect=False)
+    assert ((a - c).abs().max(0).values > 1e-9).float().mean() < 0.02
+
+
+def test_gradients_against_finite_differences():
+    sc = make_scene(40, 32, 32, sh_degree=1, profile="A", seed=11)
+    dL = upstream_gradient(32, 32, seed=5).double() * 1e3
+    base = dict(viewmatrix=sc.viewmatrix.double(), projmatrix=sc.projmatrix.double(), campos=sc.campos.double(),
+                bg=sc.bg, W=32, H=32, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, sh_degree=1)
+
+    def loss(m, op, sh, cov):
+        c, _, _ = tr.rasterize(m, op, shs=sh, cov3D_precomp=cov, **base)
+        return (c * dL).sum()
+
+    m, op = sc.means3D.double().requires_grad_(True), sc.opacities.double().requires_grad_(True)
+    sh, cov = sc.shs.double().requires_grad_(True), sc.cov3D.double().requires_grad_(True)
+    loss(m, op, sh, cov).backward()
+    g = torch.Generator().manual_seed(0)
+    eps = 1e-6
+    for name, t in (("means", m), ("opacity", op), ("sh", sh), ("cov", cov)):
+        d = torch.randn(t.shape, generator=g, dtype=torch.float64)
+        if name == "cov":
+            d = d * 1e-3
+        args = {"means": m, "opacity": op, "sh": sh, "cov": cov}
+        plus = {k: (v.detach() + eps * d if k == name else v.detach()) for k, v in args.items()}
+        minus = {k: (v.detach() - eps * d if k == name else v.detach()) for k, v in args.items()}
+        fd = (loss(plus["means"], plus["opacity"], plus["sh"], plus["cov"]) -
+              loss(minus["means"], minus["opacity"], minus["sh"], minus["cov"])) / (2 * eps)
+        an = (t.grad * d).sum()
+        assert abs(float(fd - an)) <= 2e-4 * max(1.0, abs(float(an))), (name, float(fd), float(an))
+
+
+def test_config1_plumbing_cpu_only():
+    """BASELINE config 1: 10k Gaussians, 256×256, SH deg 0, forward only, CPU (no GPU involved)."""
+    sc = make_scene(10_000, 256, 256, sh_degree=0, profile="A", seed=0)
+    st = oracle_forward(sc)
+    assert st.num_rendered > 0 and np.isfinite(st.color).all()
+    color, radii, depth = tr.rasterize(sc.means3D, sc.opacities, sc.viewmatrix, sc.projmatrix, sc.campos, sc.bg, 256,
+                                       256, sc.tanfovx, sc.tanfovy, 0, shs=sc.shs, cov3D_precomp=sc.cov3D)
+    assert np.array_equal(radii.numpy(), st.radii)
+    assert tr.psnr(color, torch.from_numpy(st.color)) > 90
