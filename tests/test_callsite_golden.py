@@ -108,7 +108,7 @@ def _render(inp, shape, kind, extra, dev):
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[9:-4] for p in GOLDEN])
 def test_images_match_reference_callsite_hip(path):
     z, inp, shape, kind, extra = _load(path)
-    out = _render(inp, shape, kind, extra, "cuda:0").cpu().numpy()
+    out = _render(inp, shape, kind, extra, "cuda:0").detach().cpu().numpy()
     ref = z["out_image"]
     d = np.abs(out - ref)
     assert (d > 1e-4).mean() <= 2e-4 and d.max() <= 0.02 * max(1.0, np.abs(ref).max())
