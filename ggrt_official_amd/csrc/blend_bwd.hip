@@ -66,6 +66,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  float* __restrict__ dL_dz) {
     __shared__ StagedSplat stage[BATCH];
     __shared__ uint32_t wave_last_sh[4];
+    __shared__ uint16_t surv[4][BATCH];  // per wave: stage indices of the entries that survive its quadrant cull
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
@@ -122,6 +123,11 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             stage[tid].c = c;
         }
         __syncthreads();
+        // ---- cull: compact this wave's survivors of the whole 256-entry batch into a wave-private list,
+        //      so that every reduction batch below is full (a reduction costs >1000 cycles whether 1 or
+        //      8 of its slots are used)
+        int ns = 0;
+        volatile uint16_t* my_surv = surv[wave];
         for (int s0 = 0; s0 < nb; s0 += 64) {
             const int e = s0 + lane;
             bool keep = false;
@@ -130,90 +136,102 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 const float4 b = stage[e].b;
                 keep = box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
             }
-            uint64_t m = __ballot(keep);
-            while (m) {
+            const uint64_t mk = __ballot(keep);
+            if (keep) my_surv[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)e;
+            ns += __popcll(mk);
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            for (int k0 = 0; k0 < ns; k0 += RB) {
                 // ---- one reduction batch: up to RB surviving entries ---------------------------------
-                float g_r[RB], g_g[RB], g_b[RB], g_mx[RB], g_my[RB], g_cxx[RB], g_cxy[RB], g_cyy[RB], g_op[RB], g_z[RB];
-                uint32_t my_id = 0xFFFFFFFFu;  // Gaussian id of slot `my_slot` (0xFFFFFFFF = empty slot)
+                // Per pixel only RAW MOMENTS are formed: with m = G·dL/dα (zero on skipped lanes)
+                //   S0 = Σm, Sx = Σm·dx, Sy = Σm·dy, Sxx = Σm·dx², Sxy = Σm·dx·dy, Syy = Σm·dy²
+                // and the per-Gaussian algebra (× opacity, × conic, × W/2 …) is done ONCE per entry after the
+                // wave reduction.  A skipped lane is treated as α = 0: T·1/(1-0), w = 0 and the "colour
+                // behind" recurrence acc ← last_α·last_c + (1-last_α)·acc becomes the identity at the next
+                // entry (last_α = 0), which is exactly the reference's `continue` — no per-value selects.
+                float g_r[RB], g_g[RB], g_b[RB], g_m[RB], g_mx[RB], g_my[RB], g_mxx[RB], g_mxy[RB], g_myy[RB], g_z[RB];
+                int my_e = -1;  // stage index of slot `my_slot` (-1 = empty slot)
+                // slot → stage index, resolved with scalar ops first so that the 8 slot bodies below are
+                // straight-line code: the compiler can batch their LDS broadcast reads and overlap slot
+                // k+1's geometry with slot k's dependent T / colour-behind chain
+                int e_sl[RB];
+                bool ok_sl[RB];
 #pragma unroll
                 for (int sl = 0; sl < RB; sl++) {
-                    g_r[sl] = g_g[sl] = g_b[sl] = g_mx[sl] = g_my[sl] = g_cxx[sl] = g_cxy[sl] = g_cyy[sl] = g_op[sl] = 0.f;
-                    g_z[sl] = 0.f;
-                    if (m) {
-                        const int j = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const int e2 = s0 + j;
+                    ok_sl[sl] = k0 + sl < ns;
+                    e_sl[sl] = my_surv[ok_sl[sl] ? k0 + sl : 0];  // empty slot: any staged entry, masked by ok_sl
+                    if (ok_sl[sl] && my_slot == sl) my_e = e_sl[sl];
+                }
+#pragma unroll
+                for (int sl = 0; sl < RB; sl++) {
+                    {
+                        const int e2 = e_sl[sl];
                         const uint32_t idx = (uint32_t)(hi_ - 1 - e2);  // position in the tile list
                         const float4 a = stage[e2].a;
                         const float4 b = stage[e2].b;
                         const float4 c = stage[e2].c;
-                        if (my_slot == sl) my_id = __float_as_uint(c.w);
                         const float dx = a.x - pixx, dy = a.y - pixy;
                         const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                         const float G = __expf(power);
-                        const float alpha = fminf(GGR_ALPHA_MAX, b.y * G);
-                        const bool valid = idx < last && power <= 0.0f && alpha >= GGR_ALPHA_MIN;
-                        if (valid) {
-                            const float inv = __frcp_rn(1.f - alpha);
-                            T = T * inv;
-                            const float w = alpha * T;
-                            acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                            acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                            acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                            lc0 = b.z; lc1 = b.w; lc2 = c.x;
-                            float dL_dalpha = (b.z - acc0) * dp0 + (b.w - acc1) * dp1 + (c.x - acc2) * dp2;
-                            g_r[sl] = w * dp0; g_g[sl] = w * dp1; g_b[sl] = w * dp2;
-                            if (HAS_DEPTH) {
-                                accz = last_alpha * lcz + (1.f - last_alpha) * accz;
-                                lcz = c.y;
-                                dL_dalpha += (c.y - accz) * dpz;
-                                g_z[sl] = w * dpz;
-                            }
-                            dL_dalpha *= T;
-                            last_alpha = alpha;
-                            dL_dalpha += (-T_final * inv) * bg_dot;
-                            const float dL_dG = b.y * dL_dalpha;
-                            const float gdx = G * dx, gdy = G * dy;
-                            const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                            const float dG_ddely = -gdy * b.x - gdx * a.w;
-                            g_mx[sl] = dL_dG * dG_ddelx * ddelx_dx;
-                            g_my[sl] = dL_dG * dG_ddely * ddely_dy;
-                            g_cxx[sl] = -0.5f * gdx * dx * dL_dG;
-                            g_cxy[sl] = -0.5f * gdx * dy * dL_dG;
-                            g_cyy[sl] = -0.5f * gdy * dy * dL_dG;
-                            g_op[sl] = G * dL_dalpha;
+                        const float alpha_raw = fminf(GGR_ALPHA_MAX, b.y * G);
+                        const bool valid = ok_sl[sl] && idx < last && power <= 0.0f && alpha_raw >= GGR_ALPHA_MIN;
+                        const float alpha = valid ? alpha_raw : 0.f;
+                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32 (1 ulp); __frcp_rn would expand to a 10-instruction IEEE division
+                        T = T * inv;
+                        const float w = alpha * T;
+                        acc0 += last_alpha * (lc0 - acc0);
+                        acc1 += last_alpha * (lc1 - acc1);
+                        acc2 += last_alpha * (lc2 - acc2);
+                        lc0 = b.z; lc1 = b.w; lc2 = c.x;
+                        float dL_dalpha = (b.z - acc0) * dp0 + (b.w - acc1) * dp1 + (c.x - acc2) * dp2;
+                        g_r[sl] = w * dp0; g_g[sl] = w * dp1; g_b[sl] = w * dp2;
+                        if (HAS_DEPTH) {
+                            accz += last_alpha * (lcz - accz);
+                            lcz = c.y;
+                            dL_dalpha += (c.y - accz) * dpz;
+                            g_z[sl] = w * dpz;
                         }
+                        last_alpha = alpha;
+                        dL_dalpha = dL_dalpha * T - (T_final * inv) * bg_dot;
+                        const float mm = valid ? G * dL_dalpha : 0.f;
+                        const float mdx = mm * dx, mdy = mm * dy;
+                        g_m[sl] = mm; g_mx[sl] = mdx; g_my[sl] = mdy;
+                        g_mxx[sl] = mdx * dx; g_mxy[sl] = mdx * dy; g_myy[sl] = mdy * dy;
                     }
                 }
                 // ---- transposing reductions: afterwards lane l holds the wave totals of slot l>>3 ----
                 const float t_r = transpose_reduce8(g_r, lane);
                 const float t_g = transpose_reduce8(g_g, lane);
                 const float t_b = transpose_reduce8(g_b, lane);
-                const float t_mx = transpose_reduce8(g_mx, lane);
-                const float t_my = transpose_reduce8(g_my, lane);
-                const float t_cxx = transpose_reduce8(g_cxx, lane);
-                const float t_cxy = transpose_reduce8(g_cxy, lane);
-                const float t_cyy = transpose_reduce8(g_cyy, lane);
-                const float t_op = transpose_reduce8(g_op, lane);
+                const float S0 = transpose_reduce8(g_m, lane);
+                const float Sx = transpose_reduce8(g_mx, lane);
+                const float Sy = transpose_reduce8(g_my, lane);
+                const float Sxx = transpose_reduce8(g_mxx, lane);
+                const float Sxy = transpose_reduce8(g_mxy, lane);
+                const float Syy = transpose_reduce8(g_myy, lane);
                 float t_z = 0.f;
                 if (HAS_DEPTH) t_z = transpose_reduce8(g_z, lane);
-                // ---- commit: lane (slot, vi) adds value vi of its slot ---------------------------------
-                if (my_id != 0xFFFFFFFFu) {
-                    const size_t g = my_id;
+                // ---- commit: lane (slot, vi) finishes and adds value vi of its slot ---------------------
+                if (my_e >= 0) {
+                    const float4 a = stage[my_e].a;
+                    const float4 b = stage[my_e].b;
+                    const size_t g = __float_as_uint(stage[my_e].c.w);
+                    const float op = b.y;
                     float val;
                     float* dst;
                     switch (vi) {
                         case 0: val = t_r; dst = dL_drgb + 3 * g; break;
                         case 1: val = t_g; dst = dL_drgb + 3 * g + 1; break;
                         case 2: val = t_b; dst = dL_drgb + 3 * g + 2; break;
-                        case 3: val = t_mx; dst = dL_dmean2D + 3 * g; break;
-                        case 4: val = t_my; dst = dL_dmean2D + 3 * g + 1; break;
-                        case 5: val = t_cxx; dst = dL_dconic + 3 * g; break;
-                        case 6: val = t_cxy; dst = dL_dconic + 3 * g + 1; break;
-                        default: val = t_cyy; dst = dL_dconic + 3 * g + 2; break;
+                        case 3: val = -op * (a.z * Sx + a.w * Sy) * ddelx_dx; dst = dL_dmean2D + 3 * g; break;
+                        case 4: val = -op * (b.x * Sy + a.w * Sx) * ddely_dy; dst = dL_dmean2D + 3 * g + 1; break;
+                        case 5: val = -0.5f * op * Sxx; dst = dL_dconic + 3 * g; break;
+                        case 6: val = -0.5f * op * Sxy; dst = dL_dconic + 3 * g + 1; break;
+                        default: val = -0.5f * op * Syy; dst = dL_dconic + 3 * g + 2; break;
                     }
                     if (val != 0.f) atomicAdd(dst, val);
-                    if (vi == 0 && t_op != 0.f) atomicAdd(dL_dopacity + g, t_op);
+                    if (vi == 0 && S0 != 0.f) atomicAdd(dL_dopacity + g, S0);
                     if (HAS_DEPTH) {
                         if (vi == 1 && t_z != 0.f) atomicAdd(dL_dz + g, t_z);
                     }
