@@ -28,7 +28,7 @@ class GgrSettings(C.Structure):
 class GgrForwardIn(C.Structure):
     _fields_ = [
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
-        ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+        ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("aux_precomp", C.c_void_p),
     ]
 
 
@@ -52,7 +52,8 @@ class GgrBackwardOut(C.Structure):
     _fields_ = [
         ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
         ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dcov3D", C.c_void_p),
-        ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("dL_dviewmatrix", C.c_void_p),
+        ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("dL_daux", C.c_void_p),
+        ("dL_dviewmatrix", C.c_void_p),
         ("dL_dprojmatrix", C.c_void_p), ("dL_dcampos", C.c_void_p), ("stage_ms", C.c_void_p),
     ]
 

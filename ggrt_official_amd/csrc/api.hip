@@ -115,7 +115,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     // 1. per-Gaussian projection
     ggr::launch_preprocess_fwd(P, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
                                in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
-                               st->viewmatrix, st->projmatrix, st->campos, W, H, st->tanfovx, st->tanfovy,
+                               in->aux_precomp, st->viewmatrix, st->projmatrix, st->campos, W, H, st->tanfovx, st->tanfovy,
                                out->radii, g, s);
     KCHECK(dbg, s, "preprocess_fwd");
     tm.mark();
@@ -196,6 +196,7 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     if (has_cp ? !out->dL_dcolors_precomp : !out->dL_dshs) return fail(GGR_E_INVALID, "null colour gradient output");
     const bool has_sr = in->fwd.scales != nullptr;
     if (has_sr && (!out->dL_dscales || !out->dL_drotations)) return fail(GGR_E_INVALID, "null scale/rotation gradient output");
+    if (in->fwd.aux_precomp && in->dL_dout_depth && !out->dL_daux) return fail(GGR_E_INVALID, "null dL_daux output");
     const int npose = (out->dL_dviewmatrix != nullptr) + (out->dL_dprojmatrix != nullptr) + (out->dL_dcampos != nullptr);
     if (npose != 0 && npose != 3) return fail(GGR_E_INVALID, "camera gradients: give all three outputs or none");
     hipStream_t s = (hipStream_t)stream;
@@ -227,7 +228,8 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
                                st->projmatrix, st->campos, W, H, st->tanfovx, st->tanfovy, in->radii, g.clamped,
                                sc.dL_dconic, sc.dL_drgb, in->dL_dout_depth ? sc.dL_dz : nullptr, out->dL_dmeans3D,
                                out->dL_dmeans2D, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
-                               out->dL_dscales, out->dL_drotations, npose ? sc.pose_acc : nullptr, s);
+                               out->dL_dscales, out->dL_drotations, in->fwd.aux_precomp ? out->dL_daux : nullptr,
+                               npose ? sc.pose_acc : nullptr, s);
     KCHECK(dbg, s, "preprocess_bwd");
     tm.mark();
     if (npose) {

@@ -169,9 +169,9 @@ namespace ggr {
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
-                           const float* viewmatrix, const float* projmatrix, const float* campos, int W,
-                           int H, float tanfovx, float tanfovy, int32_t* radii, GeomLayout g,
-                           hipStream_t s);
+                           const float* aux_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* campos, int W, int H, float tanfovx, float tanfovy, int32_t* radii,
+                           GeomLayout g, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 val) pairs on bits [0, nbits); returns the buffers that
 // hold the result (either a or b)
@@ -209,7 +209,7 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            const float* dL_dconic, const float* dL_drgb, const float* dL_dz,
                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dsh,
                            float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
-                           float* dL_drotations, float* pose_acc, hipStream_t s);
+                           float* dL_drotations, float* dL_daux, float* pose_acc, hipStream_t s);
 
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                          hipStream_t s);

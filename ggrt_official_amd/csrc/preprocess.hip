@@ -72,6 +72,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       float scale_modifier, const float* __restrict__ cov3D_precomp,
+                      const float* __restrict__ aux_precomp,
                       const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
                       const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
                       int32_t* __restrict__ radii, float4* __restrict__ splat,
@@ -209,7 +210,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 rect_out = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
                 s0 = make_float4(px, py, con0, con1);
                 s1 = make_float4(con2, opacities[i], rgb[0], rgb[1]);
-                s2 = make_float4(rgb[2], t2, 2.f * logf(255.f * opacities[i]), 0.f);  // .z = qmax for the box cull
+                s2 = make_float4(rgb[2], aux_precomp ? aux_precomp[i] : t2, 2.f * logf(255.f * opacities[i]), 0.f);  // .z = qmax for the box cull
             }
         }
     }
@@ -226,9 +227,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
-                           const float* viewmatrix, const float* projmatrix, const float* campos, int W,
-                           int H, float tanfovx, float tanfovy, int32_t* radii, GeomLayout g,
-                           hipStream_t s) {
+                           const float* aux_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* campos, int W, int H, float tanfovx, float tanfovy, int32_t* radii,
+                           GeomLayout g, hipStream_t s) {
     if (P <= 0) return;
     const int threads = 256;
     const int blocks = (P + threads - 1) / threads;
@@ -236,7 +237,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     const size_t lds = shs ? (size_t)threads * ((3 * (deg + 1) * (deg + 1)) | 1) * sizeof(float) : 0;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
-                       viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.depth_key,
+                       aux_precomp, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.depth_key,
                        g.tiles_touched, g.rect, g.clamped, g.cov3D);
 }
 

@@ -37,7 +37,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
-                      float* __restrict__ dL_drotations, float* __restrict__ pose_acc) {
+                      float* __restrict__ dL_drotations, float* __restrict__ dL_daux,
+                      float* __restrict__ pose_acc) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_stride]: SH in, dL/dSH out
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
@@ -190,7 +191,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
 
         // depth-as-feature gradient: z = t2 = [p 1]·V[:,2]
-        if (dL_dz) {
+        if (dL_dz && !dL_daux) {
             const float gz = dL_dz[i];
             dmean[0] += V[2] * gz; dmean[1] += V[6] * gz; dmean[2] += V[10] * gz;
             if (POSE) { dV[2] += p0 * gz; dV[6] += p1 * gz; dV[10] += p2 * gz; dV[14] += gz; }
@@ -323,6 +324,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             }
         }
     }
+    if (in_range && dL_daux) dL_daux[i] = (live && dL_dz) ? dL_dz[i] : 0.f;  // aux feature: gradient is the blend's
     if (in_range) {
         dL_dmeans3D[3 * i] = dmean[0]; dL_dmeans3D[3 * i + 1] = dmean[1]; dL_dmeans3D[3 * i + 2] = dmean[2];
 #pragma unroll
@@ -356,7 +358,7 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            const float* dL_dconic, const float* dL_drgb, const float* dL_dz,
                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dsh,
                            float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
-                           float* dL_drotations, float* pose_acc, hipStream_t s) {
+                           float* dL_drotations, float* dL_daux, float* pose_acc, hipStream_t s) {
     if (P <= 0) return;
     const int blocks = (P + 255) / 256;
     const int deg = D > 3 ? 3 : D;
@@ -365,12 +367,12 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
                            campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,
-                           dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, pose_acc);
+                           dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
     else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
                            campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,
-                           dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, pose_acc);
+                           dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
 }
 
 }  // namespace ggr

@@ -128,7 +128,7 @@ def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                viewmatrix, projmatrix, campos, raster_settings):
+                viewmatrix, projmatrix, campos, aux, raster_settings):
         lib = _lib.load()
         rs = raster_settings
         dev = means3D.device
@@ -141,6 +141,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         sh_c, cp_c = _f32c(sh), _f32c(colors_precomp)
         op_c = _f32c(opacities)
         sc_c, rot_c, cov_c = _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
+        aux_c = _f32c(aux)
         M = 0 if sh_c is None else int(sh_c.shape[1])
         bg = _f32c(rs.bg.to(dev))
         view, proj, cam = _f32c(viewmatrix.to(dev)), _f32c(projmatrix.to(dev)), _f32c(campos.to(dev))
@@ -166,7 +167,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             st = _settings_struct(rs, P, M, bg, view, proj, cam)
             fin = _lib.GgrForwardIn(means3D=_ptr(means3D_c), shs=_ptr(sh_c), colors_precomp=_ptr(cp_c),
                                     opacities=_ptr(op_c), scales=_ptr(sc_c), rotations=_ptr(rot_c),
-                                    cov3D_precomp=_ptr(cov_c))
+                                    cov3D_precomp=_ptr(cov_c), aux_precomp=_ptr(aux_c))
             fout = _lib.GgrForwardOut(out_color=color.data_ptr(), radii=_ptr(radii), out_depth=depth.data_ptr(),
                                       geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
                                       binning_buffer=None, num_rendered=0, stage_ms=None)
@@ -179,10 +180,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = int(fout.num_rendered)
         ctx.dims = (P, M, H, W)
-        ctx.in_shapes = (means3D.shape, None if sh is None else sh.shape, opacities.shape)
+        ctx.in_shapes = (means3D.shape, None if sh is None else sh.shape, opacities.shape,
+                         None if aux is None else aux.shape)
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         ctx.save_for_backward(means3D_c, sh_c, cp_c, op_c, sc_c, rot_c, cov_c, bg, view, proj, cam, radii, geom,
-                              img, holder.get("bin"))
+                              img, holder.get("bin"), aux_c)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth
 
@@ -190,7 +192,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_color, _grad_radii, grad_depth):
         lib = _lib.load()
         rs = ctx.raster_settings
-        (means3D, sh, cp, op, sc, rot, cov, bg, view, proj, cam, radii, geom, img, binb) = ctx.saved_tensors
+        (means3D, sh, cp, op, sc, rot, cov, bg, view, proj, cam, radii, geom, img, binb, aux) = ctx.saved_tensors
         P, M, H, W = ctx.dims
         dev = means3D.device
         need_pose = any(ctx.needs_input_grad[8:11])
@@ -208,6 +210,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_cp = torch.empty((P, 3), dtype=torch.float32, device=dev) if cp is not None else None
             d_sc = torch.empty((P, 3), dtype=torch.float32, device=dev) if sc is not None else None
             d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev) if rot is not None else None
+            d_aux = torch.empty((P,), dtype=torch.float32, device=dev) if (aux is not None and grad_depth is not None) else None
             d_view = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pose else None
             d_proj = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pose else None
             d_cam = torch.empty((3,), dtype=torch.float32, device=dev) if need_pose else None
@@ -216,14 +219,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             st = _settings_struct(rs, P, M, bg, view, proj, cam)
             bin_ = _lib.GgrBackwardIn(
                 fwd=_lib.GgrForwardIn(means3D=_ptr(means3D), shs=_ptr(sh), colors_precomp=_ptr(cp), opacities=_ptr(op),
-                                      scales=_ptr(sc), rotations=_ptr(rot), cov3D_precomp=_ptr(cov)),
+                                      scales=_ptr(sc), rotations=_ptr(rot), cov3D_precomp=_ptr(cov),
+                                      aux_precomp=_ptr(aux)),
                 radii=_ptr(radii), geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
                 binning_buffer=_ptr(binb), num_rendered=ctx.num_rendered, dL_dout_color=grad_color.data_ptr(),
                 dL_dout_depth=_ptr(grad_depth), scratch=scratch.data_ptr())
             bout = _lib.GgrBackwardOut(
                 dL_dmeans3D=d_means3D.data_ptr(), dL_dmeans2D=d_means2D.data_ptr(), dL_dshs=_ptr(d_sh),
                 dL_dcolors_precomp=_ptr(d_cp), dL_dopacities=d_op.data_ptr(), dL_dcov3D=d_cov.data_ptr(),
-                dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot), dL_dviewmatrix=_ptr(d_view),
+                dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot), dL_daux=_ptr(d_aux), dL_dviewmatrix=_ptr(d_view),
                 dL_dprojmatrix=_ptr(d_proj), dL_dcampos=_ptr(d_cam), stage_ms=None)
             prof = _current_profile()
             if prof is not None:
@@ -231,7 +235,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 prof.bwd_calls += 1
             _check(lib.ggr_backward(C.byref(st), C.byref(bin_), C.byref(bout), stream), "ggr_backward")
 
-        means_shape, sh_shape, op_shape = ctx.in_shapes
+        means_shape, sh_shape, op_shape, aux_shape = ctx.in_shapes
         has_sh, has_cp, has_sc, has_cov = ctx.has
         return (
             d_means3D.reshape(means_shape),
@@ -245,16 +249,17 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_view if ctx.needs_input_grad[8] else None,
             d_proj if ctx.needs_input_grad[9] else None,
             d_cam.reshape(ctx.saved_tensors[10].shape) if ctx.needs_input_grad[10] else None,
+            d_aux.reshape(aux_shape) if d_aux is not None else None,
             None,
         )
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
-    """Function form, argument order of upstream's ``rasterize_gaussians``."""
+                        raster_settings, aux_precomp=None):
+    """Function form, argument order of upstream's ``rasterize_gaussians`` (+ the optional aux feature)."""
     rs = raster_settings
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.campos, rs)
+                                     cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.campos, aux_precomp, rs)
 
 
 class GaussianRasterizer(nn.Module):
@@ -282,7 +287,10 @@ class GaussianRasterizer(nn.Module):
         return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, aux_precomp=None):
+        """``aux_precomp`` [P] (extension, optional): a 4th feature blended like a colour channel; the third
+        return value then is Σ aux·α·T instead of Σ z·α·T (one rasterization serves GGRt's colour AND depth
+        pass — see ``splatting.render_color_and_depth``)."""
         shs, colors_precomp = _none_if_empty(shs), _none_if_empty(colors_precomp)
         scales, rotations, cov3D_precomp = _none_if_empty(scales), _none_if_empty(rotations), _none_if_empty(cov3D_precomp)
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
@@ -291,7 +299,7 @@ class GaussianRasterizer(nn.Module):
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, self.raster_settings)
+                                   cov3D_precomp, self.raster_settings, aux_precomp)
 
 
 def debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_precomp=None, cov3D_precomp=None,
@@ -309,7 +317,7 @@ def debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_pr
     with torch.no_grad():
         color, radii, depth = _RasterizeGaussians.forward(ctx, means3D, torch.zeros_like(means3D), shs, colors_precomp,
                                                           opacities, scales, rotations, cov3D_precomp, rs.viewmatrix,
-                                                          rs.projmatrix, rs.campos, rs)
+                                                          rs.projmatrix, rs.campos, None, rs)
     P, M, H, W = ctx.dims
     dev = means3D.device
     geom, img, binb = ctx.saved[12], ctx.saved[13], ctx.saved[14]

@@ -166,14 +166,44 @@ def render_depth_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far:
     return result.mean(dim=1)
 
 
+SH_C0 = 0.28209479177387814
+
+
+def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape,
+                           background_color: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
+                           gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor,
+                           depth_mode: DepthRenderingMode = "depth", scale_invariant: bool = True,
+                           use_sh: bool = True):
+    """ONE rasterization per view for what the reference obtains from two:
+    ``render_cuda`` (colour, :49-128) + ``render_depth_cuda`` (:227-269).
+
+    The reference's depth pass re-runs preprocess + sort + blend with the depth feature as a degree-0 SH
+    coefficient, i.e. every Gaussian contributes ``max(0.5 + C0·f(z), 0)`` per channel over a black
+    background, and the three identical channels are averaged.  Here that per-Gaussian value is handed to
+    the rasterizer as its 4th blended feature (``aux_precomp``), so the depth image is the aux image of the
+    SAME pass: identical values and gradients, half the work.  Returns ([b,3,h,w], [b,h,w])."""
+    feat = depth_feature(extrinsics, gaussian_means, near, far, depth_mode)  # unscaled, as the reference
+    aux = (0.5 + SH_C0 * feat).clamp(min=0.0)
+    images, depths = [], []
+    for i, (settings, kw) in enumerate(boundary_arguments(
+            extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means, gaussian_covariances,
+            gaussian_sh_coefficients, gaussian_opacities, scale_invariant, use_sh)):
+        mean_gradients = torch.zeros_like(kw["means3D"], requires_grad=True)
+        image, radii, aux_image = GaussianRasterizer(settings)(means2D=mean_gradients, aux_precomp=aux[i], **kw)
+        images.append(image)
+        depths.append(aux_image)
+    return torch.stack(images), torch.stack(depths)
+
+
 class DecoderSplattingCUDA(nn.Module):
     """Same call contract as reference ``decoder_splatting_cuda.py:19-85``:
     ``forward(gaussians, extrinsics[b,v,4,4], intrinsics[b,v,3,3], near[b,v], far[b,v], image_shape,
     depth_mode) -> DecoderOutput(color[b,v,3,h,w], depth[b,v,h,w] | None)``."""
 
-    def __init__(self, cfg=None):
+    def __init__(self, cfg=None, fused_depth: bool = True):
         super().__init__()
         self.cfg = cfg
+        self.fused_depth = fused_depth  # False: two rasterizations per view, literally as the reference
         self.register_buffer("background_color", torch.zeros(3, dtype=torch.float32), persistent=False)
 
     @staticmethod
@@ -185,6 +215,12 @@ class DecoderSplattingCUDA(nn.Module):
                 image_shape, depth_mode: Optional[DepthRenderingMode] = None) -> DecoderOutput:
         b, v = extrinsics.shape[:2]
         bg = self.background_color.to(far.device)[None].expand(b * v, 3)
+        if depth_mode is not None and self.fused_depth:
+            color, depth = render_color_and_depth(
+                extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(), image_shape, bg,
+                self._per_view(gaussians.means, v), self._per_view(gaussians.covariances, v),
+                self._per_view(gaussians.harmonics, v), self._per_view(gaussians.opacities, v), depth_mode)
+            return DecoderOutput(color.reshape(b, v, *color.shape[1:]), depth.reshape(b, v, *depth.shape[1:]))
         color = render_cuda(extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(),
                             image_shape, bg, self._per_view(gaussians.means, v),
                             self._per_view(gaussians.covariances, v), self._per_view(gaussians.harmonics, v),

@@ -73,12 +73,17 @@ typedef struct GgrForwardIn {
     const float* scales;         /* [P,3]   or NULL */
     const float* rotations;      /* [P,4] (r,x,y,z) or NULL */
     const float* cov3D_precomp;  /* [P,6] (00,01,02,11,12,22) or NULL */
+    const float* aux_precomp;    /* [P] or NULL — extension: a 4th per-Gaussian feature blended like a colour
+                                    channel into out_depth (Σ aux·α·T).  NULL ⇒ the feature is view-space z.
+                                    Lets a host get GGRt's depth pass (cuda_splatting.py:227-269) out of the
+                                    SAME rasterization as the colour pass. */
 } GgrForwardIn;
 
 typedef struct GgrForwardOut {
     float* out_color;      /* [3,H,W] */
     int32_t* radii;        /* [P] */
-    float* out_depth;      /* [H,W]  Σ z·α·T (third value of the 3-tuple unpacked at :118); may be NULL */
+    float* out_depth;      /* [H,W]  Σ f·α·T with f = view z (or aux_precomp): third value of the 3-tuple
+                              unpacked at :118; may be NULL */
     void* geom_buffer;     /* ggr_geom_bytes(P) bytes, caller-allocated, kept for backward */
     void* image_buffer;    /* ggr_image_bytes(W,H) bytes, caller-allocated, kept for backward */
     void* binning_buffer;  /* OUT: what the allocator returned (kept by the caller for backward) */
@@ -122,6 +127,7 @@ typedef struct GgrBackwardOut {
     float* dL_dcov3D;          /* [P,6]; always required (scratch for the scale/rot path too) */
     float* dL_dscales;         /* [P,3] or NULL */
     float* dL_drotations;      /* [P,4] or NULL */
+    float* dL_daux;            /* [P]; required iff aux_precomp was given and dL_dout_depth != NULL */
     /* Extension beyond the reference: camera gradients.  The reference passes
      * the matrices inside a NamedTuple, which autograd does not differentiate; these three let
      * the host chain dL/d(extrinsics) = f(dL/dviewmatrix, dL/dprojmatrix, dL/dcampos).

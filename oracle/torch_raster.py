@@ -161,7 +161,7 @@ def bin_tiles(pre, W, H):
     return point_list, ranges, keys, N
 
 
-def blend(pre, point_list, ranges, bg, W, H, want_depth=True, tile_filter=None):
+def blend(pre, point_list, ranges, bg, W, H, want_depth=True, tile_filter=None, aux=None):
     """Per-tile front-to-back compositing with the exact skip/stop rules (Appendix A.3),
     vectorised over the tile's pixels × its list."""
     dt = pre["xy"].dtype
@@ -207,17 +207,18 @@ def blend(pre, point_list, ranges, bg, W, H, want_depth=True, tile_filter=None):
             c = (w[:, :, None] * pre["rgb"][ids][:, None, :]).sum(0)  # [pix,3]
             c = c + Tfin[:, None] * bg[None]
             pieces.append((y0, y1, x0, x1, c, Tfin, last,
-                           (w * pre["depth"][ids].to(dt)[:, None]).sum(0) if want_depth else None))
+                           (w * (pre["depth"] if aux is None else aux)[ids].to(dt)[:, None]).sum(0) if want_depth else None))
     # assemble without in-place ops on a graph tensor
     if pieces:
         canvas = [[None] * gx for _ in range(gy)]
+        dcanvas = [[None] * gx for _ in range(gy)]
         for (y0, y1, x0, x1, c, Tfin, last, dz) in pieces:
             h, w_ = y1 - y0, x1 - x0
             canvas[y0 // TILE][x0 // TILE] = c.T.reshape(3, h, w_)
             final_T[y0:y1, x0:x1] = Tfin.detach().reshape(h, w_)
             n_contrib[y0:y1, x0:x1] = last.reshape(h, w_)
             if dz is not None:
-                depth_img[y0:y1, x0:x1] = dz.detach().reshape(h, w_)
+                dcanvas[y0 // TILE][x0 // TILE] = dz.reshape(h, w_)
         rows = []
         for tyi in range(gy):
             y0, y1 = tyi * TILE, min(tyi * TILE + TILE, H)
@@ -230,19 +231,30 @@ def blend(pre, point_list, ranges, bg, W, H, want_depth=True, tile_filter=None):
                 row.append(blk)
             rows.append(torch.cat(row, 2))
         color = torch.cat(rows, 1)
+        if want_depth:  # differentiable assembly of the 4th (depth / aux) channel
+            drows = []
+            for tyi in range(gy):
+                y0, y1 = tyi * TILE, min(tyi * TILE + TILE, H)
+                drow = []
+                for txi in range(gx):
+                    x0, x1 = txi * TILE, min(txi * TILE + TILE, W)
+                    blk = dcanvas[tyi][txi]
+                    drow.append(blk if blk is not None else torch.zeros(y1 - y0, x1 - x0, dtype=dt))
+                drows.append(torch.cat(drow, 1))
+            depth_img = torch.cat(drows, 0)
     return color, final_T, n_contrib, depth_img
 
 
 def rasterize(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, sh_degree=0,
               shs=None, colors_precomp=None, cov3D_precomp=None, scales=None, rotations=None,
-              scale_modifier=1.0, return_state=False, tile_filter=None):
+              scale_modifier=1.0, return_state=False, tile_filter=None, aux=None):
     """Full forward.  Returns (color[3,H,W], radii[P], depth[H,W]) like the boundary's 3-tuple.
     ``tile_filter(tx, ty) -> bool`` restricts the blend to a subset of tiles (bounded CPU-baseline
     samples only; the other tiles are left at the background colour)."""
     pre = preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh_degree,
                      shs, colors_precomp, cov3D_precomp, scales, rotations, scale_modifier)
     point_list, ranges, keys, N = bin_tiles(pre, W, H)
-    color, final_T, n_contrib, depth_img = blend(pre, point_list, ranges, bg, W, H, tile_filter=tile_filter)
+    color, final_T, n_contrib, depth_img = blend(pre, point_list, ranges, bg, W, H, tile_filter=tile_filter, aux=aux)
     if return_state:
         return color, pre["radii"].to(torch.int32), depth_img, dict(
             pre=pre, point_list=point_list, ranges=ranges, keys=keys, num_rendered=N, final_T=final_T,

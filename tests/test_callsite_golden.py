@@ -37,11 +37,11 @@ class _OracleRasterizer(torch.nn.Module):
         self.rs = rs
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, aux_precomp=None):
         rs = self.rs
         return tr.rasterize(means3D, opacities, rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg, rs.image_width,
                             rs.image_height, rs.tanfovx, rs.tanfovy, rs.sh_degree, shs=shs,
-                            colors_precomp=colors_precomp, cov3D_precomp=cov3D_precomp)
+                            colors_precomp=colors_precomp, cov3D_precomp=cov3D_precomp, aux=aux_precomp)
 
 
 def test_golden_files_present():
@@ -131,3 +131,48 @@ def test_decoder_module_cpu(monkeypatch):
                                 torch.zeros(v, 3), inp["gaussian_means"], inp["gaussian_covariances"],
                                 inp["gaussian_sh_coefficients"], inp["gaussian_opacities"])
     assert torch.allclose(out.color[0], ref, atol=1e-6)
+
+
+def _decoder_case():
+    z, inp, shape, kind, extra = _load([p for p in GOLDEN if "color_d25" in p][0])
+    v = inp["extrinsics"].shape[0]
+    gs = splatting.Gaussians(means=inp["gaussian_means"][:1], covariances=inp["gaussian_covariances"][:1],
+                             harmonics=inp["gaussian_sh_coefficients"][:1], opacities=inp["gaussian_opacities"][:1])
+    args = (inp["extrinsics"][None], inp["intrinsics"][None], inp["near"][None], inp["far"][None], shape)
+    return gs, args, v
+
+
+@pytest.mark.parametrize("mode", ["depth", "disparity", "relative_disparity", "log"])
+def test_fused_colour_depth_equals_two_passes_cpu(monkeypatch, mode):
+    """one rasterization with the aux feature == the reference's colour pass + depth pass."""
+    monkeypatch.setattr(splatting, "GaussianRasterizer", _OracleRasterizer)
+    gs, args, v = _decoder_case()
+    two = splatting.DecoderSplattingCUDA(fused_depth=False)(gs, *args, depth_mode=mode)
+    one = splatting.DecoderSplattingCUDA(fused_depth=True)(gs, *args, depth_mode=mode)
+    assert torch.allclose(one.color, two.color, atol=1e-6)
+    assert torch.allclose(one.depth, two.depth, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["depth", "relative_disparity"])
+def test_fused_colour_depth_equals_two_passes_hip_with_gradients(mode):
+    gs, args, v = _decoder_case()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(0)
+    wc = torch.randn(1, v, 3, *args[4], generator=g).to(dev)
+    wd = torch.randn(1, v, *args[4], generator=g).to(dev)
+    grads = []
+    outs = []
+    for fused in (False, True):
+        leaves = [t.clone().to(dev).requires_grad_(True) for t in (gs.means, gs.covariances, gs.harmonics, gs.opacities)]
+        gg = splatting.Gaussians(*leaves)
+        out = splatting.DecoderSplattingCUDA(fused_depth=fused).to(dev)(gg, *[a.to(dev) if torch.is_tensor(a) else a for a in args],
+                                                                       depth_mode=mode)
+        ((out.color * wc).sum() + (out.depth * wd).sum()).backward()
+        grads.append([t.grad.cpu().numpy() for t in leaves])
+        outs.append((out.color.detach().cpu().numpy(), out.depth.detach().cpu().numpy()))
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-5
+    assert (np.abs(outs[0][1] - outs[1][1]) > 1e-4).mean() < 1e-3
+    for a, b in zip(*grads):
+        rel = np.linalg.norm(a - b) / max(np.linalg.norm(a), 1e-30)
+        assert rel < 1e-3, rel

@@ -155,7 +155,7 @@ def test_c_oracle_matches_torch_autograd(D, use_cov, seed):
     assert np.array_equal(state["point_list"].numpy().astype(np.uint32), st.point_list)
     assert np.array_equal(state["ranges"].numpy(), st.ranges)
     np.testing.assert_allclose(color.detach().numpy(), st.color, atol=5e-6)
-    np.testing.assert_allclose(depth.numpy(), st.out_depth, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(depth.detach().numpy(), st.out_depth, rtol=1e-5, atol=1e-5)
     assert (state["n_contrib"].numpy() != st.n_contrib).mean() < 1e-3
     (color * dL.double()).sum().backward()
     assert rel_l2(ref["means3D"], m.grad.numpy()) < 1e-4
