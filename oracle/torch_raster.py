@@ -67,7 +67,9 @@ def cov3d_from_scale_rot(scales, rotations, mod=1.0):
 
 def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh_degree=0,
                shs=None, colors_precomp=None, cov3D_precomp=None, scales=None, rotations=None,
-               scale_modifier=1.0):
+               scale_modifier=1.0, depth_grad=False):
+    """``depth_grad``: keep view-space z differentiable as the blended depth FEATURE (the "w-depth"
+    forks' out_depth gradient); its use as a sort key never carries gradient."""
     dt = means3D.dtype
     P = means3D.shape[0]
     V, PM = viewmatrix.to(dt), projmatrix.to(dt)
@@ -129,7 +131,7 @@ def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx
         clamped = raw < 0
         rgb = raw.clamp(min=0.0)
     return dict(xy=torch.stack([px, py], -1), conic=conic, opacity=opacities.reshape(-1), rgb=rgb,
-                depth=tz.detach(), radii=torch.where(visible, radius, torch.zeros_like(radius)),
+                depth=tz if depth_grad else tz.detach(), radii=torch.where(visible, radius, torch.zeros_like(radius)),
                 rect=(rminx, rminy, rmaxx, rmaxy), visible=visible,
                 tiles_touched=torch.where(visible, area, torch.zeros_like(area)), clamped=clamped, cov3D=cov6)
 
@@ -148,7 +150,7 @@ def bin_tiles(pre, W, H):
     ty = rminy[owner] + local // wdt[owner]
     tx = rminx[owner] + local % wdt[owner]
     tile = ty * gx + tx
-    dbits = pre["depth"][vis].to(torch.float32).view(torch.int32).to(torch.int64)[owner]
+    dbits = pre["depth"][vis].detach().to(torch.float32).view(torch.int32).to(torch.int64)[owner]
     keys = (tile << 32) | dbits
     order = torch.sort(keys, stable=True).indices
     keys = keys[order]
@@ -247,12 +249,12 @@ def blend(pre, point_list, ranges, bg, W, H, want_depth=True, tile_filter=None, 
 
 def rasterize(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, sh_degree=0,
               shs=None, colors_precomp=None, cov3D_precomp=None, scales=None, rotations=None,
-              scale_modifier=1.0, return_state=False, tile_filter=None, aux=None):
+              scale_modifier=1.0, return_state=False, tile_filter=None, aux=None, depth_grad=False):
     """Full forward.  Returns (color[3,H,W], radii[P], depth[H,W]) like the boundary's 3-tuple.
     ``tile_filter(tx, ty) -> bool`` restricts the blend to a subset of tiles (bounded CPU-baseline
     samples only; the other tiles are left at the background colour)."""
     pre = preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh_degree,
-                     shs, colors_precomp, cov3D_precomp, scales, rotations, scale_modifier)
+                     shs, colors_precomp, cov3D_precomp, scales, rotations, scale_modifier, depth_grad=depth_grad)
     point_list, ranges, keys, N = bin_tiles(pre, W, H)
     color, final_T, n_contrib, depth_img = blend(pre, point_list, ranges, bg, W, H, tile_filter=tile_filter, aux=aux)
     if return_state:
@@ -274,7 +276,7 @@ def rasterize_global_sort(means3D, opacities, viewmatrix, projmatrix, campos, bg
                      shs, colors_precomp, cov3D_precomp)
     dt = means3D.dtype
     vis = pre["visible"].nonzero().squeeze(-1)
-    dbits = pre["depth"][vis].to(torch.float32).view(torch.int32).to(torch.int64)
+    dbits = pre["depth"][vis].detach().to(torch.float32).view(torch.int32).to(torch.int64)
     order = torch.sort(dbits, stable=True).indices
     ids = vis[order]
     ys, xs = torch.meshgrid(torch.arange(H, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
