@@ -42,7 +42,7 @@ def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int) -> dict:
     return {
         # per-stage split of B_fwd = P(12+24+4+12K) + N(12+12) + N·40 + W·H·20
         "fwd_preprocess": P * (12 + 24 + 4 + 12 * K),
-        "fwd_binning": N * 24,
+        "fwd_binning": N * 24,  # SURVEY's figure (12-B pair written + read once); this build writes 4 B/entry
         "fwd_blend": N * 40 + W * H * 20,
         # B_bwd = W·H·20 + N·40 + P(12+24+4+12K) + P(12+12+24+4+12M)
         "bwd_blend": W * H * 20 + N * 40,

@@ -57,7 +57,7 @@ class GgrBackwardOut(C.Structure):
         ("dL_dprojmatrix", C.c_void_p), ("dL_dcampos", C.c_void_p), ("stage_ms", C.c_void_p),
     ]
 
-FWD_STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend"]
+FWD_STAGES = ["preprocess", "depth_sort", "tile_count", "tile_scatter", "blend"]
 BWD_STAGES = ["clear", "blend", "preprocess"]
 
 
@@ -70,6 +70,7 @@ SYMBOLS = [
     ("ggr_geom_bytes", C.c_size_t, [C.c_int32]),
     ("ggr_image_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
     ("ggr_binning_bytes", C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    ("ggr_work_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("ggr_backward_scratch_bytes", C.c_size_t, [C.c_int32]),
     ("ggr_forward", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrForwardIn), C.POINTER(GgrForwardOut),
                               ALLOC_FN, C.c_void_p, C.c_void_p]),

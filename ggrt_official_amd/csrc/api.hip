@@ -57,12 +57,6 @@ struct StageTimer {
     ~StageTimer() { finish(); }
 };
 
-int ceil_log2(uint32_t v) {
-    int b = 0;
-    while ((1ull << b) < v) b++;
-    return b;
-}
-
 int validate(const GgrSettings* st, const GgrForwardIn* in) {
     if (!st || !in) return fail(GGR_E_INVALID, "null settings / inputs");
     if (st->num_points < 0 || st->image_width < 0 || st->image_height < 0)
@@ -77,10 +71,12 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
     if (in->shs && st->sh_stride < (st->sh_degree > 3 ? 16 : (st->sh_degree + 1) * (st->sh_degree + 1)))
         return fail(GGR_E_INVALID, "sh_stride %d too small for sh_degree %d", st->sh_stride, st->sh_degree);
     const int64_t tiles = (int64_t)((st->image_width + GGR_TILE - 1) / GGR_TILE) * ((st->image_height + GGR_TILE - 1) / GGR_TILE);
-    if (tiles > 65536) return fail(GGR_E_LIMIT, "image has %lld tiles; at most 65536 supported", (long long)tiles);
+    if (tiles > (1 << 24)) return fail(GGR_E_LIMIT, "image has %lld tiles; at most 2^24 supported", (long long)tiles);
     if (st->image_width > 65535 * GGR_TILE || st->image_height > 65535 * GGR_TILE) return fail(GGR_E_LIMIT, "image too large");
     return GGR_OK;
 }
+
+size_t tiles_of(int W, int H) { return (size_t)((W + GGR_TILE - 1) / GGR_TILE) * ((H + GGR_TILE - 1) / GGR_TILE); }
 
 }  // namespace
 
@@ -91,7 +87,10 @@ const char* ggr_last_error(void) { return g_err; }
 
 size_t ggr_geom_bytes(int32_t P) { return ggr_carve_geom(nullptr, (size_t)(P > 0 ? P : 0)).bytes; }
 size_t ggr_image_bytes(int32_t W, int32_t H) { return ggr_carve_image(nullptr, W, H).bytes; }
-size_t ggr_binning_bytes(int64_t N, int32_t, int32_t) { return ggr_carve_bin(nullptr, (size_t)(N > 0 ? N : 0)).bytes; }
+size_t ggr_binning_bytes(int64_t N, int32_t, int32_t) { return ggr_point_list_bytes((size_t)(N > 0 ? N : 0)); }
+size_t ggr_work_bytes(int32_t P, int32_t W, int32_t H) {
+    return ggr::plan_tile_lists((size_t)(P > 0 ? P : 0), tiles_of(W, H)).work_bytes;
+}
 size_t ggr_backward_scratch_bytes(int32_t P) { return ggr_carve_bwd(nullptr, (size_t)(P > 0 ? P : 0)).bytes; }
 
 int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* out, GgrAllocFn alloc,
@@ -104,8 +103,8 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     if (st->num_points > 0 && !out->radii) return fail(GGR_E_INVALID, "null radii");
     hipStream_t s = (hipStream_t)stream;
     const int P = st->num_points, W = st->image_width, H = st->image_height;
-    const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
-    const size_t tiles = (size_t)gx * gy;
+    const int gx = (W + GGR_TILE - 1) / GGR_TILE;
+    const size_t tiles = tiles_of(W, H);
     const bool dbg = st->debug != 0;
 
     GeomLayout g = ggr_carve_geom(out->geom_buffer, (size_t)P);
@@ -115,8 +114,8 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     // 1. per-Gaussian projection
     ggr::launch_preprocess_fwd(P, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
                                in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
-                               in->aux_precomp, st->viewmatrix, st->projmatrix, st->campos, W, H, st->tanfovx, st->tanfovy,
-                               out->radii, g, s);
+                               in->aux_precomp, st->viewmatrix, st->projmatrix, st->campos, W, H, st->tanfovx,
+                               st->tanfovy, out->radii, g, s);
     KCHECK(dbg, s, "preprocess_fwd");
     tm.mark();
 
@@ -130,9 +129,17 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     }
     tm.mark();
 
-    // 3. offsets (inclusive scan of tiles_touched in depth order) and num_rendered
-    ggr::launch_scan_tiles(g.tiles_touched, order, g.offsets, g.scan_tmp, g.counters, (size_t)P, s);
-    KCHECK(dbg, s, "offsets scan");
+    // 3. per-(chunk, tile) counts → list positions, tile ranges, num_rendered
+    const ggr::TileListPlan plan = ggr::plan_tile_lists((size_t)P, tiles);
+    void* work = alloc(alloc_ctx, plan.work_bytes);  // 1st allocator call: transient work area
+    if (!work) return fail(GGR_E_ALLOC, "work-area allocator returned NULL");
+    if (P > 0) {
+        ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, s);
+    } else {
+        HIP_TRY(hipMemsetAsync(im.ranges, 0, (tiles ? tiles : 1) * sizeof(uint2), s));
+        HIP_TRY(hipMemsetAsync(g.counters, 0, 4, s));
+    }
+    KCHECK(dbg, s, "tile_list_count");
     uint32_t num_rendered = 0;
     HIP_TRY(hipMemcpyAsync(&num_rendered, g.counters, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));  // the single host sync of forward
@@ -140,34 +147,20 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     out->num_rendered = (int64_t)num_rendered;
     tm.mark();
 
-    void* bin_mem = alloc(alloc_ctx, ggr_carve_bin(nullptr, num_rendered).bytes);
+    void* bin_mem = alloc(alloc_ctx, ggr_point_list_bytes(num_rendered));  // 2nd call: kept for backward
     if (!bin_mem) return fail(GGR_E_ALLOC, "binning allocator returned NULL");
     out->binning_buffer = bin_mem;
-    BinLayout b = ggr_carve_bin(bin_mem, num_rendered);
+    uint32_t* point_list = (uint32_t*)bin_mem;
 
-    // 4. emit (tile, id) pairs in depth order; 5. stable sort by tile id; 6. ranges
-    uint32_t *tk = b.keys_a, *pl = b.vals_a;
+    // 4. in-order scatter of the ids into the per-tile lists
     if (num_rendered > 0) {
-        ggr::launch_emit_pairs((size_t)P, order, g.offsets, g.tiles_touched, g.rect, gx, b.keys_a, b.vals_a, s);
-        KCHECK(dbg, s, "emit_pairs");
-        tm.mark();
-        ggr::radix_sort_pairs(b.keys_a, b.keys_b, b.vals_a, b.vals_b, b.hist, num_rendered,
-                              ceil_log2((uint32_t)tiles), &tk, &pl, s);
-        KCHECK(dbg, s, "tile sort");
+        ggr::launch_tile_list_scatter(plan, (size_t)P, tiles, gx, order, g.rect, work, point_list, s);
+        KCHECK(dbg, s, "tile_list_scatter");
     }
-    // the sorted list must live in vals_a / keys_a so that backward finds it without extra state
-    if (pl != b.vals_a && num_rendered > 0) {
-        HIP_TRY(hipMemcpyAsync(b.vals_a, pl, (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(b.keys_a, tk, (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, s));
-    }
-    if (num_rendered == 0) tm.mark();  // keep stage indices aligned when nothing was emitted
-    tm.mark();
-    ggr::launch_tile_ranges(b.keys_a, num_rendered, im.ranges, tiles, s);
-    KCHECK(dbg, s, "tile_ranges");
     tm.mark();
 
-    // 7. blend
-    ggr::launch_blend_fwd(W, H, im.ranges, b.vals_a, g.splat, st->bg, out->out_color, im.final_T, im.n_contrib,
+    // 5. blend
+    ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, st->bg, out->out_color, im.final_T, im.n_contrib,
                           out->out_depth, s);
     KCHECK(dbg, s, "blend_fwd");
     tm.mark();
@@ -206,17 +199,17 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
 
     GeomLayout g = ggr_carve_geom((void*)in->geom_buffer, (size_t)P);
     ImageLayout im = ggr_carve_image((void*)in->image_buffer, W, H);
-    BinLayout b = ggr_carve_bin((void*)in->binning_buffer, (size_t)in->num_rendered);
+    const uint32_t* point_list = (const uint32_t*)in->binning_buffer;
     BwdScratch sc = ggr_carve_bwd(in->scratch, (size_t)P);
 
     StageTimer tm(s, out->stage_ms, GGR_BWD_STAGES);
     HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));
     HIP_TRY(hipMemsetAsync(out->dL_dmeans2D, 0, (size_t)P * 12, s));
     HIP_TRY(hipMemsetAsync(out->dL_dopacities, 0, (size_t)P * 4, s));
-
     tm.mark();
+
     if (in->num_rendered > 0) {
-        ggr::launch_blend_bwd(W, H, im.ranges, b.vals_a, g.splat, st->bg, im.final_T, im.n_contrib,
+        ggr::launch_blend_bwd(W, H, im.ranges, point_list, g.splat, st->bg, im.final_T, im.n_contrib,
                               in->dL_dout_color, in->dL_dout_depth, out->dL_dmeans2D, sc.dL_dconic,
                               out->dL_dopacities, sc.dL_drgb, in->dL_dout_depth ? sc.dL_dz : nullptr, s);
         KCHECK(dbg, s, "blend_bwd");
@@ -265,11 +258,10 @@ int ggr_debug_unpack_binning(const void* binning_buffer, const void* image_buffe
     hipStream_t s = (hipStream_t)stream;
     if (!image_buffer) return fail(GGR_E_INVALID, "null image buffer");
     ImageLayout im = ggr_carve_image((void*)image_buffer, W, H);
-    const size_t tiles = (size_t)((W + GGR_TILE - 1) / GGR_TILE) * ((H + GGR_TILE - 1) / GGR_TILE);
+    const size_t tiles = tiles_of(W, H);
     if (point_list && N > 0) {
         if (!binning_buffer) return fail(GGR_E_INVALID, "null binning buffer");
-        BinLayout b = ggr_carve_bin((void*)binning_buffer, (size_t)N);
-        HIP_TRY(hipMemcpyAsync(point_list, b.vals_a, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(point_list, binning_buffer, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
     }
     if (ranges && tiles) HIP_TRY(hipMemcpyAsync(ranges, im.ranges, tiles * 8, hipMemcpyDeviceToDevice, s));
     if (final_T) HIP_TRY(hipMemcpyAsync(final_T, im.final_T, (size_t)W * H * 4, hipMemcpyDeviceToDevice, s));

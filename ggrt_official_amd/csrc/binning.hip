@@ -229,151 +229,5 @@ void launch_iota(uint32_t* v, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n);
 }
 
-// ---------------------------------------------------------------------------------------------
-// offsets scan (inclusive) of tiles_touched gathered in depth order
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(v, off);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
-
-// phase 0: block sums; phase 1 (single block): exclusive scan of block sums; phase 2: final scan
-__global__ void __launch_bounds__(256)
-scan_block_sums_kernel(const uint32_t* __restrict__ tt, const uint32_t* __restrict__ order, size_t n,
-                       uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t ws[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t base = (size_t)blockIdx.x * GGR_SORT_TILE;
-    uint32_t acc = 0;
-#pragma unroll
-    for (int r = 0; r < GGR_SORT_ITEMS; r++) {
-        const size_t idx = base + r * 256 + tid;
-        if (idx < n) acc += tt[order[idx]];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if (lane == 0) ws[wave] = acc;
-    __syncthreads();
-    if (tid == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-__global__ void __launch_bounds__(256)
-scan_of_sums_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t* __restrict__ total_out) {
-    __shared__ uint32_t sh[256];
-    __shared__ uint32_t carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t start = 0; start < nblocks; start += 256) {
-        const uint32_t i = start + tid;
-        const uint32_t v = i < nblocks ? block_sums[i] : 0u;
-        sh[tid] = v;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const uint32_t t = tid >= off ? sh[tid - off] : 0u;
-            __syncthreads();
-            sh[tid] += t;
-            __syncthreads();
-        }
-        const uint32_t incl = sh[tid];
-        const uint32_t c = carry;
-        if (i < nblocks) block_sums[i] = c + incl - v;
-        __syncthreads();
-        if (tid == 255) carry = c + incl;
-        __syncthreads();
-    }
-    if (tid == 0) *total_out = carry;
-}
-
-__global__ void __launch_bounds__(256)
-scan_final_kernel(const uint32_t* __restrict__ tt, const uint32_t* __restrict__ order, size_t n,
-                  const uint32_t* __restrict__ block_excl, uint32_t* __restrict__ offsets) {
-    __shared__ uint32_t ws[4];
-    __shared__ uint32_t running;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t base = (size_t)blockIdx.x * GGR_SORT_TILE;
-    if (tid == 0) running = block_excl[blockIdx.x];
-    __syncthreads();
-    for (int r = 0; r < GGR_SORT_ITEMS; r++) {
-        const size_t idx = base + r * 256 + tid;
-        const uint32_t v = idx < n ? tt[order[idx]] : 0u;
-        const uint32_t incl = wave_incl_scan(v, lane);
-        if (lane == 63) ws[wave] = incl;
-        __syncthreads();
-        uint32_t pre = running;
-        for (int w = 0; w < wave; w++) pre += ws[w];
-        if (idx < n) offsets[idx] = pre + incl;
-        __syncthreads();
-        if (tid == 0) running += ws[0] + ws[1] + ws[2] + ws[3];
-        __syncthreads();
-    }
-}
-
-void launch_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets,
-                       uint32_t* scan_tmp, uint32_t* total_out, size_t P, hipStream_t s) {
-    if (P == 0) {
-        hipMemsetAsync(total_out, 0, 4, s);
-        return;
-    }
-    const uint32_t nblocks = (uint32_t)ggr_sort_blocks(P);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(256), 0, s, tiles_touched, order, P, scan_tmp);
-    hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(256), 0, s, scan_tmp, nblocks, total_out);
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nblocks), dim3(256), 0, s, tiles_touched, order, P, scan_tmp, offsets);
-}
-
-// ---------------------------------------------------------------------------------------------
-// pair emission: for the i-th Gaussian in depth order write (tile id, Gaussian id) for every tile
-// of its rect (row-major: y outer, x inner — the emission order of Appendix A.2)
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-emit_pairs_kernel(size_t P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                  const uint32_t* __restrict__ tiles_touched, const uint2* __restrict__ rect, int grid_x,
-                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t g = order[i];
-    const uint32_t cnt = tiles_touched[g];
-    if (cnt == 0) return;
-    uint32_t off = offsets[i] - cnt;
-    const uint2 rc = rect[g];
-    const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
-    for (uint32_t y = y0; y < y1; y++)
-        for (uint32_t x = x0; x < x1; x++) {
-            keys[off] = y * (uint32_t)grid_x + x;
-            vals[off] = g;
-            off++;
-        }
-}
-
-void launch_emit_pairs(size_t P, const uint32_t* order, const uint32_t* offsets,
-                       const uint32_t* tiles_touched, const uint2* rect, int grid_x, uint32_t* keys,
-                       uint32_t* vals, hipStream_t s) {
-    if (P == 0) return;
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, order, offsets,
-                       tiles_touched, rect, grid_x, keys, vals);
-}
-
-__global__ void __launch_bounds__(256)
-tile_ranges_kernel(const uint32_t* __restrict__ keys, size_t N, uint2* __restrict__ ranges) {
-    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
-    const uint32_t t = keys[k];
-    if (k == 0) ranges[t].x = 0;
-    else {
-        const uint32_t p = keys[k - 1];
-        if (p != t) { ranges[p].y = (uint32_t)k; ranges[t].x = (uint32_t)k; }
-    }
-    if (k == N - 1) ranges[t].y = (uint32_t)N;
-}
-
-void launch_tile_ranges(const uint32_t* keys_sorted, size_t N, uint2* ranges, size_t tiles, hipStream_t s) {
-    hipMemsetAsync(ranges, 0, tiles * sizeof(uint2), s);
-    if (N == 0) return;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, keys_sorted, N, ranges);
-}
 
 }  // namespace ggr

@@ -1,25 +1,24 @@
 // ggr_common.h — shared constants, HBM layouts and launch helpers for the gfx950 kernels.
 //
-// Data layout in HBM (all caller-owned, carved out of three opaque buffers; 256-B aligned sections)
+// Data layout in HBM (all caller-owned, carved out of opaque buffers; 256-B aligned sections)
 //
-//   geom buffer   (per Gaussian, P entries)
-//     splat[P]         3 × float4 = 48 B  {x, y, conic.xx, conic.xy | conic.yy, opacity, r, g | b, z, qmax, 0}
-//                      (qmax = 2·ln(255·opacity): the largest dᵀ·conic·d at which α still reaches 1/255)
+//   geom buffer   (per Gaussian, P entries; kept for backward)
+//     splat[P]         3 × float4 = 48 B  {x, y, conic.xx, conic.xy | conic.yy, opacity, r, g | b, f, qmax, 0}
 //                      one record = everything the blend kernels need for a list entry, so a tile-list
 //                      fetch is ONE 48-B gather instead of three gathers from three SoA arrays
+//                      (f = view-space z or the caller's aux feature; qmax = 2·ln(255·opacity): the largest
+//                      dᵀ·conic·d at which α still reaches 1/255)
 //     depth_key[P]     u32   float bits of view z (0xFFFFFFFF if culled)
 //     tiles_touched[P] u32
 //     rect[P]          u32×2 packed tile rect (minx | miny<<16, maxx | maxy<<16)
 //     clamped[P]       u32   bit c set ⇔ SH colour channel c was clamped at 0
 //     cov3D[P]         6 × f32 (scale/rot path only; otherwise the caller's cov3D_precomp is used)
-//     order[P]         u32   Gaussian ids sorted by (depth, id)
-//     offsets[P]       u32   inclusive scan of tiles_touched in that order
-//     sort scratch     keys/vals double buffers + per-block digit histograms
-//     counters         u32[64]  (num_rendered, …)
-//   binning buffer (per list entry, N = num_rendered)
-//     tile keys ×2, values ×2 (u32 each), per-block digit histograms; after the sort one of the
-//     value buffers is the final point_list
-//   image buffer
+//     depth-sort double buffers (keys/vals) + radix work area, counters
+//   work buffer   (forward only, obtained from the allocator, may be released after ggr_forward)
+//     table[chunks][tiles] u32, gsum[groups][tiles] u32, tile_start[tiles] u32   (tile_lists.hip)
+//   binning buffer (kept for backward)
+//     point_list[N] u32: Gaussian ids, tile by tile, each tile's run in (depth, id) order
+//   image buffer  (kept for backward)
 //     ranges[tiles] (uint2), final_T[H·W] f32, n_contrib[H·W] u32
 #pragma once
 #include <hip/hip_runtime.h>
@@ -42,6 +41,9 @@
 #define GGR_RADIX_BITS 8
 #define GGR_RADIX 256
 
+// tile-list builder: Gaussians (in depth order) per chunk
+#define GGR_BIN_CHUNK 1024
+
 static inline size_t ggr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) / GGR_SORT_TILE; }
@@ -55,14 +57,11 @@ struct GeomLayout {
     uint2* rect;
     uint32_t* clamped;
     float* cov3D;
-    uint32_t* order;      // final sorted ids (aliases one of the sort value buffers)
-    uint32_t* offsets;
     uint32_t* keys_a;
     uint32_t* keys_b;
     uint32_t* vals_a;
     uint32_t* vals_b;
     uint32_t* hist;       // sort work area (ggr_sort_hist_words)
-    uint32_t* scan_tmp;   // block sums for the offsets scan
     uint32_t* counters;   // [64]
     size_t bytes;
 };
@@ -79,42 +78,17 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P) {
     L.rect = (uint2*)take(Pp * 8);
     L.clamped = (uint32_t*)take(Pp * 4);
     L.cov3D = (float*)take(Pp * 24);
-    L.offsets = (uint32_t*)take(Pp * 4);
     L.keys_a = (uint32_t*)take(Pp * 4);
     L.keys_b = (uint32_t*)take(Pp * 4);
     L.vals_a = (uint32_t*)take(Pp * 4);
     L.vals_b = (uint32_t*)take(Pp * 4);
     L.hist = (uint32_t*)take(ggr_sort_hist_words(Pp) * 4);
-    L.scan_tmp = (uint32_t*)take((ggr_sort_blocks(Pp) + 1) * 4);
     L.counters = (uint32_t*)take(64 * 4);
-    L.order = nullptr;
     L.bytes = o;
     return L;
 }
 
-struct BinLayout {
-    uint32_t* keys_a;
-    uint32_t* keys_b;
-    uint32_t* vals_a;
-    uint32_t* vals_b;
-    uint32_t* hist;
-    size_t bytes;
-};
-
-static inline BinLayout ggr_carve_bin(void* base, size_t N) {
-    BinLayout L;
-    char* p = (char*)base;
-    size_t o = 0;
-    size_t Np = N ? N : 1;
-    auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes); return r; };
-    L.keys_a = (uint32_t*)take(Np * 4);
-    L.keys_b = (uint32_t*)take(Np * 4);
-    L.vals_a = (uint32_t*)take(Np * 4);
-    L.vals_b = (uint32_t*)take(Np * 4);
-    L.hist = (uint32_t*)take(ggr_sort_hist_words(Np) * 4);
-    L.bytes = o;
-    return L;
-}
+static inline size_t ggr_point_list_bytes(size_t N) { return ggr_align((N ? N : 1) * 4); }
 
 struct ImageLayout {
     uint2* ranges;
@@ -141,7 +115,7 @@ static inline ImageLayout ggr_carve_image(void* base, int W, int H) {
 struct BwdScratch {
     float* dL_dconic;  // [P,3]  (xx, xy[half convention], yy)
     float* dL_drgb;    // [P,3]
-    float* dL_dz;      // [P]    depth-as-feature gradient (only with dL_dout_depth)
+    float* dL_dz;      // [P]    depth / aux feature gradient (only with dL_dout_depth)
     float* pose_acc;   // [64]: dL/dviewmatrix [0:16], dL/dprojmatrix [16:32], dL/dcampos [32:35]
     size_t bytes;
 };
@@ -161,9 +135,6 @@ static inline BwdScratch ggr_carve_bwd(void* base, size_t P) {
 }
 
 // ---- kernel launchers (defined in the .hip translation units) -------------------------------
-struct GgrSettings;
-struct GgrForwardIn;
-
 namespace ggr {
 
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
@@ -181,15 +152,18 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
 
 void launch_iota(uint32_t* v, size_t n, hipStream_t s);
 
-// offsets[i] = inclusive scan of tiles_touched[order[i]]; total -> counters[0]
-void launch_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets,
-                       uint32_t* scan_tmp, uint32_t* total_out, size_t P, hipStream_t s);
-
-void launch_emit_pairs(size_t P, const uint32_t* order, const uint32_t* offsets,
-                       const uint32_t* tiles_touched, const uint2* rect, int grid_x, uint32_t* keys,
-                       uint32_t* vals, hipStream_t s);
-
-void launch_tile_ranges(const uint32_t* keys_sorted, size_t N, uint2* ranges, size_t tiles, hipStream_t s);
+// tile-list builder (tile_lists.hip)
+struct TileListPlan {
+    uint32_t nchunks, nbands, band_tiles, groups, chunks_per_group;
+    size_t table_words, gsum_words, work_bytes;
+};
+TileListPlan plan_tile_lists(size_t P, size_t T);
+// K1 + K2: fills the work area, ranges[T] and *total_out (= N, device)
+void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
+                            const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, hipStream_t s);
+// K3: writes point_list[N]
+void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
+                              const uint2* rect, const void* work, uint32_t* point_list, hipStream_t s);
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
@@ -216,7 +190,5 @@ void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, u
 
 void launch_unpack_geom(GeomLayout g, int P, float* depth, float* xy, float* conic_opacity, float* rgb,
                         int32_t* tiles_touched, uint8_t* clamped, hipStream_t s);
-
-
 
 }  // namespace ggr

@@ -157,9 +157,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             holder = {}
 
             def _alloc(_ctx, nbytes):
+                # called twice (include/ggr_raster.h): 1st = transient work area, 2nd = tile lists (kept)
                 try:
-                    holder["bin"] = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
-                    return holder["bin"].data_ptr()
+                    key = "work" if "work" not in holder else "bin"
+                    holder[key] = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+                    return holder[key].data_ptr()
                 except Exception:  # pragma: no cover - out of memory
                     return None
 

@@ -42,7 +42,7 @@ enum {
     GGR_E_INVALID = 1,   /* bad argument combination (e.g. both/neither of shs & colors_precomp) */
     GGR_E_HIP = 2,       /* a HIP runtime call or kernel launch failed */
     GGR_E_ALLOC = 3,     /* the allocator callback returned NULL */
-    GGR_E_LIMIT = 4      /* size beyond what the kernels index (P, N ≥ 2^31, > 65536 tiles) */
+    GGR_E_LIMIT = 4      /* size beyond what the kernels index (P, N ≥ 2^31, > 2^24 tiles) */
 };
 
 /* Mirrors the NamedTuple built at cuda_splatting.py:101-113 (field meaning identical). */
@@ -95,13 +95,16 @@ typedef struct GgrForwardOut {
 
 /* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */
 enum {
-    GGR_FWD_PREPROCESS = 0, GGR_FWD_DEPTH_SORT = 1, GGR_FWD_SCAN = 2, GGR_FWD_EMIT = 3,
-    GGR_FWD_TILE_SORT = 4, GGR_FWD_RANGES = 5, GGR_FWD_BLEND = 6, GGR_FWD_STAGES = 7
+    GGR_FWD_PREPROCESS = 0, GGR_FWD_DEPTH_SORT = 1, GGR_FWD_TILE_COUNT = 2 /* counts + scans + the N readback */,
+    GGR_FWD_TILE_SCATTER = 3, GGR_FWD_BLEND = 4, GGR_FWD_STAGES = 5
 };
 enum { GGR_BWD_CLEAR = 0, GGR_BWD_BLEND = 1, GGR_BWD_PREPROCESS = 2, GGR_BWD_STAGES = 3 };
 
-/* Called once per forward, after num_rendered is known, with ggr_binning_bytes(num_rendered,…).
- * Must return device memory (256-byte aligned) or NULL. */
+/* Called TWICE per forward, in this order; must return device memory (256-byte aligned) or NULL:
+ *   1st call  ggr_work_bytes(P,W,H) bytes: transient work area of the tile-list builder — the caller may
+ *             release it as soon as ggr_forward has returned;
+ *   2nd call  ggr_binning_bytes(num_rendered,…) bytes, after num_rendered is known: the tile lists, kept
+ *             by the caller for backward (returned in GgrForwardOut.binning_buffer). */
 typedef void* (*GgrAllocFn)(void* ctx, size_t bytes);
 
 typedef struct GgrBackwardIn {
@@ -144,6 +147,7 @@ const char* ggr_last_error(void);
 size_t ggr_geom_bytes(int32_t num_points);
 size_t ggr_image_bytes(int32_t width, int32_t height);
 size_t ggr_binning_bytes(int64_t num_rendered, int32_t width, int32_t height);
+size_t ggr_work_bytes(int32_t num_points, int32_t width, int32_t height);
 size_t ggr_backward_scratch_bytes(int32_t num_points);
 
 /* replaces diff_gaussian_rasterization._C.rasterize_gaussians */

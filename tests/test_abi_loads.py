@@ -24,7 +24,7 @@ def test_library_builds_and_loads():
 
 def test_every_declared_symbol_is_exported_and_bound():
     declared = _declared_functions()
-    assert len(declared) >= 11
+    assert len(declared) >= 12
     raw = ctypes.CDLL(_lib.LIB_PATH)
     bound = {n for n, _, _ in _lib.SYMBOLS}
     for name in declared:
@@ -36,10 +36,12 @@ def test_size_queries_are_consistent():
     lib = _lib.load()
     assert lib.ggr_geom_bytes(0) > 0 and lib.ggr_geom_bytes(1000) > lib.ggr_geom_bytes(10)
     assert lib.ggr_image_bytes(1920, 1080) >= 1920 * 1080 * 8
-    assert lib.ggr_binning_bytes(10_000_000, 1920, 1080) >= 10_000_000 * 16
+    assert lib.ggr_binning_bytes(10_000_000, 1920, 1080) >= 10_000_000 * 4
+    assert lib.ggr_work_bytes(1_000_000, 1920, 1080) >= 977 * 8160 * 4
     assert lib.ggr_backward_scratch_bytes(1_000_000) >= 1_000_000 * 28
     for f, args in ((lib.ggr_geom_bytes, (12345,)), (lib.ggr_image_bytes, (333, 77)),
-                    (lib.ggr_binning_bytes, (98765, 333, 77)), (lib.ggr_backward_scratch_bytes, (4321,))):
+                    (lib.ggr_binning_bytes, (98765, 333, 77)), (lib.ggr_backward_scratch_bytes, (4321,)),
+                    (lib.ggr_work_bytes, (4321, 333, 77))):
         assert f(*args) % 256 == 0
 
 
