@@ -154,7 +154,7 @@ void launch_iota(uint32_t* v, size_t n, hipStream_t s);
 
 // tile-list builder (tile_lists.hip)
 struct TileListPlan {
-    uint32_t nchunks, nbands, band_tiles, groups, chunks_per_group;
+    uint32_t nchunks, nbands, band_tiles, nsbands, sband_tiles, groups, chunks_per_group;
     size_t table_words, gsum_words, work_bytes;
 };
 TileListPlan plan_tile_lists(size_t P, size_t T);

@@ -46,7 +46,7 @@ bin_count_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __
         const uint32_t i = base + k;
         if (i >= P) break;
         uint32_t x0, y0, x1, y1;
-        unpack_rect(rect[order[i]], x0, y0, x1, y1);
+        unpack_rect(rect[i], x0, y0, x1, y1);  // rect_sorted: already in depth order
         if (x1 <= x0 || y1 <= y0) continue;
         if ((y1 - 1) * grid_x + x1 - 1 < lo || y0 * grid_x + x0 >= hi) continue;
         for (uint32_t y = y0; y < y1; y++)
@@ -62,18 +62,19 @@ bin_count_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __
 // ---- K2a: per (tile, group of chunks) sum ---------------------------------------------------------
 __global__ void __launch_bounds__(256)
 bin_group_sum_kernel(const uint32_t* __restrict__ table, uint32_t T, uint32_t nchunks, uint32_t chunks_per_group,
-                     uint32_t* __restrict__ gsum /*[G][T]*/) {
+                     uint32_t* __restrict__ gsum /*[G][T]*/, uint32_t* __restrict__ total /*[T], zeroed*/) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     if (t >= T) return;
     const uint32_t c0 = g * chunks_per_group, c1 = min(nchunks, c0 + chunks_per_group);
     uint32_t s = 0;
     for (uint32_t c = c0; c < c1; c++) s += table[(size_t)c * T + t];
     gsum[(size_t)g * T + t] = s;
+    if (s) atomicAdd(&total[t], s);  // G atomics per tile at most
 }
 
-// ---- K2b: ONE block: exclusive scan over groups per tile, exclusive scan over tiles -----------------
+// ---- K2b: ONE block: exclusive scan of the per-tile totals → tile_start, ranges, N --------------------
 __global__ void __launch_bounds__(1024)
-bin_tile_scan_kernel(uint32_t* __restrict__ gsum, uint32_t T, uint32_t G, uint32_t* __restrict__ tile_start,
+bin_tile_scan_kernel(uint32_t T, uint32_t* __restrict__ tile_start /*in: totals, out: starts*/,
                      uint2* __restrict__ ranges, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t carry;
@@ -82,13 +83,7 @@ bin_tile_scan_kernel(uint32_t* __restrict__ gsum, uint32_t T, uint32_t G, uint32
     __syncthreads();
     for (uint32_t t0 = 0; t0 < T; t0 += 1024) {
         const uint32_t t = t0 + tid;
-        uint32_t run = 0;
-        if (t < T)
-            for (uint32_t g = 0; g < G; g++) {
-                const uint32_t v = gsum[(size_t)g * T + t];
-                gsum[(size_t)g * T + t] = run;  // exclusive prefix over groups
-                run += v;
-            }
+        const uint32_t run = t < T ? tile_start[t] : 0u;
         sh[tid] = run;
         __syncthreads();
         for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -117,7 +112,8 @@ bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchun
     const uint32_t t = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     if (t >= T) return;
     const uint32_t c0 = g * chunks_per_group, c1 = min(nchunks, c0 + chunks_per_group);
-    uint32_t run = tile_start[t] + gsum[(size_t)g * T + t];
+    uint32_t run = tile_start[t];
+    for (uint32_t gg = 0; gg < g; gg++) run += gsum[(size_t)gg * T + t];  // exclusive prefix over groups
     for (uint32_t c = c0; c < c1; c++) {
         const uint32_t v = table[(size_t)c * T + t];
         table[(size_t)c * T + t] = run;
@@ -130,48 +126,74 @@ __global__ void __launch_bounds__(64)
 bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect, uint32_t T,
                    uint32_t band_tiles, uint32_t grid_x, const uint32_t* __restrict__ table,
                    uint32_t* __restrict__ point_list) {
-    extern __shared__ uint32_t cursor[];  // [band_tiles]: next free list position per tile of the band
+    // LDS: cursor[band_tiles] (next free list position per tile of the band) + the compacted list of this
+    // chunk's Gaussians that touch the band: id, packed origin (x0 | y0<<16), packed size (w | h<<16)
+    extern __shared__ uint32_t lds[];
+    uint32_t* cursor = lds;
+    uint32_t* l_id = lds + band_tiles;
+    uint32_t* l_xy = l_id + GGR_BIN_CHUNK;
+    uint32_t* l_wh = l_xy + GGR_BIN_CHUNK;
     const uint32_t chunk = blockIdx.x, band = blockIdx.y, lane = threadIdx.x;
     const uint32_t lo = band * band_tiles, hi = min(T, lo + band_tiles);
     for (uint32_t i = lane; i < hi - lo; i += 64) cursor[i] = table[(size_t)chunk * T + lo + i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     const uint32_t base = chunk * GGR_BIN_CHUNK;
     const uint32_t end = min(P, base + GGR_BIN_CHUNK);
+    // phase A: coalesced, independent loads; keep (in order) the Gaussians whose rect can touch the band
+    uint32_t nh = 0;
+#pragma unroll 4
     for (uint32_t b0 = base; b0 < end; b0 += 64) {
         const uint32_t i = b0 + lane;
         uint32_t g = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         if (i < end) {
             g = order[i];
-            unpack_rect(rect[g], x0, y0, x1, y1);
+            unpack_rect(rect[i], x0, y0, x1, y1);  // rect is already in depth order (rect_sorted)
         }
         const uint32_t w = x1 > x0 ? x1 - x0 : 0, h = y1 > y0 ? y1 - y0 : 0;
-        const uint32_t n = w * h;
-        const bool hit = n > 0 && (y1 - 1) * grid_x + x1 - 1 >= lo && y0 * grid_x + x0 < hi;
-        uint64_t mask = __ballot(hit);
-        while (mask) {  // Gaussians of this 64-batch that touch the band, in order
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const uint32_t gj = __builtin_amdgcn_readlane(g, j);
-            const uint32_t xj = __builtin_amdgcn_readlane(x0, j), yj = __builtin_amdgcn_readlane(y0, j);
-            const uint32_t wj = __builtin_amdgcn_readlane(w, j), nj = __builtin_amdgcn_readlane(n, j);
-            const float inv_w = 1.0f / (float)wj;
-            for (uint32_t l0 = 0; l0 < nj; l0 += 64) {
-                const uint32_t l = l0 + lane;
-                if (l < nj) {
-                    // row / column of the l-th tile of the rect: (l + ½)/w is ≥ ½/w away from any integer, far
-                    // more than the fp32 error of the product for every l < 2^16
-                    const uint32_t ly = (uint32_t)(((float)l + 0.5f) * inv_w);
-                    const uint32_t lx = l - ly * wj;
-                    const uint32_t t = (yj + ly) * grid_x + xj + lx;
-                    if (t >= lo && t < hi) {
-                        const uint32_t pos = atomicAdd(&cursor[t - lo], 1u);
-                        point_list[pos] = gj;
-                    }
+        const bool hit = w * h > 0 && (y1 - 1) * grid_x + x1 - 1 >= lo && y0 * grid_x + x0 < hi;
+        const uint64_t mk = __ballot(hit);
+        if (hit) {
+            const uint32_t p = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            l_id[p] = g;
+            l_xy[p] = x0 | (y0 << 16);
+            l_wh[p] = w | (h << 16);
+        }
+        nh += (uint32_t)__popcll(mk);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // phase B: one Gaussian per step, lanes = tiles of its rect.  Distinct tiles within a step, program order
+    // across steps, and LDS executes one wave's operations in order ⇒ the lists come out stable.  The next
+    // entry is fetched while the current one is processed.
+    uint32_t gj = 0, xy = 0, wh = 0;
+    if (nh) { gj = l_id[0]; xy = l_xy[0]; wh = l_wh[0]; }
+    for (uint32_t k = 0; k < nh; k++) {
+        const uint32_t cg = gj, cxy = xy, cwh = wh;
+        if (k + 1 < nh) { gj = l_id[k + 1]; xy = l_xy[k + 1]; wh = l_wh[k + 1]; }
+        const uint32_t xj = cxy & 0xFFFFu, yj = cxy >> 16, wj = cwh & 0xFFFFu, nj = wj * (cwh >> 16);
+        const float inv_w = 1.0f / (float)wj;
+        for (uint32_t l0 = 0; l0 < nj; l0 += 64) {
+            const uint32_t l = l0 + lane;
+            if (l < nj) {
+                // row / column of the l-th tile of the rect: (l + ½)/w is ≥ ½/w away from any integer, far
+                // more than the fp32 error of the product for every l < 2^16
+                const uint32_t ly = (uint32_t)(((float)l + 0.5f) * inv_w);
+                const uint32_t lx = l - ly * wj;
+                const uint32_t t = (yj + ly) * grid_x + xj + lx;
+                if (t >= lo && t < hi) {
+                    const uint32_t pos = atomicAdd(&cursor[t - lo], 1u);
+                    point_list[pos] = cg;
                 }
             }
         }
     }
+}
+
+// rect_sorted[i] = rect[order[i]]: lets K1 / K3 stream the rects instead of chasing order[] → rect[]
+__global__ void __launch_bounds__(256)
+gather_rect_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect,
+                   uint2* __restrict__ rect_sorted) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P) rect_sorted[i] = rect[order[i]];
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -179,44 +201,72 @@ TileListPlan plan_tile_lists(size_t P, size_t T) {
     TileListPlan p;
     p.nchunks = (uint32_t)((P + GGR_BIN_CHUNK - 1) / GGR_BIN_CHUNK);
     if (p.nchunks == 0) p.nchunks = 1;
+    // count: wide bands (few re-reads of the rects, order-free LDS adds); scatter: narrow bands (many short,
+    // independent in-order walks instead of few long ones — every step waits for a ds_add_rtn)
     p.band_tiles = (uint32_t)(T < 4096 ? (T ? T : 1) : 4096);
     p.nbands = (uint32_t)((T + p.band_tiles - 1) / p.band_tiles);
     if (p.nbands == 0) p.nbands = 1;
+    p.sband_tiles = (uint32_t)(T < 1024 ? (T ? T : 1) : 1024);
+    p.nsbands = (uint32_t)((T + p.sband_tiles - 1) / p.sband_tiles);
+    if (p.nsbands == 0) p.nsbands = 1;
     p.groups = p.nchunks < 32 ? p.nchunks : 32;
     p.chunks_per_group = (p.nchunks + p.groups - 1) / p.groups;
     p.groups = (p.nchunks + p.chunks_per_group - 1) / p.chunks_per_group;
     const size_t Tp = T ? T : 1;
     p.table_words = (size_t)p.nchunks * Tp;
     p.gsum_words = (size_t)p.groups * Tp;
-    p.work_bytes = ggr_align(p.table_words * 4) + ggr_align(p.gsum_words * 4) + ggr_align(Tp * 4);
+    p.work_bytes = ggr_align(p.table_words * 4) + ggr_align(p.gsum_words * 4) + ggr_align(Tp * 4) +
+                   ggr_align((P ? P : 1) * sizeof(uint2));
     return p;
 }
 
+namespace {
+struct WorkArea {
+    uint32_t* table;
+    uint32_t* gsum;
+    uint32_t* tile_start;
+    uint2* rect_sorted;
+};
+WorkArea carve_work(const TileListPlan& pl, void* work, size_t T) {
+    WorkArea w;
+    char* p = (char*)work;
+    w.table = (uint32_t*)p; p += ggr_align(pl.table_words * 4);
+    w.gsum = (uint32_t*)p; p += ggr_align(pl.gsum_words * 4);
+    w.tile_start = (uint32_t*)p; p += ggr_align((T ? T : 1) * 4);
+    w.rect_sorted = (uint2*)p;
+    return w;
+}
+}  // namespace
+
 void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                             const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, hipStream_t s) {
-    uint32_t* table = (uint32_t*)work;
-    uint32_t* gsum = (uint32_t*)((char*)work + ggr_align(pl.table_words * 4));
-    uint32_t* tile_start = (uint32_t*)((char*)gsum + ggr_align(pl.gsum_words * 4));
-    if (T == 0) {
+    const WorkArea w = carve_work(pl, work, T);
+    if (T == 0 || P == 0) {
         (void)hipMemsetAsync(total_out, 0, 4, s);
+        if (T) (void)hipMemsetAsync(ranges, 0, T * sizeof(uint2), s);
         return;
     }
+    hipLaunchKernelGGL(gather_rect_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (uint32_t)P, order, rect,
+                       w.rect_sorted);
     hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nchunks, pl.nbands), dim3(256), pl.band_tiles * 4, s, (uint32_t)P,
-                       order, rect, (uint32_t)T, pl.band_tiles, (uint32_t)grid_x, table);
+                       order, w.rect_sorted, (uint32_t)T, pl.band_tiles, (uint32_t)grid_x, w.table);
     const unsigned tb = (unsigned)((T + 255) / 256);
-    hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, table, (uint32_t)T, pl.nchunks,
-                       pl.chunks_per_group, gsum);
-    hipLaunchKernelGGL(bin_tile_scan_kernel, dim3(1), dim3(1024), 0, s, gsum, (uint32_t)T, pl.groups, tile_start,
-                       ranges, total_out);
-    hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, table, (uint32_t)T, pl.nchunks,
-                       pl.chunks_per_group, gsum, tile_start);
+    (void)hipMemsetAsync(w.tile_start, 0, T * 4, s);
+    hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
+                       pl.chunks_per_group, w.gsum, w.tile_start);
+    hipLaunchKernelGGL(bin_tile_scan_kernel, dim3(1), dim3(1024), 0, s, (uint32_t)T, w.tile_start, ranges, total_out);
+    hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
+                       pl.chunks_per_group, w.gsum, w.tile_start);
 }
 
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                               const uint2* rect, const void* work, uint32_t* point_list, hipStream_t s) {
+    (void)rect;
     if (T == 0 || P == 0) return;
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks, pl.nbands), dim3(64), pl.band_tiles * 4, s, (uint32_t)P,
-                       order, rect, (uint32_t)T, pl.band_tiles, (uint32_t)grid_x, (const uint32_t*)work, point_list);
+    const WorkArea w = carve_work(pl, (void*)work, T);
+    const size_t lds = ((size_t)pl.sband_tiles + 3 * GGR_BIN_CHUNK) * 4;
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks, pl.nsbands), dim3(64), lds, s, (uint32_t)P, order,
+                       w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, point_list);
 }
 
 }  // namespace ggr
