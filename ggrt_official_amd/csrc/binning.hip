@@ -1,14 +1,13 @@
-// binning.hip — tile binning for gfx950: depth pre-sort, offsets scan, pair emission, tile sort, ranges.
+// binning.hip — the depth pre-sort of the tile binning for gfx950 (stable u32-key radix sort).
 //
-// Replaces the scan / duplicateWithKeys / 64-bit radix sort / identifyTileRanges stages of the
-// rasterizer behind reference cuda_splatting.py:114-125.
+// Part of what replaces the scan / duplicateWithKeys / 64-bit radix sort / identifyTileRanges stages of
+// the rasterizer behind reference cuda_splatting.py:114-125.
 //
-// MI355X-first reformulation (identical resulting order, ~5× less sort traffic):
+// MI355X-first reformulation (identical resulting lists, far less traffic):
 //   the reference sorts N = Σ tiles_touched pairs by the 64-bit key (tile << 32 | depth_bits) — ≥6 radix
-//   passes over N·12 B.  Here the P Gaussians are first sorted by (depth_bits) with a stable sort
-//   (ties keep ascending id, 4 passes over P·8 B, P ≪ N), pairs are emitted in that order, and a
-//   stable sort by tile id alone (⌈log2 tiles⌉ ≤ 16 bits → 2 passes over N·8 B) yields exactly the
-//   (tile, depth, id) order of the 64-bit sort.
+//   passes over N·12 B.  Here only the P Gaussians (P ≪ N) are sorted, by depth bits, with the stable
+//   sort below (ties keep ascending id, 4 passes over P·8 B); tile_lists.hip then builds the per-tile
+//   lists from that order with a stable counting sort by tile that never materialises the N pairs.
 //
 // The radix sort is hand-written for wave64: one upfront histogram of all digits, then per 8-bit digit
 // ONE kernel ("onesweep") that ranks stably with ballot-based digit matching (8 ballots per 64 keys)

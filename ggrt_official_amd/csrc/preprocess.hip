@@ -85,13 +85,26 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // lane-per-Gaussian it would touch 64 different cache lines per load instruction).
     const int sh_deg = D > 3 ? 3 : D;
     const int sh_rowf = 3 * (sh_deg + 1) * (sh_deg + 1);
-    const int sh_stride = sh_rowf | 1;  // odd stride → conflict-free per-lane row reads
+    // odd row length (GGRt: 3·M = 75 floats): the block's rows are ONE contiguous, 16-B aligned region (g0 is
+    // a multiple of 256) → copy it flat with float4 loads; an odd LDS stride is already conflict-free for
+    // the per-lane row reads, so nothing needs repacking.  Otherwise repack to the odd stride 3K | 1.
+    const bool sh_flat = ((M * 3) & 1) != 0 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0;
+    const int sh_stride = sh_flat ? M * 3 : (sh_rowf | 1);
     if (shs) {
         const size_t g0 = (size_t)blockIdx.x * blockDim.x;
         const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
         const size_t row = (size_t)M * 3;
-        if ((row & 3) == 0 && (sh_rowf & 3) == 0) {
+        if (sh_flat) {
+            const size_t total = (size_t)nG * row;
+            const float* src = shs + g0 * row;
+            const int n4 = (int)(total >> 2);
+#pragma unroll 4
+            for (int j = threadIdx.x; j < n4; j += blockDim.x)
+                reinterpret_cast<float4*>(sh_lds)[j] = reinterpret_cast<const float4*>(src)[j];
+            for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) sh_lds[j] = src[j];
+        } else if ((row & 3) == 0 && (sh_rowf & 3) == 0) {
             const int q_per = sh_rowf >> 2;
+#pragma unroll 4
             for (int j = threadIdx.x; j < nG * q_per; j += blockDim.x) {
                 const int g = j / q_per, q = j - g * q_per;
                 const float4 v = *reinterpret_cast<const float4*>(shs + (g0 + g) * row + 4 * q);
@@ -99,10 +112,12 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
         } else {
-            for (int j = threadIdx.x; j < nG * sh_rowf; j += blockDim.x) {
-                const int g = j / sh_rowf, k = j - g * sh_rowf;
-                sh_lds[g * sh_stride + k] = shs[(g0 + g) * row + k];
-            }
+            // rows not 16-B aligned (GGRt: M = 25 → 300-B rows): one wave per row, lanes along the row
+            // (contiguous 4-B loads, no per-element div/mod)
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;
+#pragma unroll 8
+            for (int g = wv; g < nG; g += nw)
+                for (int k = ln; k < sh_rowf; k += 64) sh_lds[g * sh_stride + k] = shs[(g0 + g) * row + k];
         }
         __syncthreads();
     }
@@ -234,7 +249,9 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     const int threads = 256;
     const int blocks = (P + threads - 1) / threads;
     const int deg = D > 3 ? 3 : D;
-    const size_t lds = shs ? (size_t)threads * ((3 * (deg + 1) * (deg + 1)) | 1) * sizeof(float) : 0;
+    const bool flat = ((3 * M) & 1) && (reinterpret_cast<uintptr_t>(shs) & 15) == 0;  // same predicate as the kernel
+    const size_t row_stride = flat ? (size_t)(3 * M) : (size_t)((3 * (deg + 1) * (deg + 1)) | 1);
+    const size_t lds = shs ? (size_t)threads * row_stride * sizeof(float) : 0;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                        aux_precomp, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.depth_key,

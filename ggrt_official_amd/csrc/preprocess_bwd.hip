@@ -45,14 +45,26 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const bool live = in_range && radii[i] > 0;
     // coalesced staging of the block's SH rows (same reason as in preprocess_fwd)
     const int sh_rowf = 3 * ((D > 3 ? 3 : D) + 1) * ((D > 3 ? 3 : D) + 1);
-    const int sh_stride = sh_rowf | 1;
     const bool use_sh = !has_colors_precomp && shs != nullptr;
     const size_t g0 = (size_t)blockIdx.x * blockDim.x;
     const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
     const size_t sh_row = (size_t)M * 3;
+    // odd row length (GGRt: 3·M = 75): the block's rows are ONE contiguous 16-B aligned region (g0 is a
+    // multiple of 256) → flat float4 copy in and out; an odd LDS stride is conflict-free as it is
+    const bool sh_flat = (sh_row & 1) != 0 && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
+    const int sh_stride = sh_flat ? (int)sh_row : (sh_rowf | 1);
     if (use_sh) {
-        if ((sh_row & 3) == 0 && (sh_rowf & 3) == 0) {
+        if (sh_flat) {
+            const size_t total = (size_t)nG * sh_row;
+            const float* src = shs + g0 * sh_row;
+            const int n4 = (int)(total >> 2);
+#pragma unroll 4
+            for (int j = threadIdx.x; j < n4; j += blockDim.x)
+                reinterpret_cast<float4*>(sh_lds)[j] = reinterpret_cast<const float4*>(src)[j];
+            for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) sh_lds[j] = src[j];
+        } else if ((sh_row & 3) == 0 && (sh_rowf & 3) == 0) {
             const int q_per = sh_rowf >> 2;
+#pragma unroll 4
             for (int j = threadIdx.x; j < nG * q_per; j += blockDim.x) {
                 const int g = j / q_per, q = j - g * q_per;
                 const float4 v = *reinterpret_cast<const float4*>(shs + (g0 + g) * sh_row + 4 * q);
@@ -60,10 +72,11 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
         } else {
-            for (int j = threadIdx.x; j < nG * sh_rowf; j += blockDim.x) {
-                const int g = j / sh_rowf, k = j - g * sh_rowf;
-                sh_lds[g * sh_stride + k] = shs[(g0 + g) * sh_row + k];
-            }
+            // rows not 16-B aligned (GGRt: M = 25): one wave per row, lanes along the row, no div/mod
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;
+#pragma unroll 8
+            for (int g = wv; g < nG; g += nw)
+                for (int k = ln; k < sh_rowf; k += 64) sh_lds[g * sh_stride + k] = shs[(g0 + g) * sh_row + k];
         }
         __syncthreads();
     }
@@ -295,7 +308,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         // culled Gaussian: all gradients are zero
         if (use_sh) {
             float* dsh = sh_lds + threadIdx.x * sh_stride;
-            for (int k = 0; k < sh_rowf; k++) dsh[k] = 0.f;
+            for (int k = 0; k < (sh_flat ? (int)sh_row : sh_rowf); k++) dsh[k] = 0.f;
         }
         if (has_colors_precomp) { dL_dcolors_precomp[3 * i] = 0.f; dL_dcolors_precomp[3 * i + 1] = 0.f; dL_dcolors_precomp[3 * i + 2] = 0.f; }
         if (scales && dL_dscales) {
@@ -305,8 +318,19 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     }
     if (use_sh) {
         // coalesced write-out of dL/dSH: the first 3K floats of every row from LDS, the rest zero
+        if (sh_flat && live) {  // unused coefficients (k ≥ 16) of a live row get zero gradient
+            float* dsh = sh_lds + threadIdx.x * sh_stride;
+            for (int k = sh_rowf; k < (int)sh_row; k++) dsh[k] = 0.f;
+        }
         __syncthreads();
-        if ((sh_row & 3) == 0 && (sh_rowf & 3) == 0) {
+        if (sh_flat) {
+            const size_t total = (size_t)nG * sh_row;
+            float* dst = dL_dsh + g0 * sh_row;
+            const int n4 = (int)(total >> 2);
+            for (int j = threadIdx.x; j < n4; j += blockDim.x)
+                reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(sh_lds)[j];
+            for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) dst[j] = sh_lds[j];
+        } else if ((sh_row & 3) == 0 && (sh_rowf & 3) == 0) {
             const int q_row = (int)(sh_row >> 2), q_used = sh_rowf >> 2;
             for (int j = threadIdx.x; j < nG * q_row; j += blockDim.x) {
                 const int g = j / q_row, q = j - g * q_row;
@@ -318,10 +342,11 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 *reinterpret_cast<float4*>(dL_dsh + (g0 + g) * sh_row + 4 * q) = v;
             }
         } else {
-            for (int j = threadIdx.x; j < nG * (int)sh_row; j += blockDim.x) {
-                const int g = j / (int)sh_row, k = j - g * (int)sh_row;
-                dL_dsh[(g0 + g) * sh_row + k] = k < sh_rowf ? sh_lds[g * sh_stride + k] : 0.f;
-            }
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;
+#pragma unroll 8
+            for (int g = wv; g < nG; g += nw)
+                for (int k = ln; k < (int)sh_row; k += 64)
+                    dL_dsh[(g0 + g) * sh_row + k] = k < sh_rowf ? sh_lds[g * sh_stride + k] : 0.f;
         }
     }
     if (in_range && dL_daux) dL_daux[i] = (live && dL_dz) ? dL_dz[i] : 0.f;  // aux feature: gradient is the blend's
@@ -362,7 +387,9 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     if (P <= 0) return;
     const int blocks = (P + 255) / 256;
     const int deg = D > 3 ? 3 : D;
-    const size_t lds = (!has_colors_precomp && shs) ? (size_t)256 * ((3 * (deg + 1) * (deg + 1)) | 1) * sizeof(float) : 0;
+    const bool flat = ((3 * M) & 1) && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
+    const size_t row_stride = flat ? (size_t)(3 * M) : (size_t)((3 * (deg + 1) * (deg + 1)) | 1);
+    const size_t lds = (!has_colors_precomp && shs) ? (size_t)256 * row_stride * sizeof(float) : 0;
     if (pose_acc)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,

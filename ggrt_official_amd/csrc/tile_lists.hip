@@ -206,7 +206,13 @@ TileListPlan plan_tile_lists(size_t P, size_t T) {
     p.band_tiles = (uint32_t)(T < 4096 ? (T ? T : 1) : 4096);
     p.nbands = (uint32_t)((T + p.band_tiles - 1) / p.band_tiles);
     if (p.nbands == 0) p.nbands = 1;
-    p.sband_tiles = (uint32_t)(T < 1024 ? (T ? T : 1) : 1024);
+    {   // aim for ≥ ~8192 independent walks (chunks × bands); a band is 64 … 1024 tiles
+        const size_t want_bands = (8192 + p.nchunks - 1) / p.nchunks;
+        size_t sb = ((T ? T : 1) + want_bands - 1) / want_bands;
+        sb = sb < 64 ? 64 : (sb > 1024 ? 1024 : sb);
+        if (sb > (T ? T : 1)) sb = T ? T : 1;
+        p.sband_tiles = (uint32_t)sb;
+    }
     p.nsbands = (uint32_t)((T + p.sband_tiles - 1) / p.sband_tiles);
     if (p.nsbands == 0) p.nsbands = 1;
     p.groups = p.nchunks < 32 ? p.nchunks : 32;
