@@ -3,10 +3,13 @@
 
 A "step" = one forward + one backward of the rasterizer over one synthetic frame whose inputs are
 already resident in HBM (BASELINE.json config 3: 1 M Gaussians, 1920×1080, SH degree 3, profile A —
-``ggrt_official_amd/synthetic.py``).  With N > 1 ranks every rank renders its OWN frame (frames shard
-one-per-GPU) and the step ends with the one exchange GGRt's data-parallel training has:
-an RCCL all-reduce of a flat fp32 parameter-gradient buffer sized like GGRt's encoder + pose network
-(≈65 M floats) — the rasterizer's own gradients are per-frame and are not exchanged.
+``ggrt_official_amd/synthetic.py``).  The backward produces the reference's gradient set (means3D, cov3D,
+SH, opacity, means2D) plus the camera gradient (viewmatrix / projmatrix / campos).  With N > 1 ranks
+every rank renders its OWN frame (frames shard one-per-GPU, SURVEY.md §8e: the per-frame Gaussians are
+never exchanged) and the step ends with the path's one exchange: a mean all-reduce of the camera
+gradient over RCCL.  ``--grad-buffer-floats 65000000`` additionally all-reduces a stand-in for GGRt's
+encoder + pose-network gradients (≈260 MB); that is off by default because those modules
+are outside the measured path.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying two extra objects:
   "roofline":     the dominant kernel's algorithmic bytes / its live HIP-event duration vs 8 TB/s
@@ -115,8 +118,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3", help="key of ggrt_official_amd.synthetic.CONFIGS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--grad-buffer-floats", type=int, default=65_000_000,
-                    help="size of the all-reduced parameter-gradient stand-in (N>1 only)")
+    ap.add_argument("--grad-buffer-floats", type=int, default=0,
+                    help="N>1 only: ALSO all-reduce a flat fp32 buffer of this size per step, a stand-in for GGRt's "
+                         "encoder + pose-network gradients (≈65_000_000, SURVEY.md §5); off by default because those "
+                         "modules are outside the measured path and nothing in this benchmark could overlap it")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra untimed steps with per-stage HIP events")
     args = ap.parse_args()
 
@@ -132,16 +137,21 @@ def main():
     sc = make_scene(seed=rank, **cfg).to(dev)       # one frame per rank, inputs resident in HBM
     W, H = sc.width, sc.height
     dL = upstream_gradient(W, H, seed=1234 + rank, device=dev)
-    rs = sc.settings()
+    # camera tensors are leaves too: the step produces dL/d(viewmatrix, projmatrix, campos) — the one
+    # gradient of this path that data-parallel ranks share (the per-frame Gaussians are not shared)
+    view = sc.viewmatrix.clone().requires_grad_(True)
+    proj = sc.projmatrix.clone().requires_grad_(True)
+    campos = sc.campos.clone().requires_grad_(True)
+    rs = sc.settings()._replace(viewmatrix=view, projmatrix=proj, campos=campos)
     rast = GaussianRasterizer(rs)
     means = sc.means3D.clone().requires_grad_(True)
     cov = sc.cov3D.clone().requires_grad_(True)
     op = sc.opacities.clone().requires_grad_(True)
     shs = sc.shs.clone().requires_grad_(True)
     means2D = torch.zeros_like(means, requires_grad=True)
-    leaves = (means, cov, op, shs, means2D)
-    grad_buf = torch.zeros(args.grad_buffer_floats, device=dev) if world > 1 else None
-    num_rendered = {}
+    leaves = (means, cov, op, shs, means2D, view, proj, campos)
+    pose_buf = torch.zeros(35, device=dev)
+    grad_buf = torch.zeros(args.grad_buffer_floats, device=dev) if (world > 1 and args.grad_buffer_floats) else None
 
     def step():
         for t in leaves:
@@ -149,7 +159,11 @@ def main():
         color, radii, depth = rast(means3D=means, means2D=means2D, opacities=op, shs=shs, cov3D_precomp=cov)
         (color * dL).sum().backward()
         if world > 1:
-            parallel.allreduce_mean_(grad_buf)
+            # the path's exchange step: mean all-reduce of the camera gradient over RCCL/xGMI
+            torch.cat([view.grad.reshape(-1), proj.grad.reshape(-1), campos.grad.reshape(-1)], out=pose_buf)
+            parallel.allreduce_mean_(pose_buf)
+            if grad_buf is not None:  # optional stand-in for the encoder + pose-network gradients
+                parallel.allreduce_mean_(grad_buf)
         return color
 
     log(f"scene {args.config} resident on {dev}; warmup {args.warmup}")
@@ -195,6 +209,17 @@ def main():
         b_fwd = ab["fwd_preprocess"] + ab["fwd_binning"] + ab["fwd_blend"]
         b_bwd = ab["bwd_blend"] + ab["bwd_preprocess"]
         ms_per_step = elapsed / args.steps * 1e3
+        # HBM bytes of the dominant kernel from the rocprofv3 PMC passes of this same command (FETCH_SIZE and
+        # WRITE_SIZE in separate passes, FETCH ×2 per the gfx950 correction — scripts/profile_bench.sh,
+        # scripts/pmc_summary.py); only valid for the configuration it was collected on (C3)
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")
+        if args.config == "C3" and os.path.exists(pmc_path):
+            kname = {"bwd_blend": "blend_bwd_kernel", "fwd_blend": "blend_fwd_kernel",
+                     "fwd_preprocess": "preprocess_fwd_kernel", "bwd_preprocess": "preprocess_bwd_kernel"}[dom]
+            for k, v in json.load(open(pmc_path)).items():
+                if kname in k:
+                    traffic = int(v["hbm_bytes_per_launch"])
         rec = {
             "metric": "Gaussian raster fwd+bwd Mpix/s @1M Gaussians 1080p",
             "value": round(world * W * H * args.steps / elapsed / 1e6, 3),
@@ -202,11 +227,13 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH deg {D}, profile {cfg['profile']}, "
-                                   f"fwd+bwd, 1 frame per GPU" + (f", + RCCL all-reduce of {args.grad_buffer_floats} "
-                                                                 f"fp32 grads" if world > 1 else ""),
+                                   f"fwd+bwd incl. camera gradient, 1 frame per GPU" +
+                                   (", RCCL all-reduce of the camera gradient" if world > 1 else "") +
+                                   (f" + of {args.grad_buffer_floats} stand-in fp32 grads"
+                                    if world > 1 and args.grad_buffer_floats else ""),
                        "num_rendered": N, "parallelism": f"frames x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes": ab[dom], "kernel_ms": round(kernel_ms[dom], 4),
                          "note": "blend kernels are fp32-VALU/exp-bound (≈160 flop per list-entry byte), not "
                                  "HBM-bound; see DESIGN.md §4"},

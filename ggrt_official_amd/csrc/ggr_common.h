@@ -129,7 +129,7 @@ static inline BwdScratch ggr_carve_bwd(void* base, size_t P) {
     L.dL_dconic = (float*)take(Pp * 12);
     L.dL_drgb = (float*)take(Pp * 12);
     L.dL_dz = (float*)take(Pp * 4);
-    L.pose_acc = (float*)take(64 * 4);
+    L.pose_acc = (float*)take((64 + ((Pp + 255) / 256) * 64) * 4);  // result row + one row of partials per block
     L.bytes = o;
     return L;
 }

@@ -18,9 +18,18 @@ __device__ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
                                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                            -0.5900435899266435f};
 
-__device__ __forceinline__ float wave_sum_all(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_take(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over the 64 lanes, valid in lane 63 (DPP row shifts + row broadcasts; no LDS traffic)
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_take<0x111>(v);        // row_shr:1
+    v += dpp_take<0x112>(v);        // row_shr:2
+    v += dpp_take<0x114>(v);        // row_shr:4
+    v += dpp_take<0x118>(v);        // row_shr:8  → lane 15 of each row = row sum
+    v += dpp_take<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+    v += dpp_take<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3
     return v;
 }
 
@@ -356,23 +365,43 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
     }
     if (POSE) {
-        // wave reduction, then one atomic per wave per component (35 components)
-        const int lane = threadIdx.x & 63;
+        // Camera gradient: 35 components summed over ALL Gaussians.  Atomics would put ≈ P/64 × 35 adds on
+        // 35 addresses (measured: 2.5 ms at P = 1 M); instead wave (DPP) → block (LDS) reduction, one row of
+        // 35 partials per block written with plain stores, and pose_finish_kernel sums the rows.
+        __shared__ float wred[4][40];  // 640 B: keeps the dynamic LDS base 16-B aligned (guide G17)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const float sv = wave_sum_all(dV[k]);
-            const float sp = wave_sum_all(dPM[k]);
-            if (lane == 0) {
-                if (sv != 0.f) atomicAdd(&pose_acc[k], sv);
-                if (sp != 0.f) atomicAdd(&pose_acc[16 + k], sp);
-            }
+            const float sv = wave_sum_lane63(dV[k]);
+            const float sp = wave_sum_lane63(dPM[k]);
+            if (lane == 63) { wred[wave][k] = sv; wred[wave][16 + k] = sp; }
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float sc = wave_sum_all(dcam[k]);
-            if (lane == 0 && sc != 0.f) atomicAdd(&pose_acc[32 + k], sc);
+            const float sc = wave_sum_lane63(dcam[k]);
+            if (lane == 63) wred[wave][32 + k] = sc;
         }
+        __syncthreads();
+        if (threadIdx.x < 35)
+            pose_acc[64 + (size_t)blockIdx.x * 64 + threadIdx.x] =
+                wred[0][threadIdx.x] + wred[1][threadIdx.x] + wred[2][threadIdx.x] + wred[3][threadIdx.x];
     }
+}
+
+// pose_acc[k] = Σ_blocks pose_acc[64 + b·64 + k]  (one workgroup per component, fixed order → deterministic)
+__global__ void __launch_bounds__(256)
+pose_finish_kernel(float* __restrict__ pose_acc, int nblocks) {
+    __shared__ float sh[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    for (int b = tid; b < nblocks; b += 256) acc += pose_acc[64 + (size_t)b * 64 + k];
+    sh[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) pose_acc[k] = sh[0];
 }
 
 void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs,
@@ -390,12 +419,13 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     const bool flat = ((3 * M) & 1) && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
     const size_t row_stride = flat ? (size_t)(3 * M) : (size_t)((3 * (deg + 1) * (deg + 1)) | 1);
     const size_t lds = (!has_colors_precomp && shs) ? (size_t)256 * row_stride * sizeof(float) : 0;
-    if (pose_acc)
+    if (pose_acc) {
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
                            campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,
                            dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
-    else
+        hipLaunchKernelGGL(pose_finish_kernel, dim3(35), dim3(256), 0, s, pose_acc, blocks);
+    } else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
                            campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,

@@ -206,7 +206,11 @@ TileListPlan plan_tile_lists(size_t P, size_t T) {
     p.band_tiles = (uint32_t)(T < 4096 ? (T ? T : 1) : 4096);
     p.nbands = (uint32_t)((T + p.band_tiles - 1) / p.band_tiles);
     if (p.nbands == 0) p.nbands = 1;
-    {   // aim for ≥ ~8192 independent walks (chunks × bands); a band is 64 … 1024 tiles
+    {   // aim for ≥ ~8192 independent walks (chunks × bands); a band is 64 … 1024 tiles.  (Tried and dropped:
+        // band-fast grid order with a band count ≡ 0 mod 8 so that one XCD's L2 owns a band's list region —
+        // rocprof shows the 4-B scattered stores leave as ≈32-B partial writes (366 MB for 43 MB of ids), but
+        // the kernel is bound by the per-step ds_add_rtn latency, not by that traffic: no gain at C3, and
+        // the smaller bands cost 20–70 % on small images.)
         const size_t want_bands = (8192 + p.nchunks - 1) / p.nchunks;
         size_t sb = ((T ? T : 1) + want_bands - 1) / want_bands;
         sb = sb < 64 ? 64 : (sb > 1024 ? 1024 : sb);
