@@ -162,26 +162,55 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // phase B: one Gaussian per step, lanes = tiles of its rect.  Distinct tiles within a step, program order
-    // across steps, and LDS executes one wave's operations in order ⇒ the lists come out stable.  The next
-    // entry is fetched while the current one is processed.
-    uint32_t gj = 0, xy = 0, wh = 0;
-    if (nh) { gj = l_id[0]; xy = l_xy[0]; wh = l_wh[0]; }
-    for (uint32_t k = 0; k < nh; k++) {
-        const uint32_t cg = gj, cxy = xy, cwh = wh;
-        if (k + 1 < nh) { gj = l_id[k + 1]; xy = l_xy[k + 1]; wh = l_wh[k + 1]; }
-        const uint32_t xj = cxy & 0xFFFFu, yj = cxy >> 16, wj = cwh & 0xFFFFu, nj = wj * (cwh >> 16);
-        const float inv_w = 1.0f / (float)wj;
-        for (uint32_t l0 = 0; l0 < nj; l0 += 64) {
-            const uint32_t l = l0 + lane;
-            if (l < nj) {
+    // across steps, and LDS executes one wave's operations in order ⇒ the lists come out stable.
+    // Every step is a ds_add_rtn → global store chain whose latency (not its issue cost) bounds the walk, so
+    // four steps are software-pipelined: four independent ds_add_rtn back to back (still in program order),
+    // then the four stores.
+    constexpr int U = 4;
+    for (uint32_t k0 = 0; k0 < nh; k0 += U) {
+        uint32_t cg[U], xj[U], yj[U], wj[U], nj[U], pos[U];
+        bool in[U];
+        float inv_w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = k0 + u < nh ? k0 + u : k0;  // tail: re-read entry k0, masked out below
+            cg[u] = l_id[k];
+            const uint32_t cxy = l_xy[k], cwh = l_wh[k];
+            xj[u] = cxy & 0xFFFFu; yj[u] = cxy >> 16; wj[u] = cwh & 0xFFFFu;
+            nj[u] = k0 + u < nh ? wj[u] * (cwh >> 16) : 0u;
+            inv_w[u] = 1.0f / (float)wj[u];
+        }
+        if (max(max(nj[0], nj[1]), max(nj[2], nj[3])) <= 64u) {
+            // all four rects fit one step each: pipeline them
+#pragma unroll
+            for (int u = 0; u < U; u++) {
                 // row / column of the l-th tile of the rect: (l + ½)/w is ≥ ½/w away from any integer, far
                 // more than the fp32 error of the product for every l < 2^16
-                const uint32_t ly = (uint32_t)(((float)l + 0.5f) * inv_w);
-                const uint32_t lx = l - ly * wj;
-                const uint32_t t = (yj + ly) * grid_x + xj + lx;
-                if (t >= lo && t < hi) {
-                    const uint32_t pos = atomicAdd(&cursor[t - lo], 1u);
-                    point_list[pos] = cg;
+                const uint32_t ly = (uint32_t)(((float)lane + 0.5f) * inv_w[u]);
+                const uint32_t lx = lane - ly * wj[u];
+                const uint32_t t = (yj[u] + ly) * grid_x + xj[u] + lx;
+                in[u] = lane < nj[u] && t >= lo && t < hi;
+                pos[u] = in[u] ? atomicAdd(&cursor[t - lo], 1u) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (in[u]) point_list[pos[u]] = cg[u];
+        } else {
+            // a rect of more than 64 tiles needs several steps; all of them must precede the next entry's
+            // (a later entry may share one of the tail tiles) → walk this group strictly one entry at a time
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                for (uint32_t l0 = 0; l0 < nj[u]; l0 += 64) {
+                    const uint32_t l = l0 + lane;
+                    if (l < nj[u]) {
+                        const uint32_t ly = (uint32_t)(((float)l + 0.5f) * inv_w[u]);
+                        const uint32_t lx = l - ly * wj[u];
+                        const uint32_t t = (yj[u] + ly) * grid_x + xj[u] + lx;
+                        if (t >= lo && t < hi) {
+                            const uint32_t p = atomicAdd(&cursor[t - lo], 1u);
+                            point_list[p] = cg[u];
+                        }
+                    }
                 }
             }
         }
