@@ -42,11 +42,18 @@ bin_count_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __
     for (uint32_t i = tid; i < hi - lo; i += 256) hist[i] = 0;
     __syncthreads();
     const uint32_t base = chunk * GGR_BIN_CHUNK;
-    for (uint32_t k = tid; k < GGR_BIN_CHUNK; k += 256) {
-        const uint32_t i = base + k;
-        if (i >= P) break;
+    // all of this thread's rects first (independent loads in flight together — the kernel is otherwise a
+    // chain of serial ≈1–2 µs round trips; PMC showed 59 % of the wave time waiting)
+    uint2 rcs[GGR_BIN_CHUNK / 256];
+#pragma unroll
+    for (uint32_t q = 0; q < GGR_BIN_CHUNK / 256; q++) {
+        const uint32_t i = base + tid + q * 256;
+        rcs[q] = i < P ? rect[i] : make_uint2(0u, 0u);  // rect_sorted: already in depth order
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < GGR_BIN_CHUNK / 256; q++) {
         uint32_t x0, y0, x1, y1;
-        unpack_rect(rect[i], x0, y0, x1, y1);  // rect_sorted: already in depth order
+        unpack_rect(rcs[q], x0, y0, x1, y1);
         if (x1 <= x0 || y1 <= y0) continue;
         if ((y1 - 1) * grid_x + x1 - 1 < lo || y0 * grid_x + x0 >= hi) continue;
         for (uint32_t y = y0; y < y1; y++)
@@ -67,6 +74,7 @@ bin_group_sum_kernel(const uint32_t* __restrict__ table, uint32_t T, uint32_t nc
     if (t >= T) return;
     const uint32_t c0 = g * chunks_per_group, c1 = min(nchunks, c0 + chunks_per_group);
     uint32_t s = 0;
+#pragma unroll 8
     for (uint32_t c = c0; c < c1; c++) s += table[(size_t)c * T + t];
     gsum[(size_t)g * T + t] = s;
     if (s) atomicAdd(&total[t], s);  // G atomics per tile at most
@@ -113,11 +121,19 @@ bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchun
     if (t >= T) return;
     const uint32_t c0 = g * chunks_per_group, c1 = min(nchunks, c0 + chunks_per_group);
     uint32_t run = tile_start[t];
+#pragma unroll 8
     for (uint32_t gg = 0; gg < g; gg++) run += gsum[(size_t)gg * T + t];  // exclusive prefix over groups
-    for (uint32_t c = c0; c < c1; c++) {
-        const uint32_t v = table[(size_t)c * T + t];
-        table[(size_t)c * T + t] = run;
-        run += v;
+    // counts first (independent loads, 8 in flight), then the running positions
+    for (uint32_t cb = c0; cb < c1; cb += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) v[u] = cb + u < c1 ? table[(size_t)(cb + u) * T + t] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++)
+            if (cb + u < c1) {
+                table[(size_t)(cb + u) * T + t] = run;
+                run += v[u];
+            }
     }
 }
 
@@ -135,26 +151,44 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
     uint32_t* l_wh = l_xy + GGR_BIN_CHUNK;
     const uint32_t chunk = blockIdx.x, band = blockIdx.y, lane = threadIdx.x;
     const uint32_t lo = band * band_tiles, hi = min(T, lo + band_tiles);
-    for (uint32_t i = lane; i < hi - lo; i += 64) cursor[i] = table[(size_t)chunk * T + lo + i];
     const uint32_t base = chunk * GGR_BIN_CHUNK;
     const uint32_t end = min(P, base + GGR_BIN_CHUNK);
-    // phase A: coalesced, independent loads; keep (in order) the Gaussians whose rect can touch the band
+    // ALL global loads of this wave are issued before anything waits on them (PMC: with the loads inside the
+    // loops, 52 % of a wave's life was spent in ≈19 serial 1–2 µs round trips): the band's start positions
+    // (≤ 1024 tiles = 16 per lane) and the chunk's 1024 (id, rect) pairs (16 per lane).
+    constexpr int NB = GGR_BIN_CHUNK / 64;
+    uint32_t cur0[16], gq[NB];
+    uint2 rq[NB];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t i = lane + 64 * q;
+        cur0[q] = i < hi - lo ? table[(size_t)chunk * T + lo + i] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        const uint32_t i = base + 64 * q + lane;
+        gq[q] = i < end ? order[i] : 0u;
+        rq[q] = i < end ? rect[i] : make_uint2(0u, 0u);  // rect is already in depth order (rect_sorted)
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t i = lane + 64 * q;
+        if (i < hi - lo) cursor[i] = cur0[q];
+    }
+    // phase A: keep (in order) the Gaussians whose rect can touch the band
     uint32_t nh = 0;
-#pragma unroll 4
-    for (uint32_t b0 = base; b0 < end; b0 += 64) {
-        const uint32_t i = b0 + lane;
-        uint32_t g = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-        if (i < end) {
-            g = order[i];
-            unpack_rect(rect[i], x0, y0, x1, y1);  // rect is already in depth order (rect_sorted)
-        }
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        const uint32_t g = gq[q];
+        uint32_t x0, y0, x1, y1;
+        unpack_rect(rq[q], x0, y0, x1, y1);
         const uint32_t w = x1 > x0 ? x1 - x0 : 0, h = y1 > y0 ? y1 - y0 : 0;
         const bool hit = w * h > 0 && (y1 - 1) * grid_x + x1 - 1 >= lo && y0 * grid_x + x0 < hi;
         const uint64_t mk = __ballot(hit);
         if (hit) {
             const uint32_t p = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
             l_id[p] = g;
-            l_xy[p] = x0 | (y0 << 16);
+            l_xy[p] = y0 * grid_x + x0 - lo;  // first tile of the rect RELATIVE to the band (may wrap below 0)
             l_wh[p] = w | (h << 16);
         }
         nh += (uint32_t)__popcll(mk);
@@ -168,29 +202,31 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
     // then the four stores.
     constexpr int U = 4;
     for (uint32_t k0 = 0; k0 < nh; k0 += U) {
-        uint32_t cg[U], xj[U], yj[U], wj[U], nj[U], pos[U];
+        uint32_t cg[U], bt[U], wj[U], nj[U], pos[U];
         bool in[U];
         float inv_w[U];
+        const uint32_t band_n = hi - lo;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t k = k0 + u < nh ? k0 + u : k0;  // tail: re-read entry k0, masked out below
             cg[u] = l_id[k];
-            const uint32_t cxy = l_xy[k], cwh = l_wh[k];
-            xj[u] = cxy & 0xFFFFu; yj[u] = cxy >> 16; wj[u] = cwh & 0xFFFFu;
+            bt[u] = l_xy[k];
+            const uint32_t cwh = l_wh[k];
+            wj[u] = cwh & 0xFFFFu;
             nj[u] = k0 + u < nh ? wj[u] * (cwh >> 16) : 0u;
-            inv_w[u] = 1.0f / (float)wj[u];
+            // v_rcp_f32 (1 ulp) is enough: (l + ½)/w is ≥ ½/w away from any integer, i.e. a relative margin
+            // of ½/(l + ½) ≥ 7.6e-6 for l < 2^16 against ≈ 2.5e-7 of rcp + multiply rounding
+            inv_w[u] = __builtin_amdgcn_rcpf((float)wj[u]);
         }
         if (max(max(nj[0], nj[1]), max(nj[2], nj[3])) <= 64u) {
             // all four rects fit one step each: pipeline them
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                // row / column of the l-th tile of the rect: (l + ½)/w is ≥ ½/w away from any integer, far
-                // more than the fp32 error of the product for every l < 2^16
-                const uint32_t ly = (uint32_t)(((float)lane + 0.5f) * inv_w[u]);
+                const uint32_t ly = (uint32_t)(((float)lane + 0.5f) * inv_w[u]);  // row of the lane-th tile
                 const uint32_t lx = lane - ly * wj[u];
-                const uint32_t t = (yj[u] + ly) * grid_x + xj[u] + lx;
-                in[u] = lane < nj[u] && t >= lo && t < hi;
-                pos[u] = in[u] ? atomicAdd(&cursor[t - lo], 1u) : 0u;
+                const uint32_t tr = bt[u] + ly * grid_x + lx;  // tile index relative to the band
+                in[u] = lane < nj[u] && tr < band_n;           // (unsigned: also rejects tiles before the band)
+                pos[u] = in[u] ? atomicAdd(&cursor[tr], 1u) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < U; u++)
@@ -205,9 +241,9 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
                     if (l < nj[u]) {
                         const uint32_t ly = (uint32_t)(((float)l + 0.5f) * inv_w[u]);
                         const uint32_t lx = l - ly * wj[u];
-                        const uint32_t t = (yj[u] + ly) * grid_x + xj[u] + lx;
-                        if (t >= lo && t < hi) {
-                            const uint32_t p = atomicAdd(&cursor[t - lo], 1u);
+                        const uint32_t tr = bt[u] + ly * grid_x + lx;
+                        if (tr < band_n) {
+                            const uint32_t p = atomicAdd(&cursor[tr], 1u);
                             point_list[p] = cg[u];
                         }
                     }
