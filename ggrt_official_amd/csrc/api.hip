@@ -122,8 +122,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     // 2. stable sort of the Gaussians by depth bits (ties keep ascending id)
     uint32_t *dk = nullptr, *order = nullptr;
     if (P > 0) {
-        HIP_TRY(hipMemcpyAsync(g.keys_a, g.depth_key, (size_t)P * 4, hipMemcpyDeviceToDevice, s));
-        ggr::launch_iota(g.vals_a, (size_t)P, s);
+        // (preprocess already wrote the keys into g.keys_a and the identity permutation into g.vals_a)
         ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, 32, &dk, &order, s);
         KCHECK(dbg, s, "depth sort");
     }

@@ -76,7 +76,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
                       const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
                       int32_t* __restrict__ radii, float4* __restrict__ splat,
-                      uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles_touched,
+                      uint32_t* __restrict__ depth_key, uint32_t* __restrict__ sort_vals,
+                      uint32_t* __restrict__ tiles_touched,
                       uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
                       float* __restrict__ cov3D_out) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_row_stride]
@@ -230,7 +231,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
     }
     radii[i] = rad_out;
-    depth_key[i] = key_out;
+    depth_key[i] = key_out;       // written straight into the depth sort's key / value input buffers
+    sort_vals[i] = (uint32_t)i;   // (saves a device memcpy and an iota launch)
     tiles_touched[i] = tiles_out;
     rect[i] = rect_out;
     clamped_out[i] = clamp_bits;
@@ -254,8 +256,8 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     const size_t lds = shs ? (size_t)threads * row_stride * sizeof(float) : 0;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
-                       aux_precomp, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.depth_key,
-                       g.tiles_touched, g.rect, g.clamped, g.cov3D);
+                       aux_precomp, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.keys_a,
+                       g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D);
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D,
