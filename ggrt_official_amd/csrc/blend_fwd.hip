@@ -74,23 +74,39 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 }
                 uint64_t m = __ballot(keep);
                 while (m) {
-                    const int j = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int e2 = s0 + j;
-                    const float4 a = stage[e2].a;
-                    const float4 b = stage[e2].b;
-                    const float4 c = stage[e2].c;
-                    const float dx = a.x - pixx, dy = a.y - pixy;
-                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                    const float alpha = fminf(GGR_ALPHA_MAX, b.y * __expf(power));
-                    bool ok = !done && power <= 0.0f && alpha >= GGR_ALPHA_MIN;
-                    const float test_T = T * (1.f - alpha);
-                    if (ok && test_T < GGR_T_MIN) { done = true; ok = false; }
-                    if (ok) {
-                        const float w = alpha * T;
-                        C0 += b.z * w; C1 += b.w * w; C2 += c.x * w; Dz += c.y * w;
-                        T = test_T;
-                        last = (uint32_t)(b0 + e2 + 1);
+                    // four survivors per trip, straight-line: their LDS broadcast reads and the geometry
+                    // (power, exp) are independent and overlap; only the T / colour updates are sequential
+                    constexpr int U = 4;
+                    int e4[U];
+                    bool has[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        has[u] = m != 0;
+                        e4[u] = s0 + (has[u] ? __builtin_ctzll(m) : 0);
+                        m &= m - 1;  // (0 stays 0)
+                    }
+                    float alpha[U], power[U];
+                    float4 rb[U], rc[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const float4 a = stage[e4[u]].a;
+                        rb[u] = stage[e4[u]].b;
+                        rc[u] = stage[e4[u]].c;
+                        const float dx = a.x - pixx, dy = a.y - pixy;
+                        power[u] = -0.5f * (a.z * dx * dx + rb[u].x * dy * dy) - a.w * dx * dy;
+                        alpha[u] = fminf(GGR_ALPHA_MAX, rb[u].y * __expf(power[u]));
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        bool ok = has[u] && !done && power[u] <= 0.0f && alpha[u] >= GGR_ALPHA_MIN;
+                        const float test_T = T * (1.f - alpha[u]);
+                        if (ok && test_T < GGR_T_MIN) { done = true; ok = false; }
+                        if (ok) {
+                            const float w = alpha[u] * T;
+                            C0 += rb[u].z * w; C1 += rb[u].w * w; C2 += rc[u].x * w; Dz += rc[u].y * w;
+                            T = test_T;
+                            last = (uint32_t)(b0 + e4[u] + 1);
+                        }
                     }
                 }
                 if (__all(done)) { wdone = true; break; }
