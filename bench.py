@@ -213,7 +213,7 @@ def main():
         # WRITE_SIZE in separate passes, FETCH ×2 per the gfx950 correction — scripts/profile_bench.sh,
         # scripts/pmc_summary.py); only valid for the configuration it was collected on (C3)
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_v6_pmc_traffic.json")
         if args.config == "C3" and os.path.exists(pmc_path):
             kname = {"bwd_blend": "blend_bwd_kernel", "fwd_blend": "blend_fwd_kernel",
                      "fwd_preprocess": "preprocess_fwd_kernel", "bwd_preprocess": "preprocess_bwd_kernel"}[dom]
@@ -242,6 +242,15 @@ def main():
             "render_backward": {"ms": round(t_bwd, 4), "algorithmic_bytes": b_bwd,
                                 "hbm_frac": round(b_bwd / (t_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            # informational: the blend kernels against the fp32 VECTOR roofline (they are VALU-, not HBM-bound).
+            # Algorithmic flops are SURVEY.md §8(d)'s: 20 flop per (list entry, pixel of its tile) forward, 2.5x
+            # that backward.  The exact quadrant cull skips most of those evaluations, so the "algorithmic"
+            # rate may exceed the 157.3 TFLOP/s peak — that excess is the cull, not a faster ALU.
+            "blend_valu_roofline": {
+                "peak_tflops": 157.3,
+                "fwd": {"algorithmic_flops": 20 * N * 256, "tflops": round(20 * N * 256 / (kernel_ms["fwd_blend"] * 1e-3) / 1e12, 1)},
+                "bwd": {"algorithmic_flops": 50 * N * 256, "tflops": round(50 * N * 256 / (kernel_ms["bwd_blend"] * 1e-3) / 1e12, 1)},
+            },
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, seed=0)
