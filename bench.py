@@ -123,6 +123,10 @@ def main():
                          "encoder + pose-network gradients (≈65_000_000, SURVEY.md §5); off by default because those "
                          "modules are outside the measured path and nothing in this benchmark could overlap it")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra untimed steps with per-stage HIP events")
+    ap.add_argument("--dist-backend", default=None,
+                    help="debug: process-group backend (default: nccl = RCCL).  `gloo` together with `--device 0` "
+                         "lets several ranks share ONE GPU to dry-run the N>1 control flow on a 1-GPU box")
+    ap.add_argument("--device", type=int, default=None, help="debug: CUDA device index instead of LOCAL_RANK")
     args = ap.parse_args()
 
     from ggrt_official_amd import GaussianRasterizer
@@ -130,7 +134,9 @@ def main():
     from ggrt_official_amd.synthetic import CONFIGS, make_scene, upstream_gradient
     from ggrt_official_amd import parallel
 
-    rank, world, local = parallel.init_from_env(args.gpus)
+    rank, world, local = parallel.init_from_env(args.gpus, backend=args.dist_backend)
+    if args.device is not None:
+        local = args.device
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     cfg = CONFIGS[args.config]
