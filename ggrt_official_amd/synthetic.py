@@ -164,4 +164,6 @@ CONFIGS = {
     "C3": dict(num_points=1_000_000, width=1920, height=1080, sh_degree=3, profile="A"),
     "C4p": dict(num_points=1_146_880, width=448, height=320, sh_degree=4, profile="B"),
     "C5p": dict(num_points=1_013_760, width=480, height=352, sh_degree=4, profile="B"),
+    # Waymo eval shape (reference waymo.py:88-90: 640×960, 5 source views → 4·2·640·960 Gaussians): scale check
+    "C6p": dict(num_points=4_915_200, width=960, height=640, sh_degree=4, profile="B"),
 }
