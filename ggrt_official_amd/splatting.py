@@ -120,58 +120,31 @@ def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, backgroun
     return out
 
 
-_VIEW_STREAMS: dict = {}
-MAX_CONCURRENT_VIEWS = 4
+def _rasterize_views(calls, aux=None):
+    """Runs the per-view rasterizer calls of a batch, serially like the reference's loop
+    (``cuda_splatting.py:93-127``) but without its two ``.item()`` syncs per view.
 
-
-def _rasterize_views(calls, aux=None, concurrent: bool = False):
-    """Runs the per-view rasterizer calls of a batch.  The reference's loop (``cuda_splatting.py:93-127``)
-    is strictly serial and every iteration contains a device→host sync.  With ``concurrent`` the views of
-    one batch are spread over up to MAX_CONCURRENT_VIEWS HIP streams: a view's
-    `num_rendered` read-back only blocks its own stream, and autograd replays each view's backward on the
-    stream its forward ran on.  Results are identical (tests/test_gpu_multiview.py) but measured gain is nil
-    (4 views, 480×352: 2.79 ms serial vs 2.87 ms): the single host thread still waits in every view's
-    read-back, so only the tail of view i overlaps the head of view i+1 — real multi-view batching needs the
-    sync-free forward.  Hence off by default."""
+    (measured and dropped in round 1: spreading the views over HIP streams gained nothing —
+    4 views at 480×352: 2.79 ms serial vs 2.87 ms on 4 streams, 3.44 ms with one host thread per stream —
+    because at GGRt's sizes a view is host-bound (≈ 270 µs of launches + the `num_rendered` read-back per
+    forward); the multi-stream autograd path also needed stream-lifetime care that is not worth carrying for
+    no gain.  The lever is a sync-free forward with fewer launches)"""
     outs = []
-    dev = calls[0][1]["means3D"].device if calls else None
-    if not concurrent or len(calls) < 2 or dev is None or dev.type != "cuda":
-        for i, (settings, kw) in enumerate(calls):
-            mean_gradients = torch.zeros_like(kw["means3D"], requires_grad=True)  # the `means2D` gradient sink
-            extra = {} if aux is None else {"aux_precomp": aux[i]}
-            outs.append(GaussianRasterizer(settings)(means2D=mean_gradients, **kw, **extra))
-        return outs
-    cur = torch.cuda.current_stream(dev)
-    pool = _VIEW_STREAMS.setdefault(dev.index, [torch.cuda.Stream(dev) for _ in range(MAX_CONCURRENT_VIEWS)])
-    used = pool[:min(len(calls), len(pool))]
-    for s in used:
-        s.wait_stream(cur)  # inputs were produced on the caller's stream
-    # (Also tried: one host thread per stream, since ctypes releases the GIL inside ggr_forward — slower,
-    # 3.44 ms: at GGRt's sizes a view is host-bound (Python + ≈20 launches), not GPU-bound.)
     for i, (settings, kw) in enumerate(calls):
-        s = used[i % len(used)]
-        with torch.cuda.stream(s):
-            mean_gradients = torch.zeros_like(kw["means3D"], requires_grad=True)
-            extra = {} if aux is None else {"aux_precomp": aux[i]}
-            out = GaussianRasterizer(settings)(means2D=mean_gradients, **kw, **extra)
-        for t in out:
-            if isinstance(t, torch.Tensor):
-                t.record_stream(cur)  # consumed on the caller's stream below
-        outs.append(out)
-    for s in used:
-        cur.wait_stream(s)
+        mean_gradients = torch.zeros_like(kw["means3D"], requires_grad=True)  # the `means2D` gradient sink
+        extra = {} if aux is None else {"aux_precomp": aux[i]}
+        outs.append(GaussianRasterizer(settings)(means2D=mean_gradients, **kw, **extra))
     return outs
 
 
 def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape, background_color: Tensor,
                 gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
-                gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True,
-                concurrent_views: bool = False) -> Tensor:
+                gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True) -> Tensor:
     """[batch] views → [batch,3,h,w] (reference ``cuda_splatting.py:49-128``)."""
     calls = boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                                gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant,
                                use_sh)
-    return torch.stack([o[0] for o in _rasterize_views(calls, concurrent=concurrent_views)])
+    return torch.stack([o[0] for o in _rasterize_views(calls)])
 
 
 def depth_to_relative_disparity(depth, near, far, eps: float = 1e-10):
@@ -213,7 +186,7 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                            background_color: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
                            gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor,
                            depth_mode: DepthRenderingMode = "depth", scale_invariant: bool = True,
-                           use_sh: bool = True, concurrent_views: bool = False):
+                           use_sh: bool = True):
     """ONE rasterization per view for what the reference obtains from two:
     ``render_cuda`` (colour, :49-128) + ``render_depth_cuda`` (:227-269).
 
@@ -227,7 +200,7 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
     calls = boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                                gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant,
                                use_sh)
-    outs = _rasterize_views(calls, aux=aux, concurrent=concurrent_views)
+    outs = _rasterize_views(calls, aux=aux)
     return torch.stack([o[0] for o in outs]), torch.stack([o[2] for o in outs])
 
 
