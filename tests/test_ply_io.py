@@ -1,0 +1,129 @@
+"""`.ply` interchange: byte layout, round trips, and the export's scene normalisation
+(reference ``ply_export.py:12-23,26-92``) checked against scipy's rotation conversions."""
+import numpy as np
+import pytest
+import torch
+
+from ggrt_official_amd import ply_io
+from ggrt_official_amd.synthetic import make_scene
+
+GOLDEN_HEADER = (b"ply\nformat binary_little_endian 1.0\nelement vertex 2\n"
+                 b"property float x\nproperty float y\nproperty float z\n"
+                 b"property float nx\nproperty float ny\nproperty float nz\n"
+                 b"property float f_dc_0\nproperty float f_dc_1\nproperty float f_dc_2\n"
+                 b"property float opacity\n"
+                 b"property float scale_0\nproperty float scale_1\nproperty float scale_2\n"
+                 b"property float rot_0\nproperty float rot_1\nproperty float rot_2\nproperty float rot_3\n"
+                 b"end_header\n")
+
+
+def test_attribute_order_matches_reference_listing():
+    assert ply_io.construct_list_of_attributes(2) == [
+        "x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2", "f_rest_0", "f_rest_1", "opacity",
+        "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+
+
+def test_header_bytes_and_payload(tmp_path):
+    table = np.arange(34, dtype=np.float32).reshape(2, 17)
+    p = tmp_path / "a" / "t.ply"                      # parent directory is created, like the reference
+    ply_io.write_vertex_table(p, table, ply_io.construct_list_of_attributes(0))
+    blob = p.read_bytes()
+    assert blob[:len(GOLDEN_HEADER)] == GOLDEN_HEADER
+    assert blob[len(GOLDEN_HEADER):] == table.astype("<f4").tobytes()
+    back, cols = ply_io.read_vertex_table(p)
+    assert cols == ply_io.construct_list_of_attributes(0) and np.array_equal(back, table)
+
+
+def test_read_rejects_bad_files(tmp_path):
+    p = tmp_path / "x.ply"
+    p.write_bytes(b"not a ply")
+    with pytest.raises(ValueError):
+        ply_io.read_vertex_table(p)
+    p.write_bytes(GOLDEN_HEADER + b"\0" * 10)          # truncated payload
+    with pytest.raises(ValueError, match="truncated"):
+        ply_io.read_vertex_table(p)
+    p.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 0\nend_header\n")
+    with pytest.raises(ValueError, match="binary_little_endian"):
+        ply_io.read_vertex_table(p)
+
+
+def test_empty_table_round_trip(tmp_path):
+    p = tmp_path / "e.ply"
+    ply_io.write_vertex_table(p, np.zeros((0, 17), np.float32), ply_io.construct_list_of_attributes(0))
+    back, cols = ply_io.read_vertex_table(p)
+    assert back.shape == (0, 17)
+
+
+def test_quaternion_conversions_agree_with_scipy():
+    from scipy.spatial.transform import Rotation as R
+    g = np.random.default_rng(0)
+    q = g.normal(size=(500, 4))
+    q[:4] = np.eye(4)                                  # pure-axis cases exercise every branch
+    m = ply_io.quat_wxyz_to_matrix(q)
+    ref = R.from_quat(q[:, [1, 2, 3, 0]]).as_matrix()
+    assert np.allclose(m, ref, atol=1e-12)
+    back = ply_io.matrix_to_quat_wxyz(m)
+    assert np.allclose(ply_io.quat_wxyz_to_matrix(back), m, atol=1e-12) and (back[:, 0] >= 0).all()
+
+
+def test_save_load_round_trip_is_lossless(tmp_path):
+    sc = make_scene(300, 64, 48, sh_degree=2, seed=3)
+    p = tmp_path / "s.ply"
+    ply_io.save_gaussians(p, sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs)
+    g = ply_io.load_gaussians(p)
+    assert torch.equal(g["means3D"], sc.means3D) and torch.equal(g["rotations"], sc.rotations)
+    assert torch.equal(g["opacities"], sc.opacities) and torch.equal(g["shs"], sc.shs)
+    assert torch.allclose(g["scales"], sc.scales, rtol=1e-6)     # stored as log
+
+
+def test_export_normalises_like_the_reference(tmp_path):
+    """Restates ply_export.py:35-75 with scipy (as the reference does) and compares the file's columns."""
+    from scipy.spatial.transform import Rotation as R
+    sc = make_scene(400, 64, 48, sh_degree=1, seed=5)
+    g = torch.Generator().manual_seed(1)
+    ext = torch.eye(4)
+    ext[:3, :3] = torch.from_numpy(R.from_rotvec([0.2, -0.4, 0.1]).as_matrix()).float()
+    ext[:3, 3] = torch.tensor([0.3, -0.2, 0.5])
+    q_xyzw = sc.rotations[:, [1, 2, 3, 0]]
+    harmonics = sc.shs.permute(0, 2, 1).contiguous()            # [G,3,d_sh] like the reference's Gaussians
+    opac = torch.rand(400, generator=g)
+    p = tmp_path / "v.ply"
+    ply_io.export_ply(ext, sc.means3D, sc.scales, q_xyzw, harmonics, opac, p)
+    t, cols = ply_io.read_vertex_table(p)
+    assert cols == ply_io.construct_list_of_attributes(0)
+
+    means = sc.means3D - sc.means3D.median(dim=0).values
+    f = means.abs().quantile(0.95, dim=0).max()
+    rot = torch.tensor(R.from_rotvec([0, 0, -45], True).as_matrix(), dtype=torch.float32) @ \
+        torch.tensor([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], dtype=torch.float32) @ ext[:3, :3].inverse()
+    want_means = (means / f) @ rot.T
+    assert np.allclose(t[:, 0:3], want_means.numpy(), atol=2e-6)
+    assert np.all(t[:, 3:6] == 0)
+    assert np.array_equal(t[:, 6:9], harmonics[..., 0].numpy())
+    assert np.array_equal(t[:, 9], opac.numpy())
+    assert np.allclose(t[:, 10:13], (sc.scales / f).log().numpy(), atol=1e-6)
+    want_rot = rot.double().numpy() @ R.from_quat(q_xyzw.double().numpy()).as_matrix()
+    assert np.allclose(ply_io.quat_wxyz_to_matrix(t[:, 13:17].astype(np.float64)), want_rot, atol=2e-6)
+    # most of the scene ends up in [-1, 1]
+    assert (np.abs(t[:, 0:3]) <= 1.0 + 1e-6).mean() > 0.9
+
+
+@pytest.mark.gpu
+def test_ply_scene_renders_bit_identically(tmp_path):
+    """A scene that travelled through a `.ply` renders (HIP path, scales+rotations inputs) to the same
+    image as the in-memory tensors: the file is a lossless fixture up to exp(log(scale)) rounding."""
+    from ggrt_official_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(5000, 160, 128, sh_degree=3, seed=11)
+    p = tmp_path / "scene.ply"
+    ply_io.save_gaussians(p, sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs)
+    g = ply_io.load_gaussians(p, device="cuda:0")
+    s = sc.to("cuda:0")
+    rast = GaussianRasterizer(s.settings())
+
+    def render(m, sca, rot, op, sh):
+        return rast(means3D=m, means2D=torch.zeros_like(m), opacities=op, shs=sh, scales=sca, rotations=rot)
+
+    img_a, radii_a, _ = render(s.means3D, s.scales.log().exp(), s.rotations, s.opacities, s.shs)
+    img_b, radii_b, _ = render(g["means3D"], g["scales"], g["rotations"], g["opacities"], g["shs"])
+    assert torch.equal(radii_a, radii_b) and torch.equal(img_a, img_b)
+    assert int((radii_a > 0).sum()) > 1000
