@@ -123,7 +123,7 @@ def test_ply_scene_renders_bit_identically(tmp_path):
     def render(m, sca, rot, op, sh):
         return rast(means3D=m, means2D=torch.zeros_like(m), opacities=op, shs=sh, scales=sca, rotations=rot)
 
-    img_a, radii_a, _ = render(s.means3D, s.scales.log().exp(), s.rotations, s.opacities, s.shs)
+    img_a, radii_a, _ = render(s.means3D, sc.scales.log().exp().to("cuda:0"), s.rotations, s.opacities, s.shs)
     img_b, radii_b, _ = render(g["means3D"], g["scales"], g["rotations"], g["opacities"], g["shs"])
     assert torch.equal(radii_a, radii_b) and torch.equal(img_a, img_b)
     assert int((radii_a > 0).sum()) > 1000
