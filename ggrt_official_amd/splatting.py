@@ -37,6 +37,10 @@ class Gaussians:
     covariances: Tensor  # [b, g, 3, 3]
     harmonics: Tensor    # [b, g, 3, d_sh]
     opacities: Tensor    # [b, g]
+    # fused-adapter form (§8f-4): set ``covariances=None`` and give the ellipsoids as world-space
+    # (scales, (w,x,y,z) quaternions) from ``adapter_scale_rotation``
+    scales: Optional[Tensor] = None     # [b, g, 3]
+    rotations: Optional[Tensor] = None  # [b, g, 4]
 
 
 @dataclass
@@ -80,18 +84,75 @@ def get_projection_matrix(near: Tensor, far: Tensor, fov_x: Tensor, fov_y: Tenso
 _TRIU = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
 
 
+def quaternion_to_matrix(q_xyzw: Tensor, eps: float = 1e-8) -> Tensor:
+    """(x,y,z,w) quaternions (any norm) → rotation matrices (reference ``encoder/common/gaussians.py:8-31``)."""
+    i, j, k, r = q_xyzw.unbind(-1)
+    s = 2 / ((q_xyzw * q_xyzw).sum(-1) + eps)
+    m = torch.stack([1 - s * (j * j + k * k), s * (i * j - k * r), s * (i * k + j * r),
+                     s * (i * j + k * r), 1 - s * (i * i + k * k), s * (j * k - i * r),
+                     s * (i * k - j * r), s * (j * k + i * r), 1 - s * (i * i + j * j)], -1)
+    return m.reshape(*q_xyzw.shape[:-1], 3, 3)
+
+
+def adapter_covariances(scales: Tensor, rotations_xyzw: Tensor, c2w_rotations: Tensor) -> Tensor:
+    """World-space covariance the way the reference's adapter builds it: ``C·R·S·Sᵀ·Rᵀ·Cᵀ``
+    (``encoder/common/gaussians.py:33-44`` + ``gaussian_adapter.py:79-81``) → [...,3,3]."""
+    L = c2w_rotations @ quaternion_to_matrix(rotations_xyzw) * scales[..., None, :]
+    return L @ L.transpose(-1, -2)
+
+
+def matrix_to_quaternion_wxyz(m: Tensor) -> Tensor:
+    """Rotation matrices [...,3,3] → unit (w,x,y,z); picks the best-conditioned of the four branches."""
+    m00, m11, m22 = m[..., 0, 0], m[..., 1, 1], m[..., 2, 2]
+    cand = torch.stack([
+        torch.stack([1 + m00 + m11 + m22, m[..., 2, 1] - m[..., 1, 2], m[..., 0, 2] - m[..., 2, 0], m[..., 1, 0] - m[..., 0, 1]], -1),
+        torch.stack([m[..., 2, 1] - m[..., 1, 2], 1 + m00 - m11 - m22, m[..., 0, 1] + m[..., 1, 0], m[..., 0, 2] + m[..., 2, 0]], -1),
+        torch.stack([m[..., 0, 2] - m[..., 2, 0], m[..., 0, 1] + m[..., 1, 0], 1 - m00 + m11 - m22, m[..., 1, 2] + m[..., 2, 1]], -1),
+        torch.stack([m[..., 1, 0] - m[..., 0, 1], m[..., 0, 2] + m[..., 2, 0], m[..., 1, 2] + m[..., 2, 1], 1 - m00 - m11 + m22], -1),
+    ], -2)
+    pick = torch.stack([m00 + m11 + m22, m00, m11, m22], -1).argmax(-1)
+    q = torch.gather(cand, -2, pick[..., None, None].expand(*pick.shape, 1, 4)).squeeze(-2)
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def adapter_scale_rotation(scales: Tensor, rotations_xyzw: Tensor, c2w_rotations: Tensor, eps: float = 1e-8):
+    """what the rasterizer needs INSTEAD of ``adapter_covariances`` — the same ellipsoid as
+    (scales[...,3], world-space unit quaternion (w,x,y,z)[...,4]), 28 B per Gaussian instead of a 36-B matrix
+    plus the [.,3,3] temporaries of three batched matmuls.  The camera-to-world rotation is composed onto
+    the Gaussian's quaternion (Hamilton product); ``R S Sᵀ Rᵀ`` itself is then evaluated inside the HIP
+    preprocess kernel (``scales``/``rotations`` inputs) and differentiated by its backward."""
+    qc = matrix_to_quaternion_wxyz(c2w_rotations)
+    x, y, z, w = (rotations_xyzw / (rotations_xyzw.norm(dim=-1, keepdim=True) + eps)).unbind(-1)
+    cw, cx, cy, cz = qc.unbind(-1)
+    q = torch.stack([cw * w - cx * x - cy * y - cz * z,
+                     cw * x + cx * w + cy * z - cz * y,
+                     cw * y - cx * z + cy * w + cz * x,
+                     cw * z + cx * y - cy * x + cz * w], -1)
+    return scales.broadcast_to(q.shape[:-1] + (3,)), q
+
+
 def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                        gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant=True,
-                       use_sh=True):
+                       use_sh=True, gaussian_scales=None, gaussian_rotations=None):
     """Everything ``render_cuda`` hands to the rasterizer, batched: a list of
     (GaussianRasterizationSettings, kwargs) per view.  Split out so the golden-vector tests can
-    compare it with what the reference's call site produces."""
+    compare it with what the reference's call site produces.
+
+    ``gaussian_covariances=None`` selects the fused-adapter form (§8f-4): ``gaussian_scales[b,g,3]`` +
+    world-space ``gaussian_rotations[b,g,4]`` (w,x,y,z) go to the rasterizer's ``scales``/``rotations``
+    inputs; the scale-invariant renormalisation then multiplies the scales by 1/near (≡ cov × 1/near²)."""
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
+    fused_adapter = gaussian_covariances is None
+    if fused_adapter and (gaussian_scales is None or gaussian_rotations is None):
+        raise ValueError("pass gaussian_covariances, or gaussian_scales together with gaussian_rotations")
     if scale_invariant:
         scale = 1 / near
         extrinsics = extrinsics.clone()
         extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
-        gaussian_covariances = gaussian_covariances * (scale[:, None, None, None] ** 2)
+        if fused_adapter:
+            gaussian_scales = gaussian_scales * scale[:, None, None]
+        else:
+            gaussian_covariances = gaussian_covariances * (scale[:, None, None, None] ** 2)
         gaussian_means = gaussian_means * scale[:, None, None]
         near = near * scale
         far = far * scale
@@ -106,7 +167,8 @@ def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, backgroun
     proj = get_projection_matrix(near, far, fov[:, 0], fov[:, 1], intrinsics).transpose(1, 2)
     view = torch.linalg.inv(extrinsics).transpose(1, 2)
     full = view @ proj
-    cov6 = torch.stack([gaussian_covariances[:, :, i, j] for i, j in _TRIU], dim=-1)  # [b, g, 6]
+    if not fused_adapter:
+        cov6 = torch.stack([gaussian_covariances[:, :, i, j] for i, j in _TRIU], dim=-1)  # [b, g, 6]
     out = []
     for i in range(b):
         settings = GaussianRasterizationSettings(
@@ -115,7 +177,11 @@ def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, backgroun
             sh_degree=degree, campos=extrinsics[i, :3, 3], prefiltered=False)
         kwargs = dict(means3D=gaussian_means[i], shs=shs[i] if use_sh else None,
                       colors_precomp=None if use_sh else shs[i, :, 0, :],
-                      opacities=gaussian_opacities[i, ..., None], cov3D_precomp=cov6[i])
+                      opacities=gaussian_opacities[i, ..., None])
+        if fused_adapter:
+            kwargs.update(scales=gaussian_scales[i], rotations=gaussian_rotations[i])
+        else:
+            kwargs.update(cov3D_precomp=cov6[i])
         out.append((settings, kwargs))
     return out
 
@@ -139,11 +205,13 @@ def _rasterize_views(calls, aux=None):
 
 def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape, background_color: Tensor,
                 gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
-                gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True) -> Tensor:
-    """[batch] views → [batch,3,h,w] (reference ``cuda_splatting.py:49-128``)."""
+                gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True,
+                gaussian_scales: Optional[Tensor] = None, gaussian_rotations: Optional[Tensor] = None) -> Tensor:
+    """[batch] views → [batch,3,h,w] (reference ``cuda_splatting.py:49-128``).  With
+    ``gaussian_covariances=None`` the ellipsoids come as scales + world quaternions (§8f-4)."""
     calls = boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                                gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant,
-                               use_sh)
+                               use_sh, gaussian_scales, gaussian_rotations)
     return torch.stack([o[0] for o in _rasterize_views(calls)])
 
 
@@ -186,7 +254,8 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                            background_color: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
                            gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor,
                            depth_mode: DepthRenderingMode = "depth", scale_invariant: bool = True,
-                           use_sh: bool = True):
+                           use_sh: bool = True, gaussian_scales: Optional[Tensor] = None,
+                           gaussian_rotations: Optional[Tensor] = None):
     """ONE rasterization per view for what the reference obtains from two:
     ``render_cuda`` (colour, :49-128) + ``render_depth_cuda`` (:227-269).
 
@@ -199,7 +268,7 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
     aux = (0.5 + SH_C0 * feat).clamp(min=0.0)
     calls = boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                                gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant,
-                               use_sh)
+                               use_sh, gaussian_scales, gaussian_rotations)
     outs = _rasterize_views(calls, aux=aux)
     return torch.stack([o[0] for o in outs]), torch.stack([o[2] for o in outs])
 
@@ -220,6 +289,17 @@ class DecoderSplattingCUDA(nn.Module):
         """[b, ...] → [(b v), ...] (every view sees the same Gaussians; the rasterizer only reads them)."""
         return t[:, None].expand(-1, v, *t.shape[1:]).reshape(-1, *t.shape[1:])
 
+    @classmethod
+    def _opt_per_view(cls, t: Optional[Tensor], v: int) -> Optional[Tensor]:
+        return None if t is None else cls._per_view(t, v)
+
+    @classmethod
+    def _ellipsoids(cls, gaussians: Gaussians, v: int) -> dict:
+        if gaussians.covariances is not None:
+            return {}
+        return dict(gaussian_scales=cls._per_view(gaussians.scales, v),
+                    gaussian_rotations=cls._per_view(gaussians.rotations, v))
+
     def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                 image_shape, depth_mode: Optional[DepthRenderingMode] = None) -> DecoderOutput:
         b, v = extrinsics.shape[:2]
@@ -227,13 +307,14 @@ class DecoderSplattingCUDA(nn.Module):
         if depth_mode is not None and self.fused_depth:
             color, depth = render_color_and_depth(
                 extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(), image_shape, bg,
-                self._per_view(gaussians.means, v), self._per_view(gaussians.covariances, v),
-                self._per_view(gaussians.harmonics, v), self._per_view(gaussians.opacities, v), depth_mode)
+                self._per_view(gaussians.means, v), self._opt_per_view(gaussians.covariances, v),
+                self._per_view(gaussians.harmonics, v), self._per_view(gaussians.opacities, v), depth_mode,
+                **self._ellipsoids(gaussians, v))
             return DecoderOutput(color.reshape(b, v, *color.shape[1:]), depth.reshape(b, v, *depth.shape[1:]))
         color = render_cuda(extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(),
                             image_shape, bg, self._per_view(gaussians.means, v),
-                            self._per_view(gaussians.covariances, v), self._per_view(gaussians.harmonics, v),
-                            self._per_view(gaussians.opacities, v))
+                            self._opt_per_view(gaussians.covariances, v), self._per_view(gaussians.harmonics, v),
+                            self._per_view(gaussians.opacities, v), **self._ellipsoids(gaussians, v))
         color = color.reshape(b, v, *color.shape[1:])
         depth = None if depth_mode is None else self.render_depth(gaussians, extrinsics, intrinsics, near, far,
                                                                   image_shape, depth_mode)
