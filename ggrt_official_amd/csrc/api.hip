@@ -202,15 +202,12 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     BwdScratch sc = ggr_carve_bwd(in->scratch, (size_t)P);
 
     StageTimer tm(s, out->stage_ms, GGR_BWD_STAGES);
-    HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));
-    HIP_TRY(hipMemsetAsync(out->dL_dmeans2D, 0, (size_t)P * 12, s));
-    HIP_TRY(hipMemsetAsync(out->dL_dopacities, 0, (size_t)P * 4, s));
+    HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));  // dL_dmeans2D / dL_dopacities are written by preprocess_bwd
     tm.mark();
 
     if (in->num_rendered > 0) {
         ggr::launch_blend_bwd(W, H, im.ranges, point_list, g.splat, st->bg, im.final_T, im.n_contrib,
-                              in->dL_dout_color, in->dL_dout_depth, out->dL_dmeans2D, sc.dL_dconic,
-                              out->dL_dopacities, sc.dL_drgb, in->dL_dout_depth ? sc.dL_dz : nullptr, s);
+                              in->dL_dout_color, in->dL_dout_depth, sc.grad2d, s);
         KCHECK(dbg, s, "blend_bwd");
     }
     tm.mark();
@@ -218,8 +215,8 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     ggr::launch_preprocess_bwd(P, st->sh_degree, st->sh_stride, in->fwd.means3D, in->fwd.shs, has_cp ? 1 : 0,
                                in->fwd.scales, in->fwd.rotations, st->scale_modifier, cov, st->viewmatrix,
                                st->projmatrix, st->campos, W, H, st->tanfovx, st->tanfovy, in->radii, g.clamped,
-                               sc.dL_dconic, sc.dL_drgb, in->dL_dout_depth ? sc.dL_dz : nullptr, out->dL_dmeans3D,
-                               out->dL_dmeans2D, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
+                               sc.grad2d, in->dL_dout_depth ? 1 : 0, out->dL_dmeans3D, out->dL_dmeans2D,
+                               out->dL_dopacities, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
                                out->dL_dscales, out->dL_drotations, in->fwd.aux_precomp ? out->dL_daux : nullptr,
                                npose ? sc.pose_acc : nullptr, s);
     KCHECK(dbg, s, "preprocess_bwd");

@@ -13,7 +13,12 @@
 //     v_permlane16_swap, then DPP row_ror:8 / row_half_mirror / quad_perm adds — that costs ≈2.3
 //     VALU ops per (entry, value) instead of 12 for nine independent butterflies;
 //   * ends with lane l holding the wave total of value (l & 7 | 8) of batch slot l >> 3, so the whole
-//     batch is committed with two vector atomic instructions (72 atomics, 64 + 8 lanes).
+//     batch is committed with two vector atomic instructions (72 atomics, 64 + 8 lanes) — into ONE 64-byte
+//     record per Gaussian (ggr_common.h GGR_G2D_*): with the nine values spread over four arrays the kernel
+//     was bound by atomic cache-line transactions (C3: 0.89 ms → 0.56 ms with the packed record).
+// Tried and rejected (round 1, measured): taking the nine sums on the idle MATRIX pipe instead — two
+// v_mfma_f32_16x16x4_f32 stages with polynomial pixel weights, layout pinned by tools/mfma_reduce_test.hip —
+// is exact but slower (0.70 ms vs 0.56 ms): 6 dependent MFMAs per entry serialise the wave.
 #include "blend_common.h"
 
 namespace ggr {
@@ -61,12 +66,10 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
                  const float* __restrict__ bg, const float* __restrict__ final_T,
                  const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                 const float* __restrict__ dL_ddepth, float* __restrict__ dL_dmean2D,
-                 float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_drgb,
-                 float* __restrict__ dL_dz) {
+                 const float* __restrict__ dL_ddepth, float* __restrict__ grad2d) {
     __shared__ StagedSplat stage[BATCH];
     __shared__ uint32_t wave_last_sh[4];
-    __shared__ uint16_t surv[4][BATCH];  // per wave: stage indices of the entries that survive its quadrant cull
+    __shared__ __attribute__((aligned(16))) uint16_t surv[4][BATCH];  // per wave: stage indices of the entries that survive its quadrant cull
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
@@ -126,8 +129,10 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         // ---- cull: compact this wave's survivors of the whole 256-entry batch into a wave-private list,
         //      so that every reduction batch below is full (a reduction costs >1000 cycles whether 1 or
         //      8 of its slots are used)
+        // (plain LDS accesses ordered by wavefront fences — a `volatile` pointer would turn every access
+        //  into flat_load/flat_store + s_waitcnt vmcnt(0))
         int ns = 0;
-        volatile uint16_t* my_surv = surv[wave];
+        uint16_t* my_surv = surv[wave];
         for (int s0 = 0; s0 < nb; s0 += 64) {
             const int e = s0 + lane;
             bool keep = false;
@@ -140,9 +145,12 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             if (keep) my_surv[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)e;
             ns += __popcll(mk);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         {
             for (int k0 = 0; k0 < ns; k0 += RB) {
+                const uint4 pk = *reinterpret_cast<const uint4*>(my_surv + k0);  // 8 × u16 indices, one broadcast read
+                const uint32_t pkw[4] = {pk.x, pk.y, pk.z, pk.w};
                 // ---- one reduction batch: up to RB surviving entries ---------------------------------
                 // Per pixel only RAW MOMENTS are formed: with m = G·dL/dα (zero on skipped lanes)
                 //   S0 = Σm, Sx = Σm·dx, Sy = Σm·dy, Sxx = Σm·dx², Sxy = Σm·dx·dy, Syy = Σm·dy²
@@ -160,7 +168,8 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 #pragma unroll
                 for (int sl = 0; sl < RB; sl++) {
                     ok_sl[sl] = k0 + sl < ns;
-                    e_sl[sl] = my_surv[ok_sl[sl] ? k0 + sl : 0];  // empty slot: any staged entry, masked by ok_sl
+                    // empty slot: any staged entry, masked by ok_sl (the list word behind `ns` is stale)
+                    e_sl[sl] = ok_sl[sl] ? __builtin_amdgcn_readfirstlane((int)((pkw[sl >> 1] >> (16 * (sl & 1))) & 0xffffu)) : 0;
                     if (ok_sl[sl] && my_slot == sl) my_e = e_sl[sl];
                 }
 #pragma unroll
@@ -219,21 +228,21 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                     const size_t g = __float_as_uint(stage[my_e].c.w);
                     const float op = b.y;
                     float val;
-                    float* dst;
                     switch (vi) {
-                        case 0: val = t_r; dst = dL_drgb + 3 * g; break;
-                        case 1: val = t_g; dst = dL_drgb + 3 * g + 1; break;
-                        case 2: val = t_b; dst = dL_drgb + 3 * g + 2; break;
-                        case 3: val = -op * (a.z * Sx + a.w * Sy) * ddelx_dx; dst = dL_dmean2D + 3 * g; break;
-                        case 4: val = -op * (b.x * Sy + a.w * Sx) * ddely_dy; dst = dL_dmean2D + 3 * g + 1; break;
-                        case 5: val = -0.5f * op * Sxx; dst = dL_dconic + 3 * g; break;
-                        case 6: val = -0.5f * op * Sxy; dst = dL_dconic + 3 * g + 1; break;
-                        default: val = -0.5f * op * Syy; dst = dL_dconic + 3 * g + 2; break;
+                        case 0: val = t_r; break;
+                        case 1: val = t_g; break;
+                        case 2: val = t_b; break;
+                        case 3: val = -op * (a.z * Sx + a.w * Sy) * ddelx_dx; break;
+                        case 4: val = -op * (b.x * Sy + a.w * Sx) * ddely_dy; break;
+                        case 5: val = -0.5f * op * Sxx; break;
+                        case 6: val = -0.5f * op * Sxy; break;
+                        default: val = -0.5f * op * Syy; break;
                     }
-                    if (val != 0.f) atomicAdd(dst, val);
-                    if (vi == 0 && S0 != 0.f) atomicAdd(dL_dopacity + g, S0);
+                    float* rec = grad2d + GGR_G2D_STRIDE * g;  // all of a slot's atomics land in one 64-B line
+                    if (val != 0.f) atomicAdd(rec + vi, val);
+                    if (vi == 0 && S0 != 0.f) atomicAdd(rec + GGR_G2D_OPACITY, S0);
                     if (HAS_DEPTH) {
-                        if (vi == 1 && t_z != 0.f) atomicAdd(dL_dz + g, t_z);
+                        if (vi == 1 && t_z != 0.f) atomicAdd(rec + GGR_G2D_Z, t_z);
                     }
                 }
             }
@@ -243,18 +252,15 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, const float* final_T, const uint32_t* n_contrib,
-                      const float* dL_dpix, const float* dL_ddepth, float* dL_dmean2D, float* dL_dconic,
-                      float* dL_dopacity, float* dL_drgb, float* dL_dz, hipStream_t s) {
+                      const float* dL_dpix, const float* dL_ddepth, float* grad2d, hipStream_t s) {
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
     if (gx * gy == 0) return;
     if (dL_ddepth)
         hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list,
-                           splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_drgb, dL_dz);
+                           splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d);
     else
         hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list,
-                           splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_drgb, dL_dz);
+                           splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d);
 }
 
 }  // namespace ggr

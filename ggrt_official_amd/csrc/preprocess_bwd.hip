@@ -41,10 +41,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ cov3D, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ campos, int W, int H,
                       float tanfovx, float tanfovy, const int32_t* __restrict__ radii,
-                      const uint32_t* __restrict__ clamped, const float* __restrict__ dL_dconic,
-                      const float* __restrict__ dL_drgb, const float* __restrict__ dL_dz,
+                      const uint32_t* __restrict__ clamped, const float* __restrict__ grad2d, int has_dz,
                       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
-                      float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
+                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_daux,
                       float* __restrict__ pose_acc) {
@@ -52,6 +51,19 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
     const bool live = in_range && radii[i] > 0;
+    // the blend backward's per-Gaussian record (ggr_common.h GGR_G2D_*): its mean2D and opacity entries are
+    // final results and are copied out here; a Gaussian no tile list holds still has its zeroed record
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    float g_z = 0.f;
+    if (in_range) {
+        const float4* rec = reinterpret_cast<const float4*>(grad2d) + (GGR_G2D_STRIDE / 4) * (size_t)i;
+        r0 = rec[0];  // r, g, b, mean.x
+        r1 = rec[1];  // mean.y, conic xx, xy, yy
+        const float2 r2 = *reinterpret_cast<const float2*>(rec + 2);  // opacity, z
+        g_z = r2.y;
+        dL_dmeans2D[3 * i] = r0.w; dL_dmeans2D[3 * i + 1] = r1.x; dL_dmeans2D[3 * i + 2] = 0.f;
+        dL_dopacity[i] = r2.x;
+    }
     // coalesced staging of the block's SH rows (same reason as in preprocess_fwd)
     const int sh_rowf = 3 * ((D > 3 ? 3 : D) + 1) * ((D > 3 ? 3 : D) + 1);
     const bool use_sh = !has_colors_precomp && shs != nullptr;
@@ -108,7 +120,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         float cov6[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) cov6[k] = cov3D[6 * (size_t)i + k];
-        const float dcon0 = dL_dconic[3 * i], dcon1 = dL_dconic[3 * i + 1], dcon2 = dL_dconic[3 * i + 2];
+        const float dcon0 = r1.y, dcon1 = r1.z, dcon2 = r1.w;
 
         const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
         float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
@@ -191,7 +203,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
 
         // mean2D (NDC units) → mean3D through the perspective divide
-        const float d2x = dL_dmeans2D[3 * i], d2y = dL_dmeans2D[3 * i + 1];
+        const float d2x = r0.w, d2y = r1.x;
         const float mh0 = PM[0] * p0 + PM[4] * p1 + PM[8] * p2 + PM[12];
         const float mh1 = PM[1] * p0 + PM[5] * p1 + PM[9] * p2 + PM[13];
         const float mh3 = PM[3] * p0 + PM[7] * p1 + PM[11] * p2 + PM[15];
@@ -213,14 +225,14 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
 
         // depth-as-feature gradient: z = t2 = [p 1]·V[:,2]
-        if (dL_dz && !dL_daux) {
-            const float gz = dL_dz[i];
+        if (has_dz && !dL_daux) {
+            const float gz = g_z;
             dmean[0] += V[2] * gz; dmean[1] += V[6] * gz; dmean[2] += V[10] * gz;
             if (POSE) { dV[2] += p0 * gz; dV[6] += p1 * gz; dV[10] += p2 * gz; dV[14] += gz; }
         }
 
         // colour
-        float dc0 = dL_drgb[3 * i], dc1 = dL_drgb[3 * i + 1], dc2 = dL_drgb[3 * i + 2];
+        float dc0 = r0.x, dc1 = r0.y, dc2 = r0.z;
         if (has_colors_precomp) {
             dL_dcolors_precomp[3 * i] = dc0; dL_dcolors_precomp[3 * i + 1] = dc1; dL_dcolors_precomp[3 * i + 2] = dc2;
         } else {
@@ -358,7 +370,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     dL_dsh[(g0 + g) * sh_row + k] = k < sh_rowf ? sh_lds[g * sh_stride + k] : 0.f;
         }
     }
-    if (in_range && dL_daux) dL_daux[i] = (live && dL_dz) ? dL_dz[i] : 0.f;  // aux feature: gradient is the blend's
+    if (in_range && dL_daux) dL_daux[i] = (live && has_dz) ? g_z : 0.f;  // aux feature: gradient is the blend's
     if (in_range) {
         dL_dmeans3D[3 * i] = dmean[0]; dL_dmeans3D[3 * i + 1] = dmean[1]; dL_dmeans3D[3 * i + 2] = dmean[2];
 #pragma unroll
@@ -409,8 +421,8 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            float scale_modifier, const float* cov3D, const float* viewmatrix,
                            const float* projmatrix, const float* campos, int W, int H, float tanfovx,
                            float tanfovy, const int32_t* radii, const uint32_t* clamped,
-                           const float* dL_dconic, const float* dL_drgb, const float* dL_dz,
-                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dsh,
+                           const float* grad2d, int has_dz, float* dL_dmeans3D, float* dL_dmeans2D,
+                           float* dL_dopacity, float* dL_dsh,
                            float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
                            float* dL_drotations, float* dL_daux, float* pose_acc, hipStream_t s) {
     if (P <= 0) return;
@@ -422,14 +434,14 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     if (pose_acc) {
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
-                           campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,
-                           dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
+                           campos, W, H, tanfovx, tanfovy, radii, clamped, grad2d, has_dz, dL_dmeans3D,
+                           dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
         hipLaunchKernelGGL(pose_finish_kernel, dim3(35), dim3(256), 0, s, pose_acc, blocks);
     } else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
-                           campos, W, H, tanfovx, tanfovy, radii, clamped, dL_dconic, dL_drgb, dL_dz, dL_dmeans3D,
-                           dL_dmeans2D, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
+                           campos, W, H, tanfovx, tanfovy, radii, clamped, grad2d, has_dz, dL_dmeans3D,
+                           dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
 }
 
 }  // namespace ggr
