@@ -136,7 +136,9 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
         val[r] = valid ? vals_in[idx] : 0u;
     }
-    volatile uint32_t* wc = wcount[wave];
+    // wave-private counters: plain LDS accesses, ordered by wavefront-scope fences (LDS executes a wave's
+    // operations in order; a `volatile` pointer here compiles to flat_load/flat_store + s_waitcnt vmcnt(0))
+    uint32_t* wc = wcount[wave];
 #pragma unroll
     for (int r = 0; r < GGR_SORT_ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
@@ -154,8 +156,10 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
         const uint32_t cnt = (uint32_t)__popcll(m);
         uint32_t prev = 0;
         if (valid) prev = wc[d];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (valid && before == 0) wc[d] = prev + cnt;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         rank[r] = prev + before;
     }

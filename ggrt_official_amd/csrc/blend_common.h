@@ -20,7 +20,9 @@ __device__ __forceinline__ float box_min_q(float mx, float my, float cxx, float 
                                            float y0, float x1, float y1) {
     const float dxl = mx - x1, dxh = mx - x0, dyl = my - y1, dyh = my - y0;
     if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return 0.f;
-    const float ry = -cxy / cyy, rx = -cxy / cxx;
+    // v_rcp_f32 (1 ulp) instead of two IEEE divisions: an edge minimiser that is off by 1e-7 relative changes q
+    // only to second order, far inside the caller's 1e-3 margin
+    const float ry = -cxy * __builtin_amdgcn_rcpf(cyy), rx = -cxy * __builtin_amdgcn_rcpf(cxx);
     auto qf = [&](float dx, float dy) { return cxx * dx * dx + 2.f * cxy * dx * dy + cyy * dy * dy; };
     const float q1 = qf(dxl, fminf(fmaxf(ry * dxl, dyl), dyh));
     const float q2 = qf(dxh, fminf(fmaxf(ry * dxh, dyl), dyh));
