@@ -105,8 +105,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const int top = (int)min(block_last, range.y - range.x);  // entries [0, top) are replayed
 
     float T = T_final;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accz = 0.f;
-    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lcz = 0.f, last_alpha = 0.f;
+    float R = T_final * bg_dot;  // everything behind the current entry, dotted with dL/dpixel (see the slot body)
 
     // which of the 9 (10) values this lane commits: value index vi = lane & 7 for the first atomic
     // instruction; lanes with (lane & 7) == 0 also commit value 8 (opacity) and 9 (depth) afterwards
@@ -155,9 +154,9 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 // Per pixel only RAW MOMENTS are formed: with m = G·dL/dα (zero on skipped lanes)
                 //   S0 = Σm, Sx = Σm·dx, Sy = Σm·dy, Sxx = Σm·dx², Sxy = Σm·dx·dy, Syy = Σm·dy²
                 // and the per-Gaussian algebra (× opacity, × conic, × W/2 …) is done ONCE per entry after the
-                // wave reduction.  A skipped lane is treated as α = 0: T·1/(1-0), w = 0 and the "colour
-                // behind" recurrence acc ← last_α·last_c + (1-last_α)·acc becomes the identity at the next
-                // entry (last_α = 0), which is exactly the reference's `continue` — no per-value selects.
+                // wave reduction.  A skipped lane is treated as α = 0: T·1/(1-0), w = 0, so T and the
+                // "everything behind" sum R pass through unchanged — exactly the reference's `continue`,
+                // without per-value selects.
                 float g_r[RB], g_g[RB], g_b[RB], g_m[RB], g_mx[RB], g_my[RB], g_mxx[RB], g_mxy[RB], g_myy[RB], g_z[RB];
                 int my_e = -1;  // stage index of slot `my_slot` (-1 = empty slot)
                 // slot → stage index, resolved with scalar ops first so that the 8 slot bodies below are
@@ -189,20 +188,17 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32 (1 ulp); __frcp_rn would expand to a 10-instruction IEEE division
                         T = T * inv;
                         const float w = alpha * T;
-                        acc0 += last_alpha * (lc0 - acc0);
-                        acc1 += last_alpha * (lc1 - acc1);
-                        acc2 += last_alpha * (lc2 - acc2);
-                        lc0 = b.z; lc1 = b.w; lc2 = c.x;
-                        float dL_dalpha = (b.z - acc0) * dp0 + (b.w - acc1) * dp1 + (c.x - acc2) * dp2;
+                        // dL/dα_s = T_s·(c_s·dp) − R_s/(1−α_s),  R_s = Σ_{s' behind s} w_s'·(c_s'·dp) + T_final·(bg·dp):
+                        // the reference's per-channel "colour behind" recurrence collapsed to ONE scalar per
+                        // pixel (T_s·acc_c = R-part/(1−α_s) summed over channels) — 8 VALU ops instead of 15
+                        float cdp = b.z * dp0 + b.w * dp1 + c.x * dp2;
                         g_r[sl] = w * dp0; g_g[sl] = w * dp1; g_b[sl] = w * dp2;
                         if (HAS_DEPTH) {
-                            accz += last_alpha * (lcz - accz);
-                            lcz = c.y;
-                            dL_dalpha += (c.y - accz) * dpz;
+                            cdp += c.y * dpz;
                             g_z[sl] = w * dpz;
                         }
-                        last_alpha = alpha;
-                        dL_dalpha = dL_dalpha * T - (T_final * inv) * bg_dot;
+                        const float dL_dalpha = T * cdp - R * inv;
+                        R += w * cdp;
                         const float mm = valid ? G * dL_dalpha : 0.f;
                         const float mdx = mm * dx, mdy = mm * dy;
                         g_m[sl] = mm; g_mx[sl] = mdx; g_my[sl] = mdy;
