@@ -123,7 +123,8 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     uint32_t *dk = nullptr, *order = nullptr;
     if (P > 0) {
         // (preprocess already wrote the keys into g.keys_a and the identity permutation into g.vals_a)
-        ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, 32, &dk, &order, s);
+        ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, 32, &dk, &order, s,
+                              /*hist_zeroed=*/true);  // by preprocess_fwd
         KCHECK(dbg, s, "depth sort");
     }
     tm.mark();
@@ -218,14 +219,10 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
                                sc.grad2d, in->dL_dout_depth ? 1 : 0, out->dL_dmeans3D, out->dL_dmeans2D,
                                out->dL_dopacities, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
                                out->dL_dscales, out->dL_drotations, in->fwd.aux_precomp ? out->dL_daux : nullptr,
-                               npose ? sc.pose_acc : nullptr, s);
+                               npose ? sc.pose_acc : nullptr, out->dL_dviewmatrix, out->dL_dprojmatrix,
+                               out->dL_dcampos, s);
     KCHECK(dbg, s, "preprocess_bwd");
     tm.mark();
-    if (npose) {
-        HIP_TRY(hipMemcpyAsync(out->dL_dviewmatrix, sc.pose_acc, 64, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(out->dL_dprojmatrix, sc.pose_acc + 16, 64, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(out->dL_dcampos, sc.pose_acc + 32, 12, hipMemcpyDeviceToDevice, s));
-    }
     return GGR_OK;
 }
 

@@ -214,12 +214,13 @@ size_t radix_hist_words(size_t n) { return GGR_HIST_STATUS + 4 * ggr_sort_blocks
 
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                       uint32_t* hist, size_t n, int nbits, uint32_t** keys_out, uint32_t** vals_out,
-                      hipStream_t s) {
+                      hipStream_t s, bool hist_zeroed) {
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     const int npasses = (nbits + GGR_RADIX_BITS - 1) / GGR_RADIX_BITS;
     if (n > 0 && npasses > 0) {
         const uint32_t ntiles = (uint32_t)ggr_sort_blocks(n);
-        (void)hipMemsetAsync(hist, 0, (GGR_HIST_STATUS + (size_t)npasses * ntiles * GGR_RADIX) * sizeof(uint32_t), s);
+        if (!hist_zeroed)  // (ggr_forward: preprocess_fwd clears the area — one launch less)
+            (void)hipMemsetAsync(hist, 0, (GGR_HIST_STATUS + (size_t)npasses * ntiles * GGR_RADIX) * sizeof(uint32_t), s);
         // one block per CU: the kernel ends with 256·npasses global atomics per block, and at 2048
         // blocks those ≈2 M contended atomics cost more (≈45 µs) than reading the keys
         // (64 blocks was tried for n ≈ 1 M: slower, 0.121 → 0.151 ms — each thread then walks 61 keys serially)

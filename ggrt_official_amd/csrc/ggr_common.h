@@ -153,7 +153,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
 // hold the result (either a or b)
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                       uint32_t* hist, size_t n, int nbits, uint32_t** keys_out, uint32_t** vals_out,
-                      hipStream_t s);
+                      hipStream_t s, bool hist_zeroed = false /*the caller already cleared ggr_sort_hist_words(n)*/);
 
 void launch_iota(uint32_t* v, size_t n, hipStream_t s);
 
@@ -187,7 +187,8 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            const float* grad2d, int has_dz, float* dL_dmeans3D, float* dL_dmeans2D,
                            float* dL_dopacity, float* dL_dsh,
                            float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
-                           float* dL_drotations, float* dL_daux, float* pose_acc, hipStream_t s);
+                           float* dL_drotations, float* dL_daux, float* pose_acc /*null: no camera gradient*/,
+                           float* dL_dview, float* dL_dproj, float* dL_dcampos, hipStream_t s);
 
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                          hipStream_t s);

@@ -79,9 +79,11 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       uint32_t* __restrict__ depth_key, uint32_t* __restrict__ sort_vals,
                       uint32_t* __restrict__ tiles_touched,
                       uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
-                      float* __restrict__ cov3D_out) {
+                      float* __restrict__ cov3D_out, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_row_stride]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // zero the depth sort's histogram / ticket / look-back words here instead of with a separate fill launch
+    for (uint32_t wz = (uint32_t)i; wz < zero_words; wz += gridDim.x * blockDim.x) zero_area[wz] = 0u;
     // Cooperative, coalesced staging of the block's SH rows (the per-Gaussian row is 12·K bytes: read
     // lane-per-Gaussian it would touch 64 different cache lines per load instruction).
     const int sh_deg = D > 3 ? 3 : D;
@@ -248,6 +250,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* campos, int W, int H, float tanfovx, float tanfovy, int32_t* radii,
                            GeomLayout g, hipStream_t s) {
     if (P <= 0) return;
+    const uint32_t zero_words = (uint32_t)ggr_sort_hist_words((size_t)P);  // the depth sort's work area (binning.hip)
     const int threads = 256;
     const int blocks = (P + threads - 1) / threads;
     const int deg = D > 3 ? 3 : D;
@@ -257,7 +260,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                        aux_precomp, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.keys_a,
-                       g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D);
+                       g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D, g.hist, zero_words);
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D,

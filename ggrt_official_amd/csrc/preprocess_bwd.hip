@@ -402,7 +402,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 
 // pose_acc[k] = Σ_blocks pose_acc[64 + b·64 + k]  (one workgroup per component, fixed order → deterministic)
 __global__ void __launch_bounds__(256)
-pose_finish_kernel(float* __restrict__ pose_acc, int nblocks) {
+pose_finish_kernel(const float* __restrict__ pose_acc, int nblocks, float* __restrict__ dL_dview,
+                   float* __restrict__ dL_dproj, float* __restrict__ dL_dcampos) {
     __shared__ float sh[256];
     const int k = blockIdx.x, tid = threadIdx.x;
     float acc = 0.f;
@@ -413,7 +414,11 @@ pose_finish_kernel(float* __restrict__ pose_acc, int nblocks) {
         if (tid < s) sh[tid] += sh[tid + s];
         __syncthreads();
     }
-    if (tid == 0) pose_acc[k] = sh[0];
+    if (tid == 0) {  // straight into the caller's tensors (was: 3 tiny device-to-device copies = 3 more launches)
+        if (k < 16) dL_dview[k] = sh[0];
+        else if (k < 32) dL_dproj[k - 16] = sh[0];
+        else dL_dcampos[k - 32] = sh[0];
+    }
 }
 
 void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs,
@@ -424,7 +429,8 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            const float* grad2d, int has_dz, float* dL_dmeans3D, float* dL_dmeans2D,
                            float* dL_dopacity, float* dL_dsh,
                            float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
-                           float* dL_drotations, float* dL_daux, float* pose_acc, hipStream_t s) {
+                           float* dL_drotations, float* dL_daux, float* pose_acc, float* dL_dview, float* dL_dproj,
+                           float* dL_dcampos, hipStream_t s) {
     if (P <= 0) return;
     const int blocks = (P + 255) / 256;
     const int deg = D > 3 ? 3 : D;
@@ -436,7 +442,7 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
                            campos, W, H, tanfovx, tanfovy, radii, clamped, grad2d, has_dz, dL_dmeans3D,
                            dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
-        hipLaunchKernelGGL(pose_finish_kernel, dim3(35), dim3(256), 0, s, pose_acc, blocks);
+        hipLaunchKernelGGL(pose_finish_kernel, dim3(35), dim3(256), 0, s, pose_acc, blocks, dL_dview, dL_dproj, dL_dcampos);
     } else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,

@@ -269,8 +269,10 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
 // rect_sorted[i] = rect[order[i]]: lets K1 / K3 stream the rects instead of chasing order[] → rect[]
 __global__ void __launch_bounds__(256)
 gather_rect_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect,
-                   uint2* __restrict__ rect_sorted) {
+                   uint2* __restrict__ rect_sorted, uint32_t* __restrict__ tile_total, uint32_t T) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    // also clears K2a's per-tile totals (saves a fill launch)
+    for (uint32_t t = i; t < T; t += gridDim.x * 256) tile_total[t] = 0u;
     if (i < P) rect_sorted[i] = rect[order[i]];
 }
 
@@ -335,11 +337,10 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
         return;
     }
     hipLaunchKernelGGL(gather_rect_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (uint32_t)P, order, rect,
-                       w.rect_sorted);
+                       w.rect_sorted, w.tile_start, (uint32_t)T);
     hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nchunks, pl.nbands), dim3(256), pl.band_tiles * 4, s, (uint32_t)P,
                        order, w.rect_sorted, (uint32_t)T, pl.band_tiles, (uint32_t)grid_x, w.table);
     const unsigned tb = (unsigned)((T + 255) / 256);
-    (void)hipMemsetAsync(w.tile_start, 0, T * 4, s);
     hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
                        pl.chunks_per_group, w.gsum, w.tile_start);
     hipLaunchKernelGGL(bin_tile_scan_kernel, dim3(1), dim3(1024), 0, s, (uint32_t)T, w.tile_start, ranges, total_out);
