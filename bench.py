@@ -163,7 +163,7 @@ def main():
         for t in leaves:
             t.grad = None
         color, radii, depth = rast(means3D=means, means2D=means2D, opacities=op, shs=shs, cov3D_precomp=cov)
-        (color * dL).sum().backward()
+        color.backward(dL)  # the upstream gradient dL/dcolor goes straight into the rasterizer's backward
         if world > 1:
             # the path's exchange step: mean all-reduce of the camera gradient over RCCL/xGMI
             torch.cat([view.grad.reshape(-1), proj.grad.reshape(-1), campos.grad.reshape(-1)], out=pose_buf)
@@ -219,7 +219,7 @@ def main():
         # WRITE_SIZE in separate passes, FETCH ×2 per the gfx950 correction — scripts/profile_bench.sh,
         # scripts/pmc_summary.py); only valid for the configuration it was collected on (C3)
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_v7_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")
         if args.config == "C3" and os.path.exists(pmc_path):
             kname = {"bwd_blend": "blend_bwd_kernel", "fwd_blend": "blend_fwd_kernel",
                      "fwd_preprocess": "preprocess_fwd_kernel", "bwd_preprocess": "preprocess_bwd_kernel"}[dom]
