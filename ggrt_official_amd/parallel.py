@@ -63,11 +63,8 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     """In-place mean all-reduce of a flat gradient buffer (one large message: xGMI rings are per-link
     bound, so one 260 MB collective beats many small ones)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        if dist.get_backend() == "nccl":  # RCCL averages inside the collective: one kernel instead of two
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-        else:  # gloo (CPU tests) has no AVG
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(dist.get_world_size())
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
     return flat
 
 
