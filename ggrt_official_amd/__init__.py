@@ -6,7 +6,8 @@ Scope: the rasterizer (forward + backward) behind a C ABI, the c
 (`render_cuda`, `render_depth_cuda`, `DecoderSplattingCUDA`), one-frame-per-GPU sharding helpers and a
 synthetic-scene generator for the benchmark.  Everything else of GGRt is out of scope.
 """
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, last_forward_status,
+                         rasterize_gaussians)
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_status"]
 __version__ = "0.1.0"

@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libggr_raster.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -36,7 +36,7 @@ class GgrForwardOut(C.Structure):
     _fields_ = [
         ("out_color", C.c_void_p), ("radii", C.c_void_p), ("out_depth", C.c_void_p), ("geom_buffer", C.c_void_p),
         ("image_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("num_rendered", C.c_int64),
-        ("stage_ms", C.c_void_p),
+        ("stage_ms", C.c_void_p), ("binning_capacity", C.c_int64),
     ]
 
 
@@ -76,6 +76,7 @@ SYMBOLS = [
                               ALLOC_FN, C.c_void_p, C.c_void_p]),
     ("ggr_backward", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrBackwardIn), C.POINTER(GgrBackwardOut),
                                C.c_void_p]),
+    ("ggr_forward_status", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_void_p]),
     ("ggr_mark_visible", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ggr_debug_unpack_geom", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),

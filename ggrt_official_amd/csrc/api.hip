@@ -133,28 +133,39 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     const ggr::TileListPlan plan = ggr::plan_tile_lists((size_t)P, tiles);
     void* work = alloc(alloc_ctx, plan.work_bytes);  // 1st allocator call: transient work area
     if (!work) return fail(GGR_E_ALLOC, "work-area allocator returned NULL");
+    // sync-free mode: the caller brought a list buffer of `binning_capacity` entries → no read-back, no host
+    // sync, no second allocator call; the whole forward (and backward) is then hipGraph-capturable
+    const bool sync_free = out->binning_capacity > 0 && out->binning_buffer != nullptr;
+    if (out->binning_capacity >= 0x7FFFFFFF) return fail(GGR_E_LIMIT, "binning_capacity too large");
+    const uint32_t capacity = sync_free ? (uint32_t)out->binning_capacity : 0xFFFFFFFFu;
     if (P > 0) {
-        ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, s);
+        ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, capacity, s);
     } else {
         HIP_TRY(hipMemsetAsync(im.ranges, 0, (tiles ? tiles : 1) * sizeof(uint2), s));
-        HIP_TRY(hipMemsetAsync(g.counters, 0, 4, s));
+        HIP_TRY(hipMemsetAsync(g.counters, 0, 8, s));
     }
     KCHECK(dbg, s, "tile_list_count");
     uint32_t num_rendered = 0;
-    HIP_TRY(hipMemcpyAsync(&num_rendered, g.counters, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));  // the single host sync of forward
-    if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
-    out->num_rendered = (int64_t)num_rendered;
-    tm.mark();
-
-    void* bin_mem = alloc(alloc_ctx, ggr_point_list_bytes(num_rendered));  // 2nd call: kept for backward
-    if (!bin_mem) return fail(GGR_E_ALLOC, "binning allocator returned NULL");
-    out->binning_buffer = bin_mem;
-    uint32_t* point_list = (uint32_t*)bin_mem;
+    uint32_t* point_list = nullptr;
+    if (!sync_free) {
+        HIP_TRY(hipMemcpyAsync(&num_rendered, g.counters, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));  // the single host sync of forward
+        if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
+        out->num_rendered = (int64_t)num_rendered;
+        tm.mark();
+        void* bin_mem = alloc(alloc_ctx, ggr_point_list_bytes(num_rendered));  // 2nd call: kept for backward
+        if (!bin_mem) return fail(GGR_E_ALLOC, "binning allocator returned NULL");
+        out->binning_buffer = bin_mem;
+        point_list = (uint32_t*)bin_mem;
+    } else {
+        out->num_rendered = -1;  // known on the device only: ggr_forward_status reads it (and the overflow flag)
+        tm.mark();
+        point_list = (uint32_t*)out->binning_buffer;
+    }
 
     // 4. in-order scatter of the ids into the per-tile lists
-    if (num_rendered > 0) {
-        ggr::launch_tile_list_scatter(plan, (size_t)P, tiles, gx, order, g.rect, work, point_list, s);
+    if (sync_free || num_rendered > 0) {
+        ggr::launch_tile_list_scatter(plan, (size_t)P, tiles, gx, order, g.rect, work, point_list, capacity, s);
         KCHECK(dbg, s, "tile_list_scatter");
     }
     tm.mark();
@@ -195,7 +206,7 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     hipStream_t s = (hipStream_t)stream;
     const int P = st->num_points, W = st->image_width, H = st->image_height;
     const bool dbg = st->debug != 0;
-    if (in->num_rendered > 0 && !in->binning_buffer) return fail(GGR_E_INVALID, "null binning buffer");
+    if (in->num_rendered != 0 && !in->binning_buffer) return fail(GGR_E_INVALID, "null binning buffer");
 
     GeomLayout g = ggr_carve_geom((void*)in->geom_buffer, (size_t)P);
     ImageLayout im = ggr_carve_image((void*)in->image_buffer, W, H);
@@ -206,7 +217,7 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));  // dL_dmeans2D / dL_dopacities are written by preprocess_bwd
     tm.mark();
 
-    if (in->num_rendered > 0) {
+    if (in->num_rendered != 0) {  // (-1: sync-free forward, count known on the device only)
         ggr::launch_blend_bwd(W, H, im.ranges, point_list, g.splat, st->bg, im.final_T, im.n_contrib,
                               in->dL_dout_color, in->dL_dout_depth, sc.grad2d, s);
         KCHECK(dbg, s, "blend_bwd");
@@ -223,6 +234,18 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
                                out->dL_dcampos, s);
     KCHECK(dbg, s, "preprocess_bwd");
     tm.mark();
+    return GGR_OK;
+}
+
+int ggr_forward_status(const void* geom_buffer, int32_t P, int64_t* num_rendered, int32_t* overflow, void* stream) {
+    g_err[0] = 0;
+    if (!geom_buffer) return fail(GGR_E_INVALID, "null geom buffer");
+    GeomLayout g = ggr_carve_geom((void*)geom_buffer, (size_t)(P > 0 ? P : 0));
+    uint32_t host[2] = {0u, 0u};
+    HIP_TRY(hipMemcpyAsync(host, g.counters, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (num_rendered) *num_rendered = (int64_t)host[0];
+    if (overflow) *overflow = (int32_t)host[1];
     return GGR_OK;
 }
 

@@ -163,12 +163,15 @@ struct TileListPlan {
     size_t table_words, gsum_words, work_bytes;
 };
 TileListPlan plan_tile_lists(size_t P, size_t T);
-// K1 + K2: fills the work area, ranges[T] and *total_out (= N, device)
+// K1 + K2: fills the work area, ranges[T], total_out[0] (= N, device) and total_out[1] (= N > capacity).
+// capacity = entries the list buffer can hold (sync-free mode: ranges are cut there); ~0u = sized exactly later
 void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
-                            const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, hipStream_t s);
-// K3: writes point_list[N]
+                            const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, uint32_t capacity,
+                            hipStream_t s);
+// K3: writes point_list[min(N, capacity)]
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
-                              const uint2* rect, const void* work, uint32_t* point_list, hipStream_t s);
+                              const uint2* rect, const void* work, uint32_t* point_list, uint32_t capacity,
+                              hipStream_t s);
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,

@@ -83,7 +83,8 @@ bin_group_sum_kernel(const uint32_t* __restrict__ table, uint32_t T, uint32_t nc
 // ---- K2b: ONE block: exclusive scan of the per-tile totals → tile_start, ranges, N --------------------
 __global__ void __launch_bounds__(1024)
 bin_tile_scan_kernel(uint32_t T, uint32_t* __restrict__ tile_start /*in: totals, out: starts*/,
-                     uint2* __restrict__ ranges, uint32_t* __restrict__ total_out) {
+                     uint2* __restrict__ ranges, uint32_t* __restrict__ total_out /*[0] = N, [1] = overflow*/,
+                     uint32_t capacity /*entries the caller's list buffer holds (sync-free mode); ~0u = exact*/) {
     // each thread owns E CONSECUTIVE tiles (E = ⌈T/1024⌉ rounded up to a multiple of 8, ≤ 64 per slab): local
     // sums, ONE block-wide scan of the 1024 partials, then the running starts — instead of T/1024 sequential
     // 1024-wide scans (16 µs → a few µs at 8160 tiles)
@@ -115,7 +116,10 @@ bin_tile_scan_kernel(uint32_t T, uint32_t* __restrict__ tile_start /*in: totals,
         for (uint32_t e = 0; e < E; e++) {
             if (first + e < T) {
                 tile_start[first + e] = start;
-                ranges[first + e] = cnt[e] ? make_uint2(start, start + cnt[e]) : make_uint2(0u, 0u);
+                // sync-free mode: a list that does not fit the caller's buffer is cut at its end (the overflow
+                // flag tells the caller that this frame is incomplete) — nothing ever reads or writes beyond it
+                const uint32_t rs = min(start, capacity), re = min(start + cnt[e], capacity);
+                ranges[first + e] = re > rs ? make_uint2(rs, re) : make_uint2(0u, 0u);
             }
             start += cnt[e];
         }
@@ -123,7 +127,10 @@ bin_tile_scan_kernel(uint32_t T, uint32_t* __restrict__ tile_start /*in: totals,
         if (tid == 1023) carry = c + incl;
         __syncthreads();
     }
-    if (tid == 0) *total_out = carry;
+    if (tid == 0) {
+        total_out[0] = carry;
+        total_out[1] = carry > capacity ? 1u : 0u;
+    }
 }
 
 // ---- K2c: table[c][t] ← absolute position of chunk c's first entry in tile t's list ------------------
@@ -154,7 +161,7 @@ bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchun
 __global__ void __launch_bounds__(64)
 bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect, uint32_t T,
                    uint32_t band_tiles, uint32_t grid_x, const uint32_t* __restrict__ table,
-                   uint32_t* __restrict__ point_list) {
+                   uint32_t* __restrict__ point_list, uint32_t capacity /*entries in point_list; ~0u = exact size*/) {
     // LDS: cursor[band_tiles] (next free list position per tile of the band) + the compacted list of this
     // chunk's Gaussians that touch the band: id, packed origin (x0 | y0<<16), packed size (w | h<<16)
     extern __shared__ uint32_t lds[];
@@ -243,7 +250,7 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
             }
 #pragma unroll
             for (int u = 0; u < U; u++)
-                if (in[u]) point_list[pos[u]] = cg[u];
+                if (in[u] && pos[u] < capacity) point_list[pos[u]] = cg[u];
         } else {
             // a rect of more than 64 tiles needs several steps; all of them must precede the next entry's
             // (a later entry may share one of the tail tiles) → walk this group strictly one entry at a time
@@ -257,7 +264,7 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
                         const uint32_t tr = bt[u] + ly * grid_x + lx;
                         if (tr < band_n) {
                             const uint32_t p = atomicAdd(&cursor[tr], 1u);
-                            point_list[p] = cg[u];
+                            if (p < capacity) point_list[p] = cg[u];
                         }
                     }
                 }
@@ -329,10 +336,11 @@ WorkArea carve_work(const TileListPlan& pl, void* work, size_t T) {
 }  // namespace
 
 void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
-                            const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, hipStream_t s) {
+                            const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, uint32_t capacity,
+                            hipStream_t s) {
     const WorkArea w = carve_work(pl, work, T);
     if (T == 0 || P == 0) {
-        (void)hipMemsetAsync(total_out, 0, 4, s);
+        (void)hipMemsetAsync(total_out, 0, 8, s);
         if (T) (void)hipMemsetAsync(ranges, 0, T * sizeof(uint2), s);
         return;
     }
@@ -343,19 +351,21 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     const unsigned tb = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
                        pl.chunks_per_group, w.gsum, w.tile_start);
-    hipLaunchKernelGGL(bin_tile_scan_kernel, dim3(1), dim3(1024), 0, s, (uint32_t)T, w.tile_start, ranges, total_out);
+    hipLaunchKernelGGL(bin_tile_scan_kernel, dim3(1), dim3(1024), 0, s, (uint32_t)T, w.tile_start, ranges, total_out,
+                       capacity);
     hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
                        pl.chunks_per_group, w.gsum, w.tile_start);
 }
 
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
-                              const uint2* rect, const void* work, uint32_t* point_list, hipStream_t s) {
+                              const uint2* rect, const void* work, uint32_t* point_list, uint32_t capacity,
+                              hipStream_t s) {
     (void)rect;
     if (T == 0 || P == 0) return;
     const WorkArea w = carve_work(pl, (void*)work, T);
     const size_t lds = ((size_t)pl.sband_tiles + 3 * GGR_BIN_CHUNK) * 4;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks, pl.nsbands), dim3(64), lds, s, (uint32_t)P, order,
-                       w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, point_list);
+                       w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, point_list, capacity);
 }
 
 }  // namespace ggr

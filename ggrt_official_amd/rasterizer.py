@@ -46,6 +46,10 @@ class GaussianRasterizationSettings(NamedTuple):
     campos: torch.Tensor
     prefiltered: bool
     debug: bool = False
+    list_capacity: int = 0  # extension.  0: exact mode (one 4-byte read-back + host sync per forward, like
+    #                         upstream).  > 0: SYNC-FREE mode — the per-tile lists go into a buffer of this many
+    #                         entries, nothing is read back, forward + backward are hipGraph-capturable; check
+    #                         `last_forward_status()` (count, overflow) whenever a sync is affordable
 
 
 class StageProfile:
@@ -172,13 +176,19 @@ class _RasterizeGaussians(torch.autograd.Function):
                                     cov3D_precomp=_ptr(cov_c), aux_precomp=_ptr(aux_c))
             fout = _lib.GgrForwardOut(out_color=color.data_ptr(), radii=_ptr(radii), out_depth=depth.data_ptr(),
                                       geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
-                                      binning_buffer=None, num_rendered=0, stage_ms=None)
+                                      binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0)
+            capacity = int(getattr(rs, "list_capacity", 0) or 0)
+            if capacity > 0:  # sync-free mode: bring the list buffer, no read-back inside ggr_forward
+                holder["bin"] = torch.empty((lib.ggr_binning_bytes(capacity, W, H),), dtype=torch.uint8, device=dev)
+                fout.binning_buffer = holder["bin"].data_ptr()
+                fout.binning_capacity = capacity
             prof = _current_profile()
             if prof is not None:
                 fout.stage_ms = C.cast(prof.fwd, C.c_void_p)
                 prof.fwd_calls += 1
             _check(lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream), "ggr_forward")
 
+        _tls.last_forward = (geom, P)
         ctx.raster_settings = rs
         ctx.num_rendered = int(fout.num_rendered)
         ctx.dims = (P, M, H, W)
@@ -254,6 +264,22 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_aux.reshape(aux_shape) if d_aux is not None else None,
             None,
         )
+
+
+def last_forward_status():
+    """(num_rendered, overflowed) of this thread's most recent forward — synchronises the stream.  Meant for
+    the sync-free mode (``list_capacity > 0``), where ``ggr_forward`` itself reads nothing back: an overflowed
+    frame was rendered from lists cut at the buffer's end and should be redone with a larger capacity."""
+    last = getattr(_tls, "last_forward", None)
+    if last is None:
+        raise RuntimeError("no forward has run on this thread")
+    geom, P = last
+    lib = _lib.load()
+    n, ov = C.c_int64(0), C.c_int32(0)
+    with torch.cuda.device(geom.device):
+        _check(lib.ggr_forward_status(geom.data_ptr(), P, C.byref(n), C.byref(ov),
+                                      torch.cuda.current_stream(geom.device).cuda_stream), "ggr_forward_status")
+    return int(n.value), bool(ov.value)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

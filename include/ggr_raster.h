@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 1
+#define GGR_ABI_VERSION 2
 
 enum {
     GGR_OK = 0,
@@ -86,11 +86,18 @@ typedef struct GgrForwardOut {
                               unpacked at :118; may be NULL */
     void* geom_buffer;     /* ggr_geom_bytes(P) bytes, caller-allocated, kept for backward */
     void* image_buffer;    /* ggr_image_bytes(W,H) bytes, caller-allocated, kept for backward */
-    void* binning_buffer;  /* OUT: what the allocator returned (kept by the caller for backward) */
-    int64_t num_rendered;  /* OUT: Σ tiles touched = length of the sorted (tile, Gaussian) list */
+    void* binning_buffer;  /* OUT: what the allocator returned (kept by the caller for backward).
+                              IN (sync-free mode): the caller's own list buffer, see binning_capacity */
+    int64_t num_rendered;  /* OUT: Σ tiles touched = length of the sorted (tile, Gaussian) list; -1 in sync-free mode */
     float* stage_ms;       /* HOST float[GGR_FWD_STAGES] or NULL.  When given, every stage is bracketed
                               with hipEvents on `stream`, the call synchronises at the end and ADDS the
                               elapsed milliseconds per stage (profiling only; costs a sync). */
+    int64_t binning_capacity; /* IN.  0: exact mode — one 4-byte read-back + host sync, then the allocator is asked for
+                              exactly num_rendered entries.  > 0 together with a non-NULL binning_buffer of
+                              ggr_binning_bytes(capacity) bytes: SYNC-FREE mode — no read-back, no host sync, no second
+                              allocator call, so forward + backward can be captured in a hipGraph.  Lists that do
+                              not fit are cut at the buffer's end and an overflow flag is raised on the device;
+                              ggr_forward_status() reads count and flag whenever the caller chooses to sync. */
 } GgrForwardOut;
 
 /* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */
@@ -157,6 +164,11 @@ int ggr_forward(const GgrSettings* settings, const GgrForwardIn* in, GgrForwardO
 /* replaces diff_gaussian_rasterization._C.rasterize_gaussians_backward */
 int ggr_backward(const GgrSettings* settings, const GgrBackwardIn* in, GgrBackwardOut* out,
                  void* stream);
+
+/* Sync-free mode: num_rendered and the overflow flag of the forward that filled `geom_buffer` (synchronises).
+ * No counterpart in the reference: upstream always reads num_rendered back inside rasterize_gaussians. */
+int ggr_forward_status(const void* geom_buffer, int32_t num_points, int64_t* num_rendered, int32_t* overflow,
+                       void* stream);
 
 /* replaces diff_gaussian_rasterization._C.mark_visible: present[P] (uint8) = view z > 0.2 */
 int ggr_mark_visible(int32_t num_points, const float* means3D, const float* viewmatrix,

@@ -19,7 +19,7 @@ def test_library_builds_and_loads():
     path = _build.build_library()
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.ggr_abi_version() == 1
+    assert lib.ggr_abi_version() == 2
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -49,7 +49,7 @@ def test_struct_layouts_match_header_sizes():
     # 64-bit ABI: sizes follow from the field lists in include/ggr_raster.h
     assert ctypes.sizeof(_lib.GgrSettings) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.GgrForwardIn) == 8 * 8
-    assert ctypes.sizeof(_lib.GgrForwardOut) == 8 * 8
+    assert ctypes.sizeof(_lib.GgrForwardOut) == 9 * 8
     assert ctypes.sizeof(_lib.GgrBackwardIn) == 8 * 8 + 8 * 8
     assert ctypes.sizeof(_lib.GgrBackwardOut) == 13 * 8
 
