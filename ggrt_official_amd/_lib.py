@@ -29,6 +29,8 @@ class GgrForwardIn(C.Structure):
     _fields_ = [
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("aux_precomp", C.c_void_p),
+        ("input_scale", C.c_void_p), ("cov3D_full", C.c_int32), ("sh_channel_major", C.c_int32),
+        ("aux_affine", C.c_int32), ("aux_a", C.c_float), ("aux_b", C.c_float),
     ]
 
 

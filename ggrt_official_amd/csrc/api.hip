@@ -76,6 +76,17 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
     return GGR_OK;
 }
 
+InputForm input_form(const GgrForwardIn* in) {
+    InputForm f;
+    f.input_scale = in->input_scale;
+    f.cov_stride = in->cov3D_full ? 9 : 6;
+    f.sh_channel_major = in->sh_channel_major ? 1 : 0;
+    f.aux_affine = (in->aux_affine && !in->aux_precomp) ? 1 : 0;
+    f.aux_a = in->aux_a;
+    f.aux_b = in->aux_b;
+    return f;
+}
+
 size_t tiles_of(int W, int H) { return (size_t)((W + GGR_TILE - 1) / GGR_TILE) * ((H + GGR_TILE - 1) / GGR_TILE); }
 
 }  // namespace
@@ -115,7 +126,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     ggr::launch_preprocess_fwd(P, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
                                in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
                                in->aux_precomp, st->viewmatrix, st->projmatrix, st->campos, W, H, st->tanfovx,
-                               st->tanfovy, out->radii, g, s);
+                               st->tanfovy, out->radii, g, input_form(in), s);
     KCHECK(dbg, s, "preprocess_fwd");
     tm.mark();
 
@@ -231,7 +242,7 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
                                out->dL_dopacities, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
                                out->dL_dscales, out->dL_drotations, in->fwd.aux_precomp ? out->dL_daux : nullptr,
                                npose ? sc.pose_acc : nullptr, out->dL_dviewmatrix, out->dL_dprojmatrix,
-                               out->dL_dcampos, s);
+                               out->dL_dcampos, input_form(&in->fwd), in->fwd.cov3D_precomp ? 1 : 0, s);
     KCHECK(dbg, s, "preprocess_bwd");
     tm.mark();
     return GGR_OK;

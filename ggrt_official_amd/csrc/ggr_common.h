@@ -139,6 +139,19 @@ static inline BwdScratch ggr_carve_bwd(void* base, size_t P) {
     return L;
 }
 
+// Input forms (call-site fusion): what reference render_cuda does with torch ops on the P-sized
+// tensors before every rasterizer call is applied on load instead (and chained through in backward).
+struct InputForm {
+    const float* input_scale;  // device scalar s or NULL (= 1): means·s, cov·s², scales·s — the 1/near
+                               // renormalisation of cuda_splatting.py:66-73
+    int cov_stride;            // 6: [P,6] upper triangle.  9: [P,3,3] row-major, entries (0,1,2,4,5,8) used —
+                               // the triu gather of :116,124
+    int sh_channel_major;      // 0: [P,M,3] (upstream).  1: [P,3,M] = GGRt's harmonics layout — saves the
+                               // transpose copy of :77 and its backward
+    int aux_affine;            // 1: blended feature = max(aux_a + aux_b·z/s, 0) instead of z — GGRt's depth pass
+    float aux_a, aux_b;        //    (:240-269: depth as a degree-0 SH coefficient) without a per-Gaussian tensor
+};
+
 // ---- kernel launchers (defined in the .hip translation units) -------------------------------
 namespace ggr {
 
@@ -147,7 +160,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
                            const float* aux_precomp, const float* viewmatrix, const float* projmatrix,
                            const float* campos, int W, int H, float tanfovx, float tanfovy, int32_t* radii,
-                           GeomLayout g, hipStream_t s);
+                           GeomLayout g, InputForm inf, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 val) pairs on bits [0, nbits); returns the buffers that
 // hold the result (either a or b)
@@ -191,7 +204,9 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            float* dL_dopacity, float* dL_dsh,
                            float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
                            float* dL_drotations, float* dL_daux, float* pose_acc /*null: no camera gradient*/,
-                           float* dL_dview, float* dL_dproj, float* dL_dcampos, hipStream_t s);
+                           float* dL_dview, float* dL_dproj, float* dL_dcampos, InputForm inf,
+                           int cov_is_input /*cov3D is the caller's tensor (in its form), not the stored one*/,
+                           hipStream_t s);
 
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                          hipStream_t s);

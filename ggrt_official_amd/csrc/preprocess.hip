@@ -79,7 +79,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       uint32_t* __restrict__ depth_key, uint32_t* __restrict__ sort_vals,
                       uint32_t* __restrict__ tiles_touched,
                       uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
-                      float* __restrict__ cov3D_out, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
+                      float* __restrict__ cov3D_out, uint32_t* __restrict__ zero_area, uint32_t zero_words,
+                      InputForm inf) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_row_stride]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // zero the depth sort's histogram / ticket / look-back words here instead of with a separate fill launch
@@ -92,7 +93,11 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // a multiple of 256) → copy it flat with float4 loads; an odd LDS stride is already conflict-free for
     // the per-lane row reads, so nothing needs repacking.  Otherwise repack to the odd stride 3K | 1.
     const bool sh_flat = ((M * 3) & 1) != 0 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0;
-    const int sh_stride = sh_flat ? M * 3 : (sh_rowf | 1);
+    // channel-major rows ([3][M], GGRt's harmonics layout): coefficient k of channel c sits at c·M + k, so the
+    // whole row is staged; k-major rows ([M][3], upstream) only need their first 3K floats
+    const int copy_row = inf.sh_channel_major ? M * 3 : sh_rowf;
+    const int sh_stride = sh_flat ? M * 3 : (copy_row | 1);
+    const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? M : 1;
     if (shs) {
         const size_t g0 = (size_t)blockIdx.x * blockDim.x;
         const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
@@ -105,8 +110,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             for (int j = threadIdx.x; j < n4; j += blockDim.x)
                 reinterpret_cast<float4*>(sh_lds)[j] = reinterpret_cast<const float4*>(src)[j];
             for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) sh_lds[j] = src[j];
-        } else if ((row & 3) == 0 && (sh_rowf & 3) == 0) {
-            const int q_per = sh_rowf >> 2;
+        } else if ((row & 3) == 0 && (copy_row & 3) == 0) {
+            const int q_per = copy_row >> 2;
 #pragma unroll 4
             for (int j = threadIdx.x; j < nG * q_per; j += blockDim.x) {
                 const int g = j / q_per, q = j - g * q_per;
@@ -120,7 +125,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;
 #pragma unroll 8
             for (int g = wv; g < nG; g += nw)
-                for (int k = ln; k < sh_rowf; k += 64) sh_lds[g * sh_stride + k] = shs[(g0 + g) * row + k];
+                for (int k = ln; k < copy_row; k += 64) sh_lds[g * sh_stride + k] = shs[(g0 + g) * row + k];
         }
         __syncthreads();
     }
@@ -135,13 +140,24 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     uint2 rect_out = make_uint2(0, 0);
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
 
-    const float p0 = means3D[3 * i], p1 = means3D[3 * i + 1], p2 = means3D[3 * i + 2];
+    // call-site fusion: the reference's 1/near renormalisation (means·s, cov·s², scales·s — cuda_splatting.py:
+    // 66-73) and its upper-triangle gather out of [P,3,3] covariances (:116,124) happen on load.  One fp32
+    // multiply per value, exactly what the torch ops of the unfused call site do.
+    const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
+    const float p0 = in_s * means3D[3 * i], p1 = in_s * means3D[3 * i + 1], p2 = in_s * means3D[3 * i + 2];
     float cov6[6];
     if (cov3D_precomp) {
+        const float s2 = in_s * in_s;
+        if (inf.cov_stride == 9) {
+            const float* c9 = cov3D_precomp + 9 * (size_t)i;
+            cov6[0] = c9[0] * s2; cov6[1] = c9[1] * s2; cov6[2] = c9[2] * s2;
+            cov6[3] = c9[4] * s2; cov6[4] = c9[5] * s2; cov6[5] = c9[8] * s2;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 6; k++) cov6[k] = cov3D_precomp[6 * (size_t)i + k];
+            for (int k = 0; k < 6; k++) cov6[k] = cov3D_precomp[6 * (size_t)i + k] * s2;
+        }
     } else {
-        float sc[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        float sc[3] = {in_s * scales[3 * i], in_s * scales[3 * i + 1], in_s * scales[3 * i + 2]};
         float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
         cov3d_from_scale_rot(sc, scale_modifier, q, cov6);
 #pragma unroll
@@ -216,7 +232,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     const float* sh = sh_lds + threadIdx.x * sh_stride;
                     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
                     for (int k = 0; k < K; k++) {
-                        r0 += B[k] * sh[3 * k]; r1 += B[k] * sh[3 * k + 1]; r2 += B[k] * sh[3 * k + 2];
+                        r0 += B[k] * sh[k * sh_ks]; r1 += B[k] * sh[k * sh_ks + sh_cs]; r2 += B[k] * sh[k * sh_ks + 2 * sh_cs];
                     }
                     r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
                     clamp_bits = (r0 < 0.f ? 1u : 0u) | (r1 < 0.f ? 2u : 0u) | (r2 < 0.f ? 4u : 0u);
@@ -228,7 +244,12 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 rect_out = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
                 s0 = make_float4(px, py, con0, con1);
                 s1 = make_float4(con2, opacities[i], rgb[0], rgb[1]);
-                s2 = make_float4(rgb[2], aux_precomp ? aux_precomp[i] : t2, 2.f * logf(255.f * opacities[i]), 0.f);  // .z = qmax for the box cull
+                // 4th blended feature: the caller's aux value, or view z, or (fused GGRt depth pass, :240-269)
+                // max(a + b·z_unscaled, 0) with z_unscaled = z / s
+                float feat = t2;
+                if (aux_precomp) feat = aux_precomp[i];
+                else if (inf.aux_affine) feat = fmaxf(inf.aux_a + inf.aux_b * (t2 / in_s), 0.f);
+                s2 = make_float4(rgb[2], feat, 2.f * logf(255.f * opacities[i]), 0.f);  // .z = qmax for the box cull
             }
         }
     }
@@ -248,19 +269,20 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
                            const float* aux_precomp, const float* viewmatrix, const float* projmatrix,
                            const float* campos, int W, int H, float tanfovx, float tanfovy, int32_t* radii,
-                           GeomLayout g, hipStream_t s) {
+                           GeomLayout g, InputForm inf, hipStream_t s) {
     if (P <= 0) return;
     const uint32_t zero_words = (uint32_t)ggr_sort_hist_words((size_t)P);  // the depth sort's work area (binning.hip)
     const int threads = 256;
     const int blocks = (P + threads - 1) / threads;
     const int deg = D > 3 ? 3 : D;
     const bool flat = ((3 * M) & 1) && (reinterpret_cast<uintptr_t>(shs) & 15) == 0;  // same predicate as the kernel
-    const size_t row_stride = flat ? (size_t)(3 * M) : (size_t)((3 * (deg + 1) * (deg + 1)) | 1);
+    const size_t copy_row = inf.sh_channel_major ? (size_t)(3 * M) : (size_t)(3 * (deg + 1) * (deg + 1));
+    const size_t row_stride = flat ? (size_t)(3 * M) : (copy_row | 1);
     const size_t lds = shs ? (size_t)threads * row_stride * sizeof(float) : 0;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                        aux_precomp, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.keys_a,
-                       g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D, g.hist, zero_words);
+                       g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D, g.hist, zero_words, inf);
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D,

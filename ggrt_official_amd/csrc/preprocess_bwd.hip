@@ -46,7 +46,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_daux,
-                      float* __restrict__ pose_acc) {
+                      float* __restrict__ pose_acc, InputForm inf, int cov_is_input) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_stride]: SH in, dL/dSH out
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
@@ -73,7 +73,11 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // odd row length (GGRt: 3·M = 75): the block's rows are ONE contiguous 16-B aligned region (g0 is a
     // multiple of 256) → flat float4 copy in and out; an odd LDS stride is conflict-free as it is
     const bool sh_flat = (sh_row & 1) != 0 && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
-    const int sh_stride = sh_flat ? (int)sh_row : (sh_rowf | 1);
+    // (input forms as in preprocess_fwd: channel-major rows are staged — and their gradient written — whole)
+    const int copy_row = inf.sh_channel_major ? (int)sh_row : sh_rowf;
+    const int sh_stride = sh_flat ? (int)sh_row : (copy_row | 1);
+    const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? M : 1;
+    const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
     if (use_sh) {
         if (sh_flat) {
             const size_t total = (size_t)nG * sh_row;
@@ -83,8 +87,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             for (int j = threadIdx.x; j < n4; j += blockDim.x)
                 reinterpret_cast<float4*>(sh_lds)[j] = reinterpret_cast<const float4*>(src)[j];
             for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) sh_lds[j] = src[j];
-        } else if ((sh_row & 3) == 0 && (sh_rowf & 3) == 0) {
-            const int q_per = sh_rowf >> 2;
+        } else if ((sh_row & 3) == 0 && (copy_row & 3) == 0) {
+            const int q_per = copy_row >> 2;
 #pragma unroll 4
             for (int j = threadIdx.x; j < nG * q_per; j += blockDim.x) {
                 const int g = j / q_per, q = j - g * q_per;
@@ -97,7 +101,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;
 #pragma unroll 8
             for (int g = wv; g < nG; g += nw)
-                for (int k = ln; k < sh_rowf; k += 64) sh_lds[g * sh_stride + k] = shs[(g0 + g) * sh_row + k];
+                for (int k = ln; k < copy_row; k += 64) sh_lds[g * sh_stride + k] = shs[(g0 + g) * sh_row + k];
         }
         __syncthreads();
     }
@@ -116,10 +120,22 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int K = (deg + 1) * (deg + 1);
 
     if (live) {
-        const float p0 = means3D[3 * i], p1 = means3D[3 * i + 1], p2 = means3D[3 * i + 2];
+        const float p0 = in_s * means3D[3 * i], p1 = in_s * means3D[3 * i + 1], p2 = in_s * means3D[3 * i + 2];
         float cov6[6];
+        if (cov_is_input) {  // the caller's covariances, in the caller's form (preprocess_fwd applies the same)
+            const float s2 = in_s * in_s;
+            if (inf.cov_stride == 9) {
+                const float* c9 = cov3D + 9 * (size_t)i;
+                cov6[0] = c9[0] * s2; cov6[1] = c9[1] * s2; cov6[2] = c9[2] * s2;
+                cov6[3] = c9[4] * s2; cov6[4] = c9[5] * s2; cov6[5] = c9[8] * s2;
+            } else {
 #pragma unroll
-        for (int k = 0; k < 6; k++) cov6[k] = cov3D[6 * (size_t)i + k];
+                for (int k = 0; k < 6; k++) cov6[k] = cov3D[6 * (size_t)i + k] * s2;
+            }
+        } else {  // scale / rotation path: what preprocess_fwd stored (already scaled)
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov6[k] = cov3D[6 * (size_t)i + k];
+        }
         const float dcon0 = r1.y, dcon1 = r1.z, dcon2 = r1.w;
 
         const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
@@ -226,7 +242,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 
         // depth-as-feature gradient: z = t2 = [p 1]·V[:,2]
         if (has_dz && !dL_daux) {
-            const float gz = g_z;
+            float gz = g_z;
+            if (inf.aux_affine)  // feature = max(a + b·z/s, 0)
+                gz = (inf.aux_a + inf.aux_b * (t2 / in_s) > 0.f) ? gz * (inf.aux_b / in_s) : 0.f;
             dmean[0] += V[2] * gz; dmean[1] += V[6] * gz; dmean[2] += V[10] * gz;
             if (POSE) { dV[2] += p0 * gz; dV[6] += p1 * gz; dV[10] += p2 * gz; dV[14] += gz; }
         }
@@ -249,8 +267,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             // helper: coefficient k with basis value Bk and basis gradient (bx,by,bz)
 #define SH_TERM(k, Bk, bx, by, bz)                                                                     \
     {                                                                                                  \
-        const float s0 = sh[3 * (k)], s1 = sh[3 * (k) + 1], s2 = sh[3 * (k) + 2];                      \
-        dsh[3 * (k)] = (Bk) * dc0; dsh[3 * (k) + 1] = (Bk) * dc1; dsh[3 * (k) + 2] = (Bk) * dc2;      \
+        const int o0 = (k) * sh_ks, o1 = o0 + sh_cs, o2 = o1 + sh_cs;                                  \
+        const float s0 = sh[o0], s1 = sh[o1], s2 = sh[o2];                                             \
+        dsh[o0] = (Bk) * dc0; dsh[o1] = (Bk) * dc1; dsh[o2] = (Bk) * dc2;                              \
         const float sd = s0 * dc0 + s1 * dc1 + s2 * dc2;                                               \
         ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                          \
     }
@@ -296,7 +315,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             const float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
                                 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
                                 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)};
-            const float sc[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1], scale_modifier * scales[3 * i + 2]};
+            const float sm = scale_modifier * in_s;  // d(sc)/d(scale input)
+            const float sc[3] = {scale_modifier * (in_s * scales[3 * i]), scale_modifier * (in_s * scales[3 * i + 1]),
+                                 scale_modifier * (in_s * scales[3 * i + 2])};
             float Mx[9];
 #pragma unroll
             for (int ii = 0; ii < 3; ii++)
@@ -317,7 +338,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     acc += dMij * R[3 * ii + j];
                     dR[3 * ii + j] = dMij * sc[j];
                 }
-                ds[j] = acc * scale_modifier;
+                ds[j] = acc * sm;
             }
             dL_dscales[3 * i] = ds[0]; dL_dscales[3 * i + 1] = ds[1]; dL_dscales[3 * i + 2] = ds[2];
             dL_drotations[4 * i] = 2.f * (z * (dR[3] - dR[1]) + y * (dR[2] - dR[6]) + x * (dR[7] - dR[5]));
@@ -329,7 +350,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         // culled Gaussian: all gradients are zero
         if (use_sh) {
             float* dsh = sh_lds + threadIdx.x * sh_stride;
-            for (int k = 0; k < (sh_flat ? (int)sh_row : sh_rowf); k++) dsh[k] = 0.f;
+            for (int k = 0; k < (sh_flat ? (int)sh_row : copy_row); k++) dsh[k] = 0.f;
         }
         if (has_colors_precomp) { dL_dcolors_precomp[3 * i] = 0.f; dL_dcolors_precomp[3 * i + 1] = 0.f; dL_dcolors_precomp[3 * i + 2] = 0.f; }
         if (scales && dL_dscales) {
@@ -339,7 +360,11 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     }
     if (use_sh) {
         // coalesced write-out of dL/dSH: the first 3K floats of every row from LDS, the rest zero
-        if (sh_flat && live) {  // unused coefficients (k ≥ 16) of a live row get zero gradient
+        if (live && inf.sh_channel_major) {  // unused coefficients (k ≥ K) of every channel get zero gradient
+            float* dsh = sh_lds + threadIdx.x * sh_stride;
+            for (int c = 0; c < 3; c++)
+                for (int k = K; k < M; k++) dsh[c * M + k] = 0.f;
+        } else if (sh_flat && live) {  // unused coefficients (k ≥ 16) of a live row get zero gradient
             float* dsh = sh_lds + threadIdx.x * sh_stride;
             for (int k = sh_rowf; k < (int)sh_row; k++) dsh[k] = 0.f;
         }
@@ -352,7 +377,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(sh_lds)[j];
             for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) dst[j] = sh_lds[j];
         } else if ((sh_row & 3) == 0 && (sh_rowf & 3) == 0) {
-            const int q_row = (int)(sh_row >> 2), q_used = sh_rowf >> 2;
+            const int q_row = (int)(sh_row >> 2), q_used = copy_row >> 2;
             for (int j = threadIdx.x; j < nG * q_row; j += blockDim.x) {
                 const int g = j / q_row, q = j - g * q_row;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -367,14 +392,24 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll 8
             for (int g = wv; g < nG; g += nw)
                 for (int k = ln; k < (int)sh_row; k += 64)
-                    dL_dsh[(g0 + g) * sh_row + k] = k < sh_rowf ? sh_lds[g * sh_stride + k] : 0.f;
+                    dL_dsh[(g0 + g) * sh_row + k] = k < copy_row ? sh_lds[g * sh_stride + k] : 0.f;
         }
     }
     if (in_range && dL_daux) dL_daux[i] = (live && has_dz) ? g_z : 0.f;  // aux feature: gradient is the blend's
     if (in_range) {
-        dL_dmeans3D[3 * i] = dmean[0]; dL_dmeans3D[3 * i + 1] = dmean[1]; dL_dmeans3D[3 * i + 2] = dmean[2];
+        // chain through the on-load input forms: means·s, cov·s² (the upper-triangle gather leaves the lower
+        // triangle of a [P,3,3] gradient at zero, as autograd does for the reference's fancy index)
+        dL_dmeans3D[3 * i] = in_s * dmean[0]; dL_dmeans3D[3 * i + 1] = in_s * dmean[1]; dL_dmeans3D[3 * i + 2] = in_s * dmean[2];
+        const float s2o = cov_is_input ? in_s * in_s : 1.0f;
+        if (cov_is_input && inf.cov_stride == 9) {
+            float* d9 = dL_dcov3D + 9 * (size_t)i;
+            d9[0] = dcov[0] * s2o; d9[1] = dcov[1] * s2o; d9[2] = dcov[2] * s2o;
+            d9[3] = 0.f;           d9[4] = dcov[3] * s2o; d9[5] = dcov[4] * s2o;
+            d9[6] = 0.f;           d9[7] = 0.f;           d9[8] = dcov[5] * s2o;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+            for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k] * s2o;
+        }
     }
     if (POSE) {
         // Camera gradient: 35 components summed over ALL Gaussians.  Atomics would put ≈ P/64 × 35 adds on
@@ -430,24 +465,25 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            float* dL_dopacity, float* dL_dsh,
                            float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
                            float* dL_drotations, float* dL_daux, float* pose_acc, float* dL_dview, float* dL_dproj,
-                           float* dL_dcampos, hipStream_t s) {
+                           float* dL_dcampos, InputForm inf, int cov_is_input, hipStream_t s) {
     if (P <= 0) return;
     const int blocks = (P + 255) / 256;
     const int deg = D > 3 ? 3 : D;
     const bool flat = ((3 * M) & 1) && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
-    const size_t row_stride = flat ? (size_t)(3 * M) : (size_t)((3 * (deg + 1) * (deg + 1)) | 1);
+    const size_t copy_row = inf.sh_channel_major ? (size_t)(3 * M) : (size_t)(3 * (deg + 1) * (deg + 1));
+    const size_t row_stride = flat ? (size_t)(3 * M) : (copy_row | 1);
     const size_t lds = (!has_colors_precomp && shs) ? (size_t)256 * row_stride * sizeof(float) : 0;
     if (pose_acc) {
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
                            campos, W, H, tanfovx, tanfovy, radii, clamped, grad2d, has_dz, dL_dmeans3D,
-                           dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
+                           dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc, inf, cov_is_input);
         hipLaunchKernelGGL(pose_finish_kernel, dim3(35), dim3(256), 0, s, pose_acc, blocks, dL_dview, dL_dproj, dL_dcampos);
     } else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
                            has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
                            campos, W, H, tanfovx, tanfovy, radii, clamped, grad2d, has_dz, dL_dmeans3D,
-                           dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc);
+                           dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc, inf, cov_is_input);
 }
 
 }  // namespace ggr

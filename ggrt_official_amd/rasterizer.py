@@ -50,6 +50,12 @@ class GaussianRasterizationSettings(NamedTuple):
     #                         upstream).  > 0: SYNC-FREE mode — the per-tile lists go into a buffer of this many
     #                         entries, nothing is read back, forward + backward are hipGraph-capturable; check
     #                         `last_forward_status()` (count, overflow) whenever a sync is affordable
+    # ---- input forms (extensions; defaults = upstream's forms).  They move the torch operations the reference's
+    # render_cuda runs over the P-sized tensors before every call (cuda_splatting.py:66-77,116,124) into the
+    # kernels' loads, see include/ggr_raster.h ----
+    input_scale: Optional[torch.Tensor] = None  # device scalar s: means·s, cov·s², scales·s (the 1/near renorm)
+    sh_channel_major: bool = False              # shs given as [P,3,M] (GGRt's harmonics layout) instead of [P,M,3]
+    aux_affine: Optional[tuple] = None          # (a, b): depth output = Σ max(a + b·z/s, 0)·α·T (GGRt's depth pass)
 
 
 class StageProfile:
@@ -146,7 +152,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         op_c = _f32c(opacities)
         sc_c, rot_c, cov_c = _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
         aux_c = _f32c(aux)
-        M = 0 if sh_c is None else int(sh_c.shape[1])
+        sh_cm = bool(getattr(rs, "sh_channel_major", False)) and sh_c is not None
+        if sh_cm and (sh_c.dim() != 3 or sh_c.shape[1] != 3):
+            raise RuntimeError("sh_channel_major expects shs of shape [P,3,M]")
+        M = 0 if sh_c is None else int(sh_c.shape[2] if sh_cm else sh_c.shape[1])
+        cov_full = cov_c is not None and cov_c.dim() == 3  # [P,3,3]: the upper triangle is gathered on load
+        in_scale = getattr(rs, "input_scale", None)
+        in_scale = None if in_scale is None else _f32c(in_scale.to(dev)).reshape(-1)[:1]
+        aux_aff = getattr(rs, "aux_affine", None) if aux_c is None else None
+        form = dict(input_scale=_ptr(in_scale), cov3D_full=int(cov_full), sh_channel_major=int(sh_cm),
+                    aux_affine=int(aux_aff is not None), aux_a=float(aux_aff[0]) if aux_aff else 0.0,
+                    aux_b=float(aux_aff[1]) if aux_aff else 0.0)
         bg = _f32c(rs.bg.to(dev))
         view, proj, cam = _f32c(viewmatrix.to(dev)), _f32c(projmatrix.to(dev)), _f32c(campos.to(dev))
         H, W = int(rs.image_height), int(rs.image_width)
@@ -173,7 +189,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             st = _settings_struct(rs, P, M, bg, view, proj, cam)
             fin = _lib.GgrForwardIn(means3D=_ptr(means3D_c), shs=_ptr(sh_c), colors_precomp=_ptr(cp_c),
                                     opacities=_ptr(op_c), scales=_ptr(sc_c), rotations=_ptr(rot_c),
-                                    cov3D_precomp=_ptr(cov_c), aux_precomp=_ptr(aux_c))
+                                    cov3D_precomp=_ptr(cov_c), aux_precomp=_ptr(aux_c), **form)
             fout = _lib.GgrForwardOut(out_color=color.data_ptr(), radii=_ptr(radii), out_depth=depth.data_ptr(),
                                       geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
                                       binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0)
@@ -192,6 +208,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = int(fout.num_rendered)
         ctx.dims = (P, M, H, W)
+        ctx.form = (form, in_scale, cov_full, sh_cm)  # in_scale kept alive for backward
         ctx.in_shapes = (means3D.shape, None if sh is None else sh.shape, opacities.shape,
                          None if aux is None else aux.shape)
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
@@ -217,8 +234,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_means3D = torch.empty((P, 3), dtype=torch.float32, device=dev)
             d_means2D = torch.empty((P, 3), dtype=torch.float32, device=dev)
             d_op = torch.empty((P,), dtype=torch.float32, device=dev)
-            d_cov = torch.empty((P, 6), dtype=torch.float32, device=dev)
-            d_sh = torch.empty((P, M, 3), dtype=torch.float32, device=dev) if sh is not None else None
+            form, _in_scale, cov_full, sh_cm = ctx.form
+            d_cov = torch.empty((P, 3, 3) if (cov_full and cov is not None) else (P, 6), dtype=torch.float32, device=dev)
+            d_sh = (torch.empty((P, 3, M) if sh_cm else (P, M, 3), dtype=torch.float32, device=dev)
+                    if sh is not None else None)
             d_cp = torch.empty((P, 3), dtype=torch.float32, device=dev) if cp is not None else None
             d_sc = torch.empty((P, 3), dtype=torch.float32, device=dev) if sc is not None else None
             d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev) if rot is not None else None
@@ -232,7 +251,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             bin_ = _lib.GgrBackwardIn(
                 fwd=_lib.GgrForwardIn(means3D=_ptr(means3D), shs=_ptr(sh), colors_precomp=_ptr(cp), opacities=_ptr(op),
                                       scales=_ptr(sc), rotations=_ptr(rot), cov3D_precomp=_ptr(cov),
-                                      aux_precomp=_ptr(aux)),
+                                      aux_precomp=_ptr(aux), **form),
                 radii=_ptr(radii), geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
                 binning_buffer=_ptr(binb), num_rendered=ctx.num_rendered, dL_dout_color=grad_color.data_ptr(),
                 dL_dout_depth=_ptr(grad_depth), scratch=scratch.data_ptr())

@@ -273,15 +273,95 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
     return torch.stack([o[0] for o in outs]), torch.stack([o[2] for o in outs])
 
 
+def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape,
+                       background_color: Tensor, gaussians: Gaussians, view_to_batch,
+                       depth_mode: Optional[DepthRenderingMode] = None, scale_invariant: bool = True):
+    """The call site with NO torch operation on a Gaussian-sized tensor (SURVEY.md §8 a2 "where time goes"):
+
+    * the Gaussians are not repeated per view (reference ``decoder_splatting_cuda.py:47-50``): view n reads
+      batch element ``view_to_batch[n]`` of ``gaussians`` directly;
+    * the 1/near renormalisation of means and covariances (``cuda_splatting.py:66-73``) travels as a device
+      scalar (``input_scale``) and is applied when the kernel loads them;
+    * ``harmonics`` stay ``[g,3,d_sh]`` (``sh_channel_major``) — no transpose copy (:77) and no copy back in
+      backward; ``covariances`` stay ``[g,3,3]`` — the upper-triangle gather (:116,124) happens on load;
+    * ``depth_mode="depth"``: the depth-as-colour feature ``max(0.5 + C0·z, 0)`` (:240-269) is formed inside the
+      kernel from the view depth (``aux_affine``); the other modes still build it with torch.
+
+    Same images and gradients as ``render_color_and_depth`` / ``render_cuda`` up to fp32 rounding
+    (``tests/test_callsite_fused.py``).  extrinsics/intrinsics/near/far/background: one row per view.
+    Returns (color [n,3,h,w], depth [n,h,w] | None)."""
+    n = extrinsics.shape[0]
+    h, w = image_shape
+    d_sh = gaussians.harmonics.shape[-1]
+    degree = isqrt(d_sh) - 1
+    if scale_invariant:
+        scale = 1 / near
+        extrinsics = extrinsics.clone()
+        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
+        near_s, far_s = near * scale, far * scale
+    else:
+        scale, near_s, far_s = None, near, far
+    fov = get_fov(intrinsics)
+    tan_host = (0.5 * fov).tan().detach().cpu().tolist()
+    proj = get_projection_matrix(near_s, far_s, fov[:, 0], fov[:, 1], intrinsics).transpose(1, 2)
+    view = torch.linalg.inv(extrinsics).transpose(1, 2)
+    full = view @ proj
+    fused_cov = gaussians.covariances is not None
+    # batch element b of every Gaussian tensor WITHOUT `t[b]`: select's backward zero-fills a full [B,…] tensor
+    # and copies the slice in, per view (0.2 ms per view for 1 M × 25 SH coefficients).  One unbind per tensor
+    # (backward = one stack) — or a free reshape when there is a single batch element, GGRt's case.
+    def per_batch(t: Optional[Tensor]):
+        if t is None:
+            return None
+        return [t.reshape(t.shape[1:])] if t.shape[0] == 1 else list(t.unbind(0))
+    g_means, g_cov, g_sh, g_op = (per_batch(gaussians.means), per_batch(gaussians.covariances),
+                                  per_batch(gaussians.harmonics), per_batch(gaussians.opacities))
+    g_scales, g_rot = per_batch(gaussians.scales), per_batch(gaussians.rotations)
+    colors, depths = [], []
+    for i in range(n):
+        b = int(view_to_batch[i])
+        aux, aux_affine = None, None
+        if depth_mode == "depth":
+            aux_affine = (0.5, SH_C0)
+        elif depth_mode is not None:  # disparity / relative_disparity / log: per-Gaussian feature built with torch
+            feat = depth_feature(extrinsics_unscaled(extrinsics[i:i + 1], scale, i), g_means[b][None],
+                                 near[i:i + 1], far[i:i + 1], depth_mode)
+            aux = (0.5 + SH_C0 * feat[0]).clamp(min=0.0)
+        settings = GaussianRasterizationSettings(
+            image_height=h, image_width=w, tanfovx=tan_host[i][0], tanfovy=tan_host[i][1], bg=background_color[i],
+            scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i], sh_degree=degree,
+            campos=extrinsics[i, :3, 3], prefiltered=False,
+            input_scale=None if scale is None else scale[i:i + 1], sh_channel_major=True, aux_affine=aux_affine)
+        means = g_means[b]
+        kw = dict(cov3D_precomp=g_cov[b]) if fused_cov else dict(scales=g_scales[b], rotations=g_rot[b])
+        # means2D is only a gradient sink (`cuda_splatting.py:95-99`): its values are never read
+        sink = torch.empty_like(means).requires_grad_()
+        out = GaussianRasterizer(settings)(means3D=means, means2D=sink, opacities=g_op[b][..., None], shs=g_sh[b],
+                                           aux_precomp=aux, **kw)
+        colors.append(out[0])
+        depths.append(out[2])
+    return torch.stack(colors), (torch.stack(depths) if depth_mode is not None else None)
+
+
+def extrinsics_unscaled(extrinsics_scaled: Tensor, scale: Optional[Tensor], i: int) -> Tensor:
+    """Undo the translation scaling of one view (the depth feature is defined on the unscaled scene)."""
+    if scale is None:
+        return extrinsics_scaled
+    e = extrinsics_scaled.clone()
+    e[..., :3, 3] = e[..., :3, 3] / scale[i]
+    return e
+
+
 class DecoderSplattingCUDA(nn.Module):
     """Same call contract as reference ``decoder_splatting_cuda.py:19-85``:
     ``forward(gaussians, extrinsics[b,v,4,4], intrinsics[b,v,3,3], near[b,v], far[b,v], image_shape,
     depth_mode) -> DecoderOutput(color[b,v,3,h,w], depth[b,v,h,w] | None)``."""
 
-    def __init__(self, cfg=None, fused_depth: bool = True):
+    def __init__(self, cfg=None, fused_depth: bool = True, fused_inputs: bool = True):
         super().__init__()
         self.cfg = cfg
         self.fused_depth = fused_depth  # False: two rasterizations per view, literally as the reference
+        self.fused_inputs = fused_inputs  # False: the reference's torch pre-processing of the Gaussian tensors
         self.register_buffer("background_color", torch.zeros(3, dtype=torch.float32), persistent=False)
 
     @staticmethod
@@ -304,6 +384,13 @@ class DecoderSplattingCUDA(nn.Module):
                 image_shape, depth_mode: Optional[DepthRenderingMode] = None) -> DecoderOutput:
         b, v = extrinsics.shape[:2]
         bg = self.background_color.to(far.device)[None].expand(b * v, 3)
+        if self.fused_inputs and self.fused_depth:
+            # no per-view copies of the Gaussians, no torch op on a Gaussian-sized tensor (render_views_fused)
+            color, depth = render_views_fused(
+                extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(), image_shape, bg,
+                gaussians, [n // v for n in range(b * v)], depth_mode)
+            return DecoderOutput(color.reshape(b, v, *color.shape[1:]),
+                                 None if depth is None else depth.reshape(b, v, *depth.shape[1:]))
         if depth_mode is not None and self.fused_depth:
             color, depth = render_color_and_depth(
                 extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(), image_shape, bg,

@@ -77,6 +77,17 @@ typedef struct GgrForwardIn {
                                     channel into out_depth (Σ aux·α·T).  NULL ⇒ the feature is view-space z.
                                     Lets a host get GGRt's depth pass (cuda_splatting.py:227-269) out of the
                                     SAME rasterization as the colour pass. */
+    /* ---- input forms (all zero / NULL = upstream's forms above).  They replace the torch operations reference
+     * render_cuda runs over the P-sized tensors before every call (cuda_splatting.py:66-77,116,124): applied on
+     * load, chained through in backward, results equal to the unfused call site up to fp32 rounding. ---- */
+    const float* input_scale;    /* device scalar s or NULL (= 1): means3D·s, cov3D·s², scales·s  (the 1/near
+                                    renormalisation, :66-73).  Gradients are w.r.t. the UNSCALED inputs. */
+    int32_t cov3D_full;          /* 1: cov3D_precomp is [P,3,3] row-major; entries (0,1,2,4,5,8) are used and
+                                    dL_dcov3D is [P,3,3] with a zero lower triangle (the triu gather, :116,124) */
+    int32_t sh_channel_major;    /* 1: shs (and dL_dshs) are [P,3,M] — GGRt's harmonics layout (:77 transposes it) */
+    int32_t aux_affine;          /* 1 (with aux_precomp NULL): blended feature = max(aux_a + aux_b·z/s, 0), z = view
+                                    depth — GGRt's depth-as-colour pass (:240-269) without a per-Gaussian tensor */
+    float aux_a, aux_b;
 } GgrForwardIn;
 
 typedef struct GgrForwardOut {
