@@ -72,7 +72,8 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     __shared__ __attribute__((aligned(16))) uint16_t surv[4][BATCH];  // per wave: stage indices of the entries that survive its quadrant cull
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
+    const int tile = xcd_tile((int)blockIdx.x, grid_x * ((H + GGR_TILE - 1) / GGR_TILE));
+    if (tile < 0) return;  // padding workgroup (before any barrier)
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int qx0 = tile_x * GGR_TILE + (wave & 1) * 8, qy0 = tile_y * GGR_TILE + (wave >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -252,10 +253,10 @@ void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_l
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
     if (gx * gy == 0) return;
     if (dL_ddepth)
-        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list,
+        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(xcd_grid(gx * gy)), dim3(256), 0, s, W, H, gx, ranges, point_list,
                            splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d);
     else
-        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list,
+        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(xcd_grid(gx * gy)), dim3(256), 0, s, W, H, gx, ranges, point_list,
                            splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d);
 }
 

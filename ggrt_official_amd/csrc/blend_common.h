@@ -6,6 +6,16 @@ namespace ggr {
 
 #define GGR_BATCH 256
 
+// Workgroup b runs on XCD b mod 8 and every XCD has its own L2.  Neighbouring tiles share most of their
+// Gaussians' 48-B records, so each XCD gets a contiguous eighth of the row-major tile index space instead of
+// every 8th tile.  Returns -1 for the ≤ 7 padding workgroups.
+__device__ __forceinline__ int xcd_tile(int block, int tiles) {
+    const int per = (tiles + 7) >> 3;
+    const int t = (block & 7) * per + (block >> 3);
+    return t < min((block & 7) * per + per, tiles) ? t : -1;
+}
+static inline int xcd_grid(int tiles) { return ((tiles + 7) >> 3) * 8; }
+
 // One staged list entry in LDS: 3 × 16 B, read back as wave-uniform (broadcast) ds_read_b128.
 struct __attribute__((aligned(16))) StagedSplat {
     float4 a;  // x, y, conic.xx, conic.xy

@@ -30,7 +30,8 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     __shared__ int wave_done[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
+    const int tile = xcd_tile((int)blockIdx.x, grid_x * ((H + GGR_TILE - 1) / GGR_TILE));
+    if (tile < 0) return;  // padding workgroup (before any barrier)
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int qx0 = tile_x * GGR_TILE + (wave & 1) * 8, qy0 = tile_y * GGR_TILE + (wave >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -131,7 +132,7 @@ void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_l
                       float* out_depth, hipStream_t s) {
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
     if (gx * gy == 0) return;
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg,
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(xcd_grid(gx * gy)), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg,
                        out_color, final_T, n_contrib, out_depth);
 }
 

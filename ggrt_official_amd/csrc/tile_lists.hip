@@ -161,7 +161,8 @@ bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchun
 __global__ void __launch_bounds__(64)
 bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect, uint32_t T,
                    uint32_t band_tiles, uint32_t grid_x, const uint32_t* __restrict__ table,
-                   uint32_t* __restrict__ point_list, uint32_t capacity /*entries in point_list; ~0u = exact size*/) {
+                   uint32_t* __restrict__ point_list, uint32_t capacity /*entries in point_list; ~0u = exact size*/,
+                   uint32_t nbands_total) {
     // LDS: cursor[band_tiles] (next free list position per tile of the band) + the compacted list of this
     // chunk's Gaussians that touch the band: id, packed origin (x0 | y0<<16), packed size (w | h<<16)
     extern __shared__ uint32_t lds[];
@@ -169,7 +170,15 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
     uint32_t* l_id = lds + band_tiles;
     uint32_t* l_xy = l_id + GGR_BIN_CHUNK;
     uint32_t* l_wh = l_xy + GGR_BIN_CHUNK;
-    const uint32_t chunk = blockIdx.x, band = blockIdx.y, lane = threadIdx.x;
+    // XCD-affine work order.  Workgroup b runs on XCD b mod 8, and every XCD has its own L2: when the waves that
+    // append to one tile list sit on different XCDs, each L2 writes back its own partial copy of every 64-B list
+    // line (measured: 366 MB written for 43 MB of ids).  So a band is given to ONE XCD — band = xcd + 8·k — and the
+    // chunks of a band follow each other on it; the ≤ 7 padding bands exit at once.
+    const uint32_t lane = threadIdx.x;
+    const uint32_t bands8 = (nbands_total + 7u) >> 3;             // bands per XCD
+    const uint32_t xcd = blockIdx.x & 7u, r = blockIdx.x >> 3;
+    const uint32_t band = xcd + 8u * (r % bands8), chunk = r / bands8;
+    if (band >= nbands_total || band * band_tiles >= T) return;
     const uint32_t lo = band * band_tiles, hi = min(T, lo + band_tiles);
     const uint32_t base = chunk * GGR_BIN_CHUNK;
     const uint32_t end = min(P, base + GGR_BIN_CHUNK);
@@ -293,19 +302,20 @@ TileListPlan plan_tile_lists(size_t P, size_t T) {
     p.band_tiles = (uint32_t)(T < 4096 ? (T ? T : 1) : 4096);
     p.nbands = (uint32_t)((T + p.band_tiles - 1) / p.band_tiles);
     if (p.nbands == 0) p.nbands = 1;
-    {   // aim for ≥ ~8192 independent walks (chunks × bands); a band is 64 … 1024 tiles.  (Tried and dropped:
-        // band-fast grid order with a band count ≡ 0 mod 8 so that one XCD's L2 owns a band's list region —
-        // rocprof shows the 4-B scattered stores leave as ≈32-B partial writes (366 MB for 43 MB of ids), but
-        // the kernel is bound by the per-step ds_add_rtn latency, not by that traffic: no gain at C3, and
-        // the smaller bands cost 20–70 % on small images.)
+    {   // aim for ≥ ~8192 independent walks (chunks × bands); a band is 64 … 1024 tiles.
+        // The band COUNT is a multiple of 8: bin_scatter gives each band to one XCD (see there), so equal
+        // counts per XCD keep the eight of them balanced.  (An earlier attempt at the same idea changed the
+        // band sizes at the same time and showed no gain; with the sizes kept and only the block → (band, chunk)
+        // map changed, C3's scatter went 0.164 → 0.115 ms.)
+        const size_t Tn = T ? T : 1;
         const size_t want_bands = (8192 + p.nchunks - 1) / p.nchunks;
-        size_t sb = ((T ? T : 1) + want_bands - 1) / want_bands;
-        sb = sb < 64 ? 64 : (sb > 1024 ? 1024 : sb);
-        if (sb > (T ? T : 1)) sb = T ? T : 1;
-        p.sband_tiles = (uint32_t)sb;
+        size_t nb = 8 * ((want_bands + 4) / 8);                  // nearest multiple of 8 …
+        if (nb < 8) nb = 8;
+        while ((Tn + nb - 1) / nb > 1024) nb += 8;                // … with bands of at most 1024 tiles
+        while (nb > 8 && (Tn + nb - 1) / nb < 64) nb -= 8;        // … and of at least 64 where the image allows
+        p.sband_tiles = (uint32_t)((Tn + nb - 1) / nb);
+        p.nsbands = (uint32_t)nb;                                // (trailing bands may be empty: they exit at once)
     }
-    p.nsbands = (uint32_t)((T + p.sband_tiles - 1) / p.sband_tiles);
-    if (p.nsbands == 0) p.nsbands = 1;
     p.groups = p.nchunks < 32 ? p.nchunks : 32;
     p.chunks_per_group = (p.nchunks + p.groups - 1) / p.groups;
     p.groups = (p.nchunks + p.chunks_per_group - 1) / p.chunks_per_group;
@@ -364,8 +374,10 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
     if (T == 0 || P == 0) return;
     const WorkArea w = carve_work(pl, (void*)work, T);
     const size_t lds = ((size_t)pl.sband_tiles + 3 * GGR_BIN_CHUNK) * 4;
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks, pl.nsbands), dim3(64), lds, s, (uint32_t)P, order,
-                       w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, point_list, capacity);
+    const uint32_t bands8 = (pl.nsbands + 7u) / 8u;
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks * bands8 * 8u), dim3(64), lds, s, (uint32_t)P, order,
+                       w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, point_list, capacity,
+                       pl.nsbands);
 }
 
 }  // namespace ggr
