@@ -130,27 +130,32 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     KCHECK(dbg, s, "preprocess_fwd");
     tm.mark();
 
-    // 2. stable sort of the Gaussians by depth bits (ties keep ascending id)
+    // 2. stable sort of the Gaussians by depth bits (ties keep ascending id).  Its last pass also drops every
+    //    Gaussian's tile rect at its sorted position (into the tile-list work area) and clears the per-tile totals.
+    const ggr::TileListPlan plan = ggr::plan_tile_lists((size_t)P, tiles);
+    void* work = alloc(alloc_ctx, plan.work_bytes);  // 1st allocator call: transient work area
+    if (!work) return fail(GGR_E_ALLOC, "work-area allocator returned NULL");
     uint32_t *dk = nullptr, *order = nullptr;
     if (P > 0) {
+        uint2* rect_sorted = nullptr;
+        uint32_t *zero_area = nullptr, zero_words = 0;
+        ggr::tile_list_gather_targets(plan, work, tiles, &rect_sorted, &zero_area, &zero_words);
         // (preprocess already wrote the keys into g.keys_a and the identity permutation into g.vals_a)
         ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, 32, &dk, &order, s,
-                              /*hist_zeroed=*/true);  // by preprocess_fwd
+                              /*hist_zeroed=*/true /*by preprocess_fwd*/, g.rect, rect_sorted, zero_area, zero_words);
         KCHECK(dbg, s, "depth sort");
     }
     tm.mark();
 
     // 3. per-(chunk, tile) counts → list positions, tile ranges, num_rendered
-    const ggr::TileListPlan plan = ggr::plan_tile_lists((size_t)P, tiles);
-    void* work = alloc(alloc_ctx, plan.work_bytes);  // 1st allocator call: transient work area
-    if (!work) return fail(GGR_E_ALLOC, "work-area allocator returned NULL");
     // sync-free mode: the caller brought a list buffer of `binning_capacity` entries → no read-back, no host
     // sync, no second allocator call; the whole forward (and backward) is then hipGraph-capturable
     const bool sync_free = out->binning_capacity > 0 && out->binning_buffer != nullptr;
     if (out->binning_capacity >= 0x7FFFFFFF) return fail(GGR_E_LIMIT, "binning_capacity too large");
     const uint32_t capacity = sync_free ? (uint32_t)out->binning_capacity : 0xFFFFFFFFu;
     if (P > 0) {
-        ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, capacity, s);
+        ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, capacity, s,
+                                    /*rects_gathered=*/true);
     } else {
         HIP_TRY(hipMemsetAsync(im.ranges, 0, (tiles ? tiles : 1) * sizeof(uint2), s));
         HIP_TRY(hipMemsetAsync(g.counters, 0, 8, s));

@@ -110,10 +110,15 @@ radix_global_scan_kernel(int npasses, uint32_t* __restrict__ hist) {
     }
 }
 
+// GATHER (last pass of the depth sort only): every pair also carries an 8-byte payload looked up by its value,
+// gather_dst[final position] = gather_src[val] — the tile rect of the Gaussian, so that the tile-list kernels can
+// stream the rects in depth order without a separate gather launch; the pass also clears `zero_area`.
+template <bool GATHER>
 __global__ void __launch_bounds__(GGR_SORT_THREADS)
 radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int pass,
-                      uint32_t ntiles, uint32_t* __restrict__ hist) {
+                      uint32_t ntiles, uint32_t* __restrict__ hist, const uint2* __restrict__ gather_src,
+                      uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
     __shared__ uint32_t wcount[4][GGR_RADIX];  // per-wave digit counters, later per-wave output bases
     __shared__ uint32_t tile_sh;
     const int tid = threadIdx.x;
@@ -135,6 +140,17 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
         const bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
         val[r] = valid ? vals_in[idx] : 0u;
+    }
+    uint2 pay[GATHER ? GGR_SORT_ITEMS : 1];
+    if (GATHER) {
+        for (uint32_t w = blockIdx.x * GGR_SORT_THREADS + tid; w < zero_words; w += gridDim.x * GGR_SORT_THREADS)
+            zero_area[w] = 0u;
+        // issued now, consumed after the ranking and the look-back: the random 8-B reads hide behind them
+#pragma unroll
+        for (int r = 0; r < GGR_SORT_ITEMS; r++) {
+            const size_t idx = base + r * 64 + lane;
+            pay[r] = idx < n ? gather_src[val[r]] : make_uint2(0u, 0u);
+        }
     }
     // wave-private counters: plain LDS accesses, ordered by wavefront-scope fences (LDS executes a wave's
     // operations in order; a `volatile` pointer here compiles to flat_load/flat_store + s_waitcnt vmcnt(0))
@@ -206,6 +222,7 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
             const uint32_t pos = wcount[wave][d] + rank[r];
             keys_out[pos] = key[r];
             vals_out[pos] = val[r];
+            if (GATHER) gather_dst[pos] = pay[r];
         }
     }
 }
@@ -214,7 +231,8 @@ size_t radix_hist_words(size_t n) { return GGR_HIST_STATUS + 4 * ggr_sort_blocks
 
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                       uint32_t* hist, size_t n, int nbits, uint32_t** keys_out, uint32_t** vals_out,
-                      hipStream_t s, bool hist_zeroed) {
+                      hipStream_t s, bool hist_zeroed, const uint2* gather_src, uint2* gather_dst,
+                      uint32_t* zero_area, uint32_t zero_words) {
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     const int npasses = (nbits + GGR_RADIX_BITS - 1) / GGR_RADIX_BITS;
     if (n > 0 && npasses > 0) {
@@ -228,8 +246,12 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
         hipLaunchKernelGGL(radix_global_hist_kernel, dim3(hist_blocks), dim3(256), 0, s, kin, n, npasses, hist);
         hipLaunchKernelGGL(radix_global_scan_kernel, dim3(1), dim3(256), 0, s, npasses, hist);
         for (int p = 0; p < npasses; p++) {
-            hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(GGR_SORT_THREADS), 0, s, kin, vin, kout,
-                               vout, n, p, ntiles, hist);
+            if (p == npasses - 1 && gather_src)
+                hipLaunchKernelGGL(radix_onesweep_kernel<true>, dim3(ntiles), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
+                                   kout, vout, n, p, ntiles, hist, gather_src, gather_dst, zero_area, zero_words);
+            else
+                hipLaunchKernelGGL(radix_onesweep_kernel<false>, dim3(ntiles), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
+                                   kout, vout, n, p, ntiles, hist, nullptr, nullptr, nullptr, 0u);
             uint32_t* t = kin; kin = kout; kout = t;
             t = vin; vin = vout; vout = t;
         }

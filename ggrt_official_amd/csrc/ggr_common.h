@@ -166,7 +166,10 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
 // hold the result (either a or b)
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                       uint32_t* hist, size_t n, int nbits, uint32_t** keys_out, uint32_t** vals_out,
-                      hipStream_t s, bool hist_zeroed = false /*the caller already cleared ggr_sort_hist_words(n)*/);
+                      hipStream_t s, bool hist_zeroed = false /*the caller already cleared ggr_sort_hist_words(n)*/,
+                      const uint2* gather_src = nullptr /*last pass also writes gather_dst[pos] = gather_src[val]*/,
+                      uint2* gather_dst = nullptr, uint32_t* zero_area = nullptr /*and clears these words*/,
+                      uint32_t zero_words = 0);
 
 void launch_iota(uint32_t* v, size_t n, hipStream_t s);
 
@@ -180,7 +183,11 @@ TileListPlan plan_tile_lists(size_t P, size_t T);
 // capacity = entries the list buffer can hold (sync-free mode: ranges are cut there); ~0u = sized exactly later
 void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                             const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, uint32_t capacity,
-                            hipStream_t s);
+                            hipStream_t s, bool rects_gathered = false /*the depth sort already filled rect_sorted
+                            and cleared the per-tile totals (tile_list_gather_targets)*/);
+// where the depth sort's last pass should put the rects in depth order / which words it should clear
+void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint2** rect_sorted,
+                              uint32_t** zero_area, uint32_t* zero_words);
 // K3: writes point_list[min(N, capacity)]
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                               const uint2* rect, const void* work, uint32_t* point_list, uint32_t capacity,

@@ -345,17 +345,26 @@ WorkArea carve_work(const TileListPlan& pl, void* work, size_t T) {
 }
 }  // namespace
 
+void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint2** rect_sorted,
+                              uint32_t** zero_area, uint32_t* zero_words) {
+    const WorkArea w = carve_work(pl, work, T);
+    *rect_sorted = w.rect_sorted;
+    *zero_area = w.tile_start;
+    *zero_words = (uint32_t)T;
+}
+
 void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                             const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, uint32_t capacity,
-                            hipStream_t s) {
+                            hipStream_t s, bool rects_gathered) {
     const WorkArea w = carve_work(pl, work, T);
     if (T == 0 || P == 0) {
         (void)hipMemsetAsync(total_out, 0, 8, s);
         if (T) (void)hipMemsetAsync(ranges, 0, T * sizeof(uint2), s);
         return;
     }
-    hipLaunchKernelGGL(gather_rect_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (uint32_t)P, order, rect,
-                       w.rect_sorted, w.tile_start, (uint32_t)T);
+    if (!rects_gathered)  // (ggr_forward: the depth sort's last pass has done both jobs already)
+        hipLaunchKernelGGL(gather_rect_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (uint32_t)P, order,
+                           rect, w.rect_sorted, w.tile_start, (uint32_t)T);
     hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nchunks, pl.nbands), dim3(256), pl.band_tiles * 4, s, (uint32_t)P,
                        order, w.rect_sorted, (uint32_t)T, pl.band_tiles, (uint32_t)grid_x, w.table);
     const unsigned tb = (unsigned)((T + 255) / 256);
