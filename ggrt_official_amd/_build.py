@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libggr_raster.so")
 SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "tile_lists.hip", "blend_fwd.hip", "blend_bwd.hip",
-           "preprocess_bwd.hip"]
+           "preprocess_bwd.hip", "camera.hip"]
 HEADERS = ["ggr_common.h", "blend_common.h", os.path.join("..", "..", "include", "ggr_raster.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]

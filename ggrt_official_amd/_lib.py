@@ -22,6 +22,7 @@ class GgrSettings(C.Structure):
         ("sh_stride", C.c_int32), ("num_points", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
         ("scale_modifier", C.c_float), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
         ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("tanfov_dev", C.c_void_p),
     ]
 
 
@@ -78,6 +79,8 @@ SYMBOLS = [
                               ALLOC_FN, C.c_void_p, C.c_void_p]),
     ("ggr_backward", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrBackwardIn), C.POINTER(GgrBackwardOut),
                                C.c_void_p]),
+    ("ggr_camera_setup", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ggr_forward_status", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_void_p]),
     ("ggr_mark_visible", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ggr_debug_unpack_geom", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

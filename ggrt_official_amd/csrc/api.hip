@@ -76,8 +76,9 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
     return GGR_OK;
 }
 
-InputForm input_form(const GgrForwardIn* in) {
+InputForm input_form(const GgrSettings* st, const GgrForwardIn* in) {
     InputForm f;
+    f.tanfov_dev = st->tanfov_dev;
     f.input_scale = in->input_scale;
     f.cov_stride = in->cov3D_full ? 9 : 6;
     f.sh_channel_major = in->sh_channel_major ? 1 : 0;
@@ -126,7 +127,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     ggr::launch_preprocess_fwd(P, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
                                in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
                                in->aux_precomp, st->viewmatrix, st->projmatrix, st->campos, W, H, st->tanfovx,
-                               st->tanfovy, out->radii, g, input_form(in), s);
+                               st->tanfovy, out->radii, g, input_form(st, in), s);
     KCHECK(dbg, s, "preprocess_fwd");
     tm.mark();
 
@@ -247,9 +248,22 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
                                out->dL_dopacities, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
                                out->dL_dscales, out->dL_drotations, in->fwd.aux_precomp ? out->dL_daux : nullptr,
                                npose ? sc.pose_acc : nullptr, out->dL_dviewmatrix, out->dL_dprojmatrix,
-                               out->dL_dcampos, input_form(&in->fwd), in->fwd.cov3D_precomp ? 1 : 0, s);
+                               out->dL_dcampos, input_form(st, &in->fwd), in->fwd.cov3D_precomp ? 1 : 0, s);
     KCHECK(dbg, s, "preprocess_bwd");
     tm.mark();
+    return GGR_OK;
+}
+
+int ggr_camera_setup(int32_t n, const float* extrinsics, const float* intrinsics, const float* near, const float* far,
+                     int32_t scale_invariant, float* viewmatrix, float* projmatrix, float* campos, float* tanfov,
+                     float* scale, void* stream) {
+    g_err[0] = 0;
+    if (n < 0 || (n > 0 && (!extrinsics || !intrinsics || !near || !far || !viewmatrix || !projmatrix || !campos ||
+                            !tanfov || !scale)))
+        return fail(GGR_E_INVALID, "bad arguments");
+    ggr::launch_camera_setup(n, extrinsics, intrinsics, near, far, scale_invariant, viewmatrix, projmatrix, campos,
+                             tanfov, scale, (hipStream_t)stream);
+    KCHECK(false, (hipStream_t)stream, "camera_setup");
     return GGR_OK;
 }
 

@@ -150,6 +150,7 @@ struct InputForm {
                                // transpose copy of :77 and its backward
     int aux_affine;            // 1: blended feature = max(aux_a + aux_b·z/s, 0) instead of z — GGRt's depth pass
     float aux_a, aux_b;        //    (:240-269: depth as a degree-0 SH coefficient) without a per-Gaussian tensor
+    const float* tanfov_dev;   // device float[2] overriding tanfovx / tanfovy, or NULL (GgrSettings.tanfov_dev)
 };
 
 // ---- kernel launchers (defined in the .hip translation units) -------------------------------
@@ -216,6 +217,11 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            hipStream_t s);
 
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                         hipStream_t s);
+
+// camera.hip: per-view view / full projection matrices, camera position, tan(fov/2), 1/near — one launch
+void launch_camera_setup(int n, const float* extrinsics, const float* intrinsics, const float* near, const float* far,
+                         int scale_invariant, float* view, float* full, float* campos, float* tanfov, float* scale,
                          hipStream_t s);
 
 void launch_unpack_geom(GeomLayout g, int P, float* depth, float* xy, float* conic_opacity, float* rgb,

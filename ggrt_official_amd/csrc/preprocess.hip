@@ -143,6 +143,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // call-site fusion: the reference's 1/near renormalisation (means·s, cov·s², scales·s — cuda_splatting.py:
     // 66-73) and its upper-triangle gather out of [P,3,3] covariances (:116,124) happen on load.  One fp32
     // multiply per value, exactly what the torch ops of the unfused call site do.
+    if (inf.tanfov_dev) { tanfovx = inf.tanfov_dev[0]; tanfovy = inf.tanfov_dev[1]; }  // device-resident tan(fov/2)
     const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
     const float p0 = in_s * means3D[3 * i], p1 = in_s * means3D[3 * i + 1], p2 = in_s * means3D[3 * i + 2];
     float cov6[6];

@@ -77,6 +77,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int copy_row = inf.sh_channel_major ? (int)sh_row : sh_rowf;
     const int sh_stride = sh_flat ? (int)sh_row : (copy_row | 1);
     const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? M : 1;
+    if (inf.tanfov_dev) { tanfovx = inf.tanfov_dev[0]; tanfovy = inf.tanfov_dev[1]; }  // device-resident tan(fov/2)
     const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
     if (use_sh) {
         if (sh_flat) {

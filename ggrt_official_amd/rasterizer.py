@@ -56,6 +56,7 @@ class GaussianRasterizationSettings(NamedTuple):
     input_scale: Optional[torch.Tensor] = None  # device scalar s: means·s, cov·s², scales·s (the 1/near renorm)
     sh_channel_major: bool = False              # shs given as [P,3,M] (GGRt's harmonics layout) instead of [P,M,3]
     aux_affine: Optional[tuple] = None          # (a, b): depth output = Σ max(a + b·z/s, 0)·α·T (GGRt's depth pass)
+    tanfov: Optional[torch.Tensor] = None       # device [2]: overrides tanfovx / tanfovy without a read-back (camera_setup)
 
 
 class StageProfile:
@@ -128,11 +129,14 @@ def _check(rc: int, what: str):
 
 
 def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view, proj, campos) -> _lib.GgrSettings:
+    tf = getattr(rs, "tanfov", None)
+    if tf is not None and (tf.dtype != torch.float32 or not tf.is_contiguous() or tf.device != bg.device):
+        raise RuntimeError("settings.tanfov must be a contiguous float32 [2] tensor on the rasterizer's device")
     return _lib.GgrSettings(
         image_height=int(rs.image_height), image_width=int(rs.image_width), sh_degree=int(rs.sh_degree),
         sh_stride=int(M), num_points=int(P), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
         scale_modifier=float(rs.scale_modifier), bg=_ptr(bg), viewmatrix=_ptr(view), projmatrix=_ptr(proj),
-        campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)))
+        campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfov_dev=_ptr(tf))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -283,6 +287,31 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_aux.reshape(aux_shape) if d_aux is not None else None,
             None,
         )
+
+
+def camera_setup(extrinsics: torch.Tensor, intrinsics: torch.Tensor, near: torch.Tensor, far: torch.Tensor,
+                 scale_invariant: bool = True):
+    """Per-view camera quantities of GGRt's call site (reference ``cuda_splatting.py:18-46,66-73,82-89``) from ONE
+    kernel launch, all left on the device: returns ``(viewmatrix [n,4,4], projmatrix [n,4,4], campos [n,3],
+    tanfov [n,2], scale [n])`` for ``extrinsics [n,4,4]`` (camera-to-world), normalised ``intrinsics [n,3,3]``,
+    ``near/far [n]``.  No autograd (the reference does not differentiate through its settings either)."""
+    lib = _lib.load()
+    dev = extrinsics.device
+    if dev.type != "cuda":
+        raise RuntimeError("camera_setup needs ROCm GPU tensors; there is no CPU path")
+    n = int(extrinsics.shape[0])
+    with torch.no_grad(), torch.cuda.device(dev):
+        e, k = _f32c(extrinsics.detach()), _f32c(intrinsics.detach())
+        nr, fr = _f32c(near.detach()), _f32c(far.detach())
+        view = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
+        full = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
+        campos = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        tanfov = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        scale = torch.empty((n,), dtype=torch.float32, device=dev)
+        _check(lib.ggr_camera_setup(n, e.data_ptr(), k.data_ptr(), nr.data_ptr(), fr.data_ptr(), int(bool(scale_invariant)),
+                                    view.data_ptr(), full.data_ptr(), campos.data_ptr(), tanfov.data_ptr(),
+                                    scale.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "ggr_camera_setup")
+    return view, full, campos, tanfov, scale
 
 
 def last_forward_status():

@@ -275,9 +275,13 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
 
 def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape,
                        background_color: Tensor, gaussians: Gaussians, view_to_batch,
-                       depth_mode: Optional[DepthRenderingMode] = None, scale_invariant: bool = True):
+                       depth_mode: Optional[DepthRenderingMode] = None, scale_invariant: bool = True,
+                       device_camera: bool = True, list_capacity: int = 0):
     """The call site with NO torch operation on a Gaussian-sized tensor (SURVEY.md §8 a2 "where time goes"):
 
+    * ``device_camera``: view / projection matrices, camera position, tan(fov/2) and 1/near of all views come
+      from one library kernel and stay on the device (no ``.item()`` / ``.cpu()`` — reference :104-105);
+      with ``list_capacity > 0`` (sync-free forward) the whole call then runs without any host sync;
     * the Gaussians are not repeated per view (reference ``decoder_splatting_cuda.py:47-50``): view n reads
       batch element ``view_to_batch[n]`` of ``gaussians`` directly;
     * the 1/near renormalisation of means and covariances (``cuda_splatting.py:66-73``) travels as a device
@@ -294,18 +298,30 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     h, w = image_shape
     d_sh = gaussians.harmonics.shape[-1]
     degree = isqrt(d_sh) - 1
-    if scale_invariant:
-        scale = 1 / near
-        extrinsics = extrinsics.clone()
-        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
-        near_s, far_s = near * scale, far * scale
+    ext_orig = extrinsics
+    # the per-view camera quantities: one library kernel, everything (incl. tan(fov/2) and 1/near) stays on the
+    # device — or, for poses that carry gradients / CPU golden tests, the reference's torch formulation
+    on_device = device_camera and extrinsics.is_cuda and not (extrinsics.requires_grad or intrinsics.requires_grad)
+    if on_device:
+        from .rasterizer import camera_setup
+        view, full, campos, tanfov, scale = camera_setup(extrinsics, intrinsics, near, far, scale_invariant)
+        tan_host = None
+        if not scale_invariant:
+            scale = None
     else:
-        scale, near_s, far_s = None, near, far
-    fov = get_fov(intrinsics)
-    tan_host = (0.5 * fov).tan().detach().cpu().tolist()
-    proj = get_projection_matrix(near_s, far_s, fov[:, 0], fov[:, 1], intrinsics).transpose(1, 2)
-    view = torch.linalg.inv(extrinsics).transpose(1, 2)
-    full = view @ proj
+        if scale_invariant:
+            scale = 1 / near
+            extrinsics = extrinsics.clone()
+            extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
+            near_s, far_s = near * scale, far * scale
+        else:
+            scale, near_s, far_s = None, near, far
+        fov = get_fov(intrinsics)
+        tan_host = (0.5 * fov).tan().detach().cpu().tolist()
+        proj = get_projection_matrix(near_s, far_s, fov[:, 0], fov[:, 1], intrinsics).transpose(1, 2)
+        view = torch.linalg.inv(extrinsics).transpose(1, 2)
+        full = view @ proj
+        campos, tanfov = extrinsics[:, :3, 3], None
     fused_cov = gaussians.covariances is not None
     # batch element b of every Gaussian tensor WITHOUT `t[b]`: select's backward zero-fills a full [B,…] tensor
     # and copies the slice in, per view (0.2 ms per view for 1 M × 25 SH coefficients).  One unbind per tensor
@@ -324,14 +340,15 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
         if depth_mode == "depth":
             aux_affine = (0.5, SH_C0)
         elif depth_mode is not None:  # disparity / relative_disparity / log: per-Gaussian feature built with torch
-            feat = depth_feature(extrinsics_unscaled(extrinsics[i:i + 1], scale, i), g_means[b][None],
-                                 near[i:i + 1], far[i:i + 1], depth_mode)
+            feat = depth_feature(ext_orig[i:i + 1], g_means[b][None], near[i:i + 1], far[i:i + 1], depth_mode)
             aux = (0.5 + SH_C0 * feat[0]).clamp(min=0.0)
         settings = GaussianRasterizationSettings(
-            image_height=h, image_width=w, tanfovx=tan_host[i][0], tanfovy=tan_host[i][1], bg=background_color[i],
+            image_height=h, image_width=w, tanfovx=tan_host[i][0] if tan_host else 0.0,
+            tanfovy=tan_host[i][1] if tan_host else 0.0, bg=background_color[i],
             scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i], sh_degree=degree,
-            campos=extrinsics[i, :3, 3], prefiltered=False,
-            input_scale=None if scale is None else scale[i:i + 1], sh_channel_major=True, aux_affine=aux_affine)
+            campos=campos[i], prefiltered=False, list_capacity=list_capacity,
+            input_scale=None if scale is None else scale[i:i + 1], sh_channel_major=True, aux_affine=aux_affine,
+            tanfov=None if tanfov is None else tanfov[i])
         means = g_means[b]
         kw = dict(cov3D_precomp=g_cov[b]) if fused_cov else dict(scales=g_scales[b], rotations=g_rot[b])
         # means2D is only a gradient sink (`cuda_splatting.py:95-99`): its values are never read
@@ -343,23 +360,18 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     return torch.stack(colors), (torch.stack(depths) if depth_mode is not None else None)
 
 
-def extrinsics_unscaled(extrinsics_scaled: Tensor, scale: Optional[Tensor], i: int) -> Tensor:
-    """Undo the translation scaling of one view (the depth feature is defined on the unscaled scene)."""
-    if scale is None:
-        return extrinsics_scaled
-    e = extrinsics_scaled.clone()
-    e[..., :3, 3] = e[..., :3, 3] / scale[i]
-    return e
-
-
 class DecoderSplattingCUDA(nn.Module):
     """Same call contract as reference ``decoder_splatting_cuda.py:19-85``:
     ``forward(gaussians, extrinsics[b,v,4,4], intrinsics[b,v,3,3], near[b,v], far[b,v], image_shape,
     depth_mode) -> DecoderOutput(color[b,v,3,h,w], depth[b,v,h,w] | None)``."""
 
-    def __init__(self, cfg=None, fused_depth: bool = True, fused_inputs: bool = True):
+    def __init__(self, cfg=None, fused_depth: bool = True, fused_inputs: bool = True, list_capacity: int = 0):
         super().__init__()
         self.cfg = cfg
+        # > 0: sync-free rasterizer forward with per-tile lists of at most this many entries — with the fused
+        # inputs the whole decoder call then has no host sync and can be captured in a HIP graph
+        # (check ``ggrt_official_amd.last_forward_status()`` for overflow when a sync is affordable)
+        self.list_capacity = int(list_capacity)
         self.fused_depth = fused_depth  # False: two rasterizations per view, literally as the reference
         self.fused_inputs = fused_inputs  # False: the reference's torch pre-processing of the Gaussian tensors
         self.register_buffer("background_color", torch.zeros(3, dtype=torch.float32), persistent=False)
@@ -388,7 +400,7 @@ class DecoderSplattingCUDA(nn.Module):
             # no per-view copies of the Gaussians, no torch op on a Gaussian-sized tensor (render_views_fused)
             color, depth = render_views_fused(
                 extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(), image_shape, bg,
-                gaussians, [n // v for n in range(b * v)], depth_mode)
+                gaussians, [n // v for n in range(b * v)], depth_mode, list_capacity=self.list_capacity)
             return DecoderOutput(color.reshape(b, v, *color.shape[1:]),
                                  None if depth is None else depth.reshape(b, v, *depth.shape[1:]))
         if depth_mode is not None and self.fused_depth:

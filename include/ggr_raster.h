@@ -61,6 +61,8 @@ typedef struct GgrSettings {
     const float* campos;     /* device [3] */
     int32_t prefiltered;     /* accepted, unused (as at the call site: False) */
     int32_t debug;           /* 1: synchronise + check after every kernel */
+    const float* tanfov_dev; /* device float[2] or NULL.  When given it overrides tanfovx / tanfovy, so that a host
+                                that derived them on the device (ggr_camera_setup) never has to read them back */
 } GgrSettings;
 
 /* Inputs of GaussianRasterizer.forward (cuda_splatting.py:118-125).
@@ -175,6 +177,17 @@ int ggr_forward(const GgrSettings* settings, const GgrForwardIn* in, GgrForwardO
 /* replaces diff_gaussian_rasterization._C.rasterize_gaussians_backward */
 int ggr_backward(const GgrSettings* settings, const GgrBackwardIn* in, GgrBackwardOut* out,
                  void* stream);
+
+/* The per-view camera quantities of the call site in one launch (cuda_splatting.py:18-46,66-73,82-89 and
+ * ggrt/geometry/projection.py:233-247): for each of n views  scale = scale_invariant ? 1/near : 1,
+ * view = inverse(extrinsics with its translation·scale)^T, full = view @ P^T with GGRt's projection P (built from
+ * intrinsics[0] for every view, near·scale, far·scale), campos, tan(fov/2) from the normalised intrinsics.
+ * Everything stays on the device: feed tanfov to GgrSettings.tanfov_dev and scale to GgrForwardIn.input_scale. */
+int ggr_camera_setup(int32_t n, const float* extrinsics /*[n,4,4] camera-to-world*/,
+                     const float* intrinsics /*[n,3,3] normalised*/, const float* near /*[n]*/,
+                     const float* far /*[n]*/, int32_t scale_invariant, float* viewmatrix /*[n,4,4]*/,
+                     float* projmatrix /*[n,4,4]*/, float* campos /*[n,3]*/, float* tanfov /*[n,2]*/,
+                     float* scale /*[n]*/, void* stream);
 
 /* Sync-free mode: num_rendered and the overflow flag of the forward that filled `geom_buffer` (synchronises).
  * No counterpart in the reference: upstream always reads num_rendered back inside rasterize_gaussians. */

@@ -122,7 +122,7 @@ def test_decoder_module_cpu(monkeypatch):
     v = inp["extrinsics"].shape[0]
     gs = splatting.Gaussians(means=inp["gaussian_means"][:b], covariances=inp["gaussian_covariances"][:b],
                              harmonics=inp["gaussian_sh_coefficients"][:b], opacities=inp["gaussian_opacities"][:b])
-    dec = splatting.DecoderSplattingCUDA()
+    dec = splatting.DecoderSplattingCUDA(fused_inputs=False)  # the CPU oracle stand-in takes upstream's input forms only
     out = dec(gs, inp["extrinsics"][None], inp["intrinsics"][None], inp["near"][None], inp["far"][None], shape,
               depth_mode="depth")
     assert out.color.shape == (b, v, 3, *shape) and out.depth.shape == (b, v, *shape)
@@ -147,8 +147,8 @@ def test_fused_colour_depth_equals_two_passes_cpu(monkeypatch, mode):
     """one rasterization with the aux feature == the reference's colour pass + depth pass."""
     monkeypatch.setattr(splatting, "GaussianRasterizer", _OracleRasterizer)
     gs, args, v = _decoder_case()
-    two = splatting.DecoderSplattingCUDA(fused_depth=False)(gs, *args, depth_mode=mode)
-    one = splatting.DecoderSplattingCUDA(fused_depth=True)(gs, *args, depth_mode=mode)
+    two = splatting.DecoderSplattingCUDA(fused_depth=False, fused_inputs=False)(gs, *args, depth_mode=mode)
+    one = splatting.DecoderSplattingCUDA(fused_depth=True, fused_inputs=False)(gs, *args, depth_mode=mode)
     assert torch.allclose(one.color, two.color, atol=1e-6)
     assert torch.allclose(one.depth, two.depth, atol=2e-6, rtol=1e-5)
 
