@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--config", default="C3", help="key of ggrt_official_amd.synthetic.CONFIGS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the informational HIP-graph replay leg")
+    ap.add_argument("--no-callsite", action="store_true", help="skip the informational GGRt-shape call-site leg")
     ap.add_argument("--grad-buffer-floats", type=int, default=0,
                     help="N>1 only: ALSO all-reduce a flat fp32 buffer of this size per step, a stand-in for GGRt's "
                          "encoder + pose-network gradients (≈65_000_000, SURVEY.md §5); off by default because those "
@@ -302,6 +303,15 @@ def main():
         }
         if graph_rec is not None:
             rec["hipgraph_replay"] = graph_rec
+        if world == 1 and not args.no_callsite:
+            # informational: GGRt's own shape through the call-site layer (scripts/callsite_bench.py)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import callsite_bench
+                rec["callsite_ggrt_shape"] = callsite_bench.measure(str(dev), steps=10, warmup=3)
+                log(f"call site at GGRt's shape: {rec['callsite_ggrt_shape']}")
+            except Exception as e:
+                log(f"call-site leg skipped: {type(e).__name__}: {e}")
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, seed=0)
         print(json.dumps(rec), flush=True)
