@@ -15,11 +15,12 @@
 //   K2a/b/c     exclusive prefix of table over chunks per tile (grouped: G groups of chunks so that the
 //               scan has T·G-way parallelism), exclusive scan over tiles → tile_start, ranges, N;
 //               table[c][t] becomes the ABSOLUTE list position of chunk c's first entry for tile t
-//   K3 scatter  per (chunk, tile band) ONE wave walks its chunk's Gaussians in order; the band's cursors
-//               live in LDS (initialised from table[c][·]); for each Gaussian its lanes (one per tile of the
-//               rect) do `pos = ds_add_rtn(cursor[tile], 1)` — distinct tiles within a Gaussian, program
-//               order across Gaussians, LDS executes a wave's operations in order ⇒ stable — and store the
-//               id at point_list[pos].
+//   K3 scatter  per (chunk, tile band) ONE wave walks its chunk's (Gaussian, tile) pairs in order, 64 consecutive
+//               pairs ("slots") per step; the band's cursors live in LDS (initialised from table[c][·]).  Lanes
+//               of a step that hold the same tile are matched through a per-tile lane-mask word (atomic OR,
+//               order-free); the lowest of them reserves `count` positions with one ds_add_rtn, the others take
+//               base + rank.  Program order across steps + in-order LDS ⇒ stable lists; each id is stored at
+//               point_list[pos].  One XCD owns a band (its list lines are then merged in ONE L2).
 //
 // HBM traffic: table (chunks·T·4 B, 32 MB at C3) written once, read/written once, read once; rects read
 // twice per band; N·4 B of ids written.  ≈ 0.25 GB instead of ≈ 0.9 GB for emit + 2 radix passes, and 5
@@ -158,18 +159,48 @@ bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchun
 }
 
 // ---- K3 ------------------------------------------------------------------------------------------
+// inclusive wave64 scans with DPP: four row_shr steps inside each 16-lane row, then row_bcast:15 / :31 carry the
+// row totals on (lanes without a source keep the identity 0)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+    v += dpp_u32<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_u32<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_u32<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_u32<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_u32<0x142, 0xa>(v);  // row_bcast:15 → rows 1, 3
+    v += dpp_u32<0x143, 0xc>(v);  // row_bcast:31 → rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+    v = max(v, dpp_u32<0x111, 0xf>(v));
+    v = max(v, dpp_u32<0x112, 0xf>(v));
+    v = max(v, dpp_u32<0x114, 0xf>(v));
+    v = max(v, dpp_u32<0x118, 0xf>(v));
+    v = max(v, dpp_u32<0x142, 0xa>(v));
+    v = max(v, dpp_u32<0x143, 0xc>(v));
+    return v;
+}
+
 __global__ void __launch_bounds__(64)
 bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect, uint32_t T,
                    uint32_t band_tiles, uint32_t grid_x, const uint32_t* __restrict__ table,
                    uint32_t* __restrict__ point_list, uint32_t capacity /*entries in point_list; ~0u = exact size*/,
                    uint32_t nbands_total) {
     // LDS: cursor[band_tiles] (next free list position per tile of the band) + the compacted list of this
-    // chunk's Gaussians that touch the band: id, packed origin (x0 | y0<<16), packed size (w | h<<16)
+    // chunk's Gaussians that touch the band: id, first tile relative to the band, rect width, first slot;
+    // mark[64]: scratch of one step
     extern __shared__ uint32_t lds[];
-    uint32_t* cursor = lds;
-    uint32_t* l_id = lds + band_tiles;
-    uint32_t* l_xy = l_id + GGR_BIN_CHUNK;
-    uint32_t* l_wh = l_xy + GGR_BIN_CHUNK;
+    unsigned long long* same = (unsigned long long*)lds;  // [band_tiles] lane masks: who holds tile t in this step
+    uint32_t* cursor = lds + 2 * band_tiles;
+    uint32_t* l_id = cursor + band_tiles;
+    constexpr uint32_t HALF = GGR_BIN_CHUNK / 2;  // the chunk is walked in two halves: 8 KB of list instead of 16,
+    uint32_t* l_xy = l_id + HALF;                 // i.e. 13 instead of 7 resident waves per CU for a walk whose
+    uint32_t* l_wh = l_xy + HALF;                 // steps are chains of LDS round trips
+    uint32_t* l_pre = l_wh + HALF;
+    uint32_t* mark = l_pre + HALF;
     // XCD-affine work order.  Workgroup b runs on XCD b mod 8, and every XCD has its own L2: when the waves that
     // append to one tile list sit on different XCDs, each L2 writes back its own partial copy of every 64-B list
     // line (measured: 366 MB written for 43 MB of ids).  So a band is given to ONE XCD — band = xcd + 8·k — and the
@@ -202,84 +233,98 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const uint32_t i = lane + 64 * q;
-        if (i < hi - lo) cursor[i] = cur0[q];
+        if (i < hi - lo) { cursor[i] = cur0[q]; same[i] = 0ull; }
     }
-    // phase A: keep (in order) the Gaussians whose rect can touch the band
-    uint32_t nh = 0;
+    // phase A: keep (in order) the Gaussians whose rect can touch the band, with their rows clipped to the band's,
+    // and number the (Gaussian, tile) pairs of the whole chunk consecutively: pair j of hit k is SLOT pre[k] + j
+    const uint32_t band_n = hi - lo;
+    const uint32_t row_lo = lo / grid_x, row_hi = (hi - 1) / grid_x + 1;
 #pragma unroll
-    for (int q = 0; q < NB; q++) {
+  for (int half = 0; half < 2; half++) {
+    uint32_t nh = 0, S = 0;
+#pragma unroll
+    for (int qq = 0; qq < NB / 2; qq++) {
+        const int q = half * (NB / 2) + qq;
         const uint32_t g = gq[q];
         uint32_t x0, y0, x1, y1;
         unpack_rect(rq[q], x0, y0, x1, y1);
-        const uint32_t w = x1 > x0 ? x1 - x0 : 0, h = y1 > y0 ? y1 - y0 : 0;
-        const bool hit = w * h > 0 && (y1 - 1) * grid_x + x1 - 1 >= lo && y0 * grid_x + x0 < hi;
+        const uint32_t ya = max(y0, row_lo), yb = min(y1, row_hi);
+        const uint32_t w = x1 > x0 ? x1 - x0 : 0, h = yb > ya ? yb - ya : 0;
+        const uint32_t n = w * h;
+        const bool hit = n > 0 && (yb - 1) * grid_x + x1 - 1 >= lo && ya * grid_x + x0 < hi;
+        const uint32_t incl = wave_scan_add(hit ? n : 0u);
         const uint64_t mk = __ballot(hit);
         if (hit) {
             const uint32_t p = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
             l_id[p] = g;
-            l_xy[p] = y0 * grid_x + x0 - lo;  // first tile of the rect RELATIVE to the band (may wrap below 0)
-            l_wh[p] = w | (h << 16);
+            l_xy[p] = ya * grid_x + x0 - lo;  // first tile of the clipped rect RELATIVE to the band (may wrap below 0)
+            l_wh[p] = w;
+            l_pre[p] = S + incl - n;
         }
         nh += (uint32_t)__popcll(mk);
+        S += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // phase B: one Gaussian per step, lanes = tiles of its rect.  Distinct tiles within a step, program order
-    // across steps, and LDS executes one wave's operations in order ⇒ the lists come out stable.
-    // Every step is a ds_add_rtn → global store chain whose latency (not its issue cost) bounds the walk, so
-    // four steps are software-pipelined: four independent ds_add_rtn back to back (still in program order),
-    // then the four stores.
-    constexpr int U = 4;
-    for (uint32_t k0 = 0; k0 < nh; k0 += U) {
-        uint32_t cg[U], bt[U], wj[U], nj[U], pos[U];
-        bool in[U];
-        float inv_w[U];
-        const uint32_t band_n = hi - lo;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t k = k0 + u < nh ? k0 + u : k0;  // tail: re-read entry k0, masked out below
-            cg[u] = l_id[k];
-            bt[u] = l_xy[k];
-            const uint32_t cwh = l_wh[k];
-            wj[u] = cwh & 0xFFFFu;
-            nj[u] = k0 + u < nh ? wj[u] * (cwh >> 16) : 0u;
-            // v_rcp_f32 (1 ulp) is enough: (l + ½)/w is ≥ ½/w away from any integer, i.e. a relative margin
-            // of ½/(l + ½) ≥ 7.6e-6 for l < 2^16 against ≈ 2.5e-7 of rcp + multiply rounding
-            inv_w[u] = __builtin_amdgcn_rcpf((float)wj[u]);
+    // phase B: 64 consecutive slots per step, whichever Gaussians they belong to (a rect of several hundred tiles
+    // simply spans several steps).  The order inside a tile's list is (Gaussian, i.e. slot) order:
+    //   * steps run in program order and LDS executes one wave's operations in order;
+    //   * inside a step, lanes holding the SAME tile are found with a ballot match over the tile index bits
+    //     (the radix sort's idiom): the lowest of them reserves `count` list positions with ONE ds_add_rtn and
+    //     the others take base + (number of matching lanes below them) — no reliance on how the LDS orders
+    //     conflicting atomics.
+    // ≈ S/64 steps (19 at C3) instead of one step per Gaussian (≈ 170), each with two dependent LDS round trips.
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint32_t carry1 = 0;  // (hit that owns the previous step's last slot) + 1;  0 = none yet
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        // owners: the ≤ 64 hits that START inside this step mark their first lane, a running maximum spreads them
+        mark[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t kc = carry1 + lane;  // candidate: the (lane+1)-th hit after the carried one
+        if (kc < nh) {
+            const uint32_t pk = l_pre[kc];
+            if (pk < s0 + 64u) mark[pk - s0] = kc + 1u;  // pk ≥ s0: the carried hit owns slot s0 - 1
         }
-        if (max(max(nj[0], nj[1]), max(nj[2], nj[3])) <= 64u) {
-            // all four rects fit one step each: pipeline them
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t ly = (uint32_t)(((float)lane + 0.5f) * inv_w[u]);  // row of the lane-th tile
-                const uint32_t lx = lane - ly * wj[u];
-                const uint32_t tr = bt[u] + ly * grid_x + lx;  // tile index relative to the band
-                in[u] = lane < nj[u] && tr < band_n;           // (unsigned: also rejects tiles before the band)
-                pos[u] = in[u] ? atomicAdd(&cursor[tr], 1u) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (in[u] && pos[u] < capacity) point_list[pos[u]] = cg[u];
-        } else {
-            // a rect of more than 64 tiles needs several steps; all of them must precede the next entry's
-            // (a later entry may share one of the tail tiles) → walk this group strictly one entry at a time
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                for (uint32_t l0 = 0; l0 < nj[u]; l0 += 64) {
-                    const uint32_t l = l0 + lane;
-                    if (l < nj[u]) {
-                        const uint32_t ly = (uint32_t)(((float)l + 0.5f) * inv_w[u]);
-                        const uint32_t lx = l - ly * wj[u];
-                        const uint32_t tr = bt[u] + ly * grid_x + lx;
-                        if (tr < band_n) {
-                            const uint32_t p = atomicAdd(&cursor[tr], 1u);
-                            if (p < capacity) point_list[p] = cg[u];
-                        }
-                    }
-                }
-            }
-        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t own1 = mark[lane];
+        if (lane == 0) own1 = max(own1, carry1);
+        own1 = wave_scan_max(own1);
+        carry1 = (uint32_t)__builtin_amdgcn_readlane((int)own1, 63);
+        const bool act = s < S;
+        const uint32_t k = own1 - 1u;  // (own1 ≥ 1: slot 0 is the start of hit 0)
+        const uint32_t j = s - l_pre[k], w = l_wh[k], cg = l_id[k], bt = l_xy[k];
+        // v_rcp_f32 (1 ulp) is enough: (j + ½)/w is ≥ ½/w away from any integer, i.e. a relative margin of
+        // ½/(j + ½) ≥ 7.6e-6 for j < 2^16 (a clipped rect has at most band + 2 rows of tiles) against ≈ 2.5e-7
+        const uint32_t ly = (uint32_t)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+        const uint32_t lx = j - ly * w;
+        const uint32_t tr = bt + ly * grid_x + lx;       // tile index relative to the band
+        const bool in = act && tr < band_n;               // (unsigned: also rejects tiles before the band)
+        // m = the lanes of this step that hold the same tile: an atomic OR of lane bits into the tile's mask word
+        // (order-free), read back, cleared again — three LDS operations instead of a 10-round ballot match
+        // (≈ 80 VALU instructions in a loop that is VALU-bound: 172 steps per SIMD at C3)
+        uint64_t m = 0ull;
+        if (in) atomicOr(&same[tr], 1ull << lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (in) m = same[tr];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (in) same[tr] = 0ull;
+        const uint32_t before = (uint32_t)__popcll(m & lt_mask);
+        uint32_t p0 = 0u;
+        if (in && before == 0u) p0 = atomicAdd(&cursor[tr], (uint32_t)__popcll(m));
+        const int leader = in ? (int)__builtin_ctzll(m) : (int)lane;
+        p0 = (uint32_t)__shfl((int)p0, leader);
+        const uint32_t pos = p0 + before;
+        if (in && pos < capacity) point_list[pos] = cg;
     }
+    // the next half's list overwrites this one: order this half's LDS reads before those writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // rect_sorted[i] = rect[order[i]]: lets K1 / K3 stream the rects instead of chasing order[] → rect[]
@@ -382,7 +427,7 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
     (void)rect;
     if (T == 0 || P == 0) return;
     const WorkArea w = carve_work(pl, (void*)work, T);
-    const size_t lds = ((size_t)pl.sband_tiles + 3 * GGR_BIN_CHUNK) * 4;
+    const size_t lds = (3 * (size_t)pl.sband_tiles + 4 * (GGR_BIN_CHUNK / 2) + 64) * 4;
     const uint32_t bands8 = (pl.nsbands + 7u) / 8u;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks * bands8 * 8u), dim3(64), lds, s, (uint32_t)P, order,
                        w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, point_list, capacity,
