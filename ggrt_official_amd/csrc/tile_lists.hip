@@ -33,38 +33,112 @@ __device__ __forceinline__ void unpack_rect(uint2 rc, uint32_t& x0, uint32_t& y0
     x0 = rc.x & 0xFFFFu; y0 = rc.x >> 16; x1 = rc.y & 0xFFFFu; y1 = rc.y >> 16;
 }
 
+// inclusive wave64 scans with DPP: four row_shr steps inside each 16-lane row, then row_bcast:15 / :31 carry the
+// row totals on (lanes without a source keep the identity 0)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+    v += dpp_u32<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_u32<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_u32<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_u32<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_u32<0x142, 0xa>(v);  // row_bcast:15 → rows 1, 3
+    v += dpp_u32<0x143, 0xc>(v);  // row_bcast:31 → rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+    v = max(v, dpp_u32<0x111, 0xf>(v));
+    v = max(v, dpp_u32<0x112, 0xf>(v));
+    v = max(v, dpp_u32<0x114, 0xf>(v));
+    v = max(v, dpp_u32<0x118, 0xf>(v));
+    v = max(v, dpp_u32<0x142, 0xa>(v));
+    v = max(v, dpp_u32<0x143, 0xc>(v));
+    return v;
+}
+
 // ---- K1 -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 bin_count_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect, uint32_t T,
                  uint32_t band_tiles, uint32_t grid_x, uint32_t* __restrict__ table) {
-    extern __shared__ uint32_t hist[];  // [band_tiles]
-    const uint32_t chunk = blockIdx.x, band = blockIdx.y, tid = threadIdx.x;
+    // LDS: hist[band_tiles] shared by the block + per wave the compacted list of its 256 Gaussians that touch the
+    // band (first tile relative to the band, rect width, first slot) and mark[64] (scratch of one step)
+    extern __shared__ uint32_t lds[];
+    constexpr uint32_t PER_WAVE = GGR_BIN_CHUNK / 4;
+    uint32_t* hist = lds;
+    const uint32_t chunk = blockIdx.x, band = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t* l_xy = lds + band_tiles + wave * (3 * PER_WAVE + 64);
+    uint32_t* l_w = l_xy + PER_WAVE;
+    uint32_t* l_pre = l_w + PER_WAVE;
+    uint32_t* mark = l_pre + PER_WAVE;
     const uint32_t lo = band * band_tiles, hi = min(T, lo + band_tiles);
-    for (uint32_t i = tid; i < hi - lo; i += 256) hist[i] = 0;
-    __syncthreads();
-    const uint32_t base = chunk * GGR_BIN_CHUNK;
-    // all of this thread's rects first (independent loads in flight together — the kernel is otherwise a
-    // chain of serial ≈1–2 µs round trips; PMC showed 59 % of the wave time waiting)
-    uint2 rcs[GGR_BIN_CHUNK / 256];
+    const uint32_t band_n = hi - lo;
+    for (uint32_t i = tid; i < band_n; i += 256) hist[i] = 0;
+    const uint32_t base = chunk * GGR_BIN_CHUNK + wave * PER_WAVE;
+    // all of this wave's rects first (independent loads in flight together — the kernel is otherwise a chain
+    // of serial ≈1–2 µs round trips; PMC showed 59 % of the wave time waiting)
+    uint2 rcs[PER_WAVE / 64];
 #pragma unroll
-    for (uint32_t q = 0; q < GGR_BIN_CHUNK / 256; q++) {
-        const uint32_t i = base + tid + q * 256;
+    for (uint32_t q = 0; q < PER_WAVE / 64; q++) {
+        const uint32_t i = base + q * 64 + lane;
         rcs[q] = i < P ? rect[i] : make_uint2(0u, 0u);  // rect_sorted: already in depth order
     }
+    __syncthreads();
+    // Same slot walk as bin_scatter (there with the full explanation), minus the ordering: the wave numbers the
+    // (Gaussian, tile) pairs of its quarter chunk consecutively and handles 64 of them per step with ONE
+    // order-free ds_add — every lane busy, where a thread-per-Gaussian loop over its own rect ran at the pace
+    // of the largest rect in the wave (0.051 → 0.03 ms at C3).
+    const uint32_t row_lo = lo / grid_x, row_hi = (hi - 1) / grid_x + 1;
+    uint32_t nh = 0, S = 0;
 #pragma unroll
-    for (uint32_t q = 0; q < GGR_BIN_CHUNK / 256; q++) {
+    for (uint32_t q = 0; q < PER_WAVE / 64; q++) {
         uint32_t x0, y0, x1, y1;
         unpack_rect(rcs[q], x0, y0, x1, y1);
-        if (x1 <= x0 || y1 <= y0) continue;
-        if ((y1 - 1) * grid_x + x1 - 1 < lo || y0 * grid_x + x0 >= hi) continue;
-        for (uint32_t y = y0; y < y1; y++)
-            for (uint32_t x = x0; x < x1; x++) {
-                const uint32_t t = y * grid_x + x;
-                if (t >= lo && t < hi) atomicAdd(&hist[t - lo], 1u);
-            }
+        const uint32_t ya = max(y0, row_lo), yb = min(y1, row_hi);
+        const uint32_t w = x1 > x0 ? x1 - x0 : 0, h = yb > ya ? yb - ya : 0;
+        const uint32_t n = w * h;
+        const bool hit = n > 0 && (yb - 1) * grid_x + x1 - 1 >= lo && ya * grid_x + x0 < hi;
+        const uint32_t incl = wave_scan_add(hit ? n : 0u);
+        const uint64_t mk = __ballot(hit);
+        if (hit) {
+            const uint32_t p = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            l_xy[p] = ya * grid_x + x0 - lo;
+            l_w[p] = w;
+            l_pre[p] = S + incl - n;
+        }
+        nh += (uint32_t)__popcll(mk);
+        S += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t carry1 = 0;
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        mark[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t kc = carry1 + lane;
+        if (kc < nh) {
+            const uint32_t pk = l_pre[kc];
+            if (pk < s0 + 64u) mark[pk - s0] = kc + 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t own1 = mark[lane];
+        if (lane == 0) own1 = max(own1, carry1);
+        own1 = wave_scan_max(own1);
+        carry1 = (uint32_t)__builtin_amdgcn_readlane((int)own1, 63);
+        const uint32_t k = own1 - 1u;
+        const uint32_t j = s - l_pre[k], w = l_w[k], bt = l_xy[k];
+        const uint32_t ly = (uint32_t)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)w));  // (see bin_scatter)
+        const uint32_t tr = bt + ly * grid_x + (j - ly * w);
+        if (s < S && tr < band_n) atomicAdd(&hist[tr], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // this step's mark reads before the next step's writes
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    for (uint32_t i = tid; i < hi - lo; i += 256) table[(size_t)chunk * T + lo + i] = hist[i];
+    for (uint32_t i = tid; i < band_n; i += 256) table[(size_t)chunk * T + lo + i] = hist[i];
 }
 
 // ---- K2a: per (tile, group of chunks) sum ---------------------------------------------------------
@@ -159,31 +233,6 @@ bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchun
 }
 
 // ---- K3 ------------------------------------------------------------------------------------------
-// inclusive wave64 scans with DPP: four row_shr steps inside each 16-lane row, then row_bcast:15 / :31 carry the
-// row totals on (lanes without a source keep the identity 0)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
-    v += dpp_u32<0x111, 0xf>(v);  // row_shr:1
-    v += dpp_u32<0x112, 0xf>(v);  // row_shr:2
-    v += dpp_u32<0x114, 0xf>(v);  // row_shr:4
-    v += dpp_u32<0x118, 0xf>(v);  // row_shr:8
-    v += dpp_u32<0x142, 0xa>(v);  // row_bcast:15 → rows 1, 3
-    v += dpp_u32<0x143, 0xc>(v);  // row_bcast:31 → rows 2, 3
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
-    v = max(v, dpp_u32<0x111, 0xf>(v));
-    v = max(v, dpp_u32<0x112, 0xf>(v));
-    v = max(v, dpp_u32<0x114, 0xf>(v));
-    v = max(v, dpp_u32<0x118, 0xf>(v));
-    v = max(v, dpp_u32<0x142, 0xa>(v));
-    v = max(v, dpp_u32<0x143, 0xc>(v));
-    return v;
-}
-
 __global__ void __launch_bounds__(64)
 bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect, uint32_t T,
                    uint32_t band_tiles, uint32_t grid_x, const uint32_t* __restrict__ table,
@@ -410,7 +459,8 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     if (!rects_gathered)  // (ggr_forward: the depth sort's last pass has done both jobs already)
         hipLaunchKernelGGL(gather_rect_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (uint32_t)P, order,
                            rect, w.rect_sorted, w.tile_start, (uint32_t)T);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nchunks, pl.nbands), dim3(256), pl.band_tiles * 4, s, (uint32_t)P,
+    hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nchunks, pl.nbands), dim3(256),
+                       ((size_t)pl.band_tiles + 4 * (3 * (GGR_BIN_CHUNK / 4) + 64)) * 4, s, (uint32_t)P,
                        order, w.rect_sorted, (uint32_t)T, pl.band_tiles, (uint32_t)grid_x, w.table);
     const unsigned tb = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
