@@ -177,15 +177,17 @@ bin_tile_scan_kernel(uint32_t T, uint32_t* __restrict__ tile_start /*in: totals,
             cnt[e] = first + e < T ? tile_start[first + e] : 0u;
             local += cnt[e];
         }
-        sh[tid] = local;
+        // block scan = DPP scan inside each wave + a scan of the 16 wave totals (2 barriers instead of 20)
+        const uint32_t in_wave = wave_scan_add(local);
+        if ((tid & 63u) == 63u) sh[tid >> 6] = in_wave;
         __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            const uint32_t v = tid >= off ? sh[tid - off] : 0u;
-            __syncthreads();
-            sh[tid] += v;
-            __syncthreads();
+        if (tid < 64) {
+            const uint32_t wt = tid < 16 ? sh[tid] : 0u;
+            const uint32_t ws = wave_scan_add(wt);
+            if (tid < 16) sh[16 + tid] = ws - wt;  // exclusive prefix of the wave totals
         }
-        const uint32_t incl = sh[tid], c = carry;
+        __syncthreads();
+        const uint32_t incl = in_wave + sh[16 + (tid >> 6)], c = carry;
         uint32_t start = c + incl - local;
 #pragma unroll
         for (uint32_t e = 0; e < E; e++) {
