@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libggr_raster.so")
 SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "tile_lists.hip", "blend_fwd.hip", "blend_bwd.hip",
            "preprocess_bwd.hip", "camera.hip"]
-HEADERS = ["ggr_common.h", "blend_common.h", os.path.join("..", "..", "include", "ggr_raster.h")]
+HEADERS = ["ggr_common.h", "blend_common.h", "sh_stage.h", os.path.join("..", "..", "include", "ggr_raster.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 

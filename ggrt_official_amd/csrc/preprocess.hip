@@ -8,6 +8,7 @@
 // the discrete outputs (cull decision, radius, tile rect → num_rendered) are bit-identical to the
 // CPU restatement; gfx950 fp32 divide/sqrt are correctly rounded under hipcc's defaults.
 #include "ggr_common.h"
+#include "sh_stage.h"
 
 #pragma clang fp contract(off)
 
@@ -102,31 +103,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const size_t g0 = (size_t)blockIdx.x * blockDim.x;
         const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
         const size_t row = (size_t)M * 3;
-        if (sh_flat) {
-            const size_t total = (size_t)nG * row;
-            const float* src = shs + g0 * row;
-            const int n4 = (int)(total >> 2);
-#pragma unroll 4
-            for (int j = threadIdx.x; j < n4; j += blockDim.x)
-                reinterpret_cast<float4*>(sh_lds)[j] = reinterpret_cast<const float4*>(src)[j];
-            for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) sh_lds[j] = src[j];
-        } else if ((row & 3) == 0 && (copy_row & 3) == 0) {
-            const int q_per = copy_row >> 2;
-#pragma unroll 4
-            for (int j = threadIdx.x; j < nG * q_per; j += blockDim.x) {
-                const int g = j / q_per, q = j - g * q_per;
-                const float4 v = *reinterpret_cast<const float4*>(shs + (g0 + g) * row + 4 * q);
-                float* d = sh_lds + g * sh_stride + 4 * q;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            // rows not 16-B aligned (GGRt: M = 25 → 300-B rows): one wave per row, lanes along the row
-            // (contiguous 4-B loads, no per-element div/mod)
-            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;
-#pragma unroll 8
-            for (int g = wv; g < nG; g += nw)
-                for (int k = ln; k < copy_row; k += 64) sh_lds[g * sh_stride + k] = shs[(g0 + g) * row + k];
-        }
+        stage_sh_rows(sh_lds, shs, g0, nG, row, copy_row, sh_stride, sh_flat);
         __syncthreads();
     }
     if (i >= P) return;

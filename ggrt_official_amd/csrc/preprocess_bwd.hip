@@ -7,6 +7,7 @@
 // scale/rotation backward.  Optionally accumulates the camera gradients (viewmatrix, projmatrix,
 // campos) — an extension beyond the reference.
 #include "ggr_common.h"
+#include "sh_stage.h"
 
 namespace ggr {
 
@@ -80,30 +81,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     if (inf.tanfov_dev) { tanfovx = inf.tanfov_dev[0]; tanfovy = inf.tanfov_dev[1]; }  // device-resident tan(fov/2)
     const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
     if (use_sh) {
-        if (sh_flat) {
-            const size_t total = (size_t)nG * sh_row;
-            const float* src = shs + g0 * sh_row;
-            const int n4 = (int)(total >> 2);
-#pragma unroll 4
-            for (int j = threadIdx.x; j < n4; j += blockDim.x)
-                reinterpret_cast<float4*>(sh_lds)[j] = reinterpret_cast<const float4*>(src)[j];
-            for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) sh_lds[j] = src[j];
-        } else if ((sh_row & 3) == 0 && (copy_row & 3) == 0) {
-            const int q_per = copy_row >> 2;
-#pragma unroll 4
-            for (int j = threadIdx.x; j < nG * q_per; j += blockDim.x) {
-                const int g = j / q_per, q = j - g * q_per;
-                const float4 v = *reinterpret_cast<const float4*>(shs + (g0 + g) * sh_row + 4 * q);
-                float* d = sh_lds + g * sh_stride + 4 * q;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            // rows not 16-B aligned (GGRt: M = 25): one wave per row, lanes along the row, no div/mod
-            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;
-#pragma unroll 8
-            for (int g = wv; g < nG; g += nw)
-                for (int k = ln; k < copy_row; k += 64) sh_lds[g * sh_stride + k] = shs[(g0 + g) * sh_row + k];
-        }
+        stage_sh_rows(sh_lds, shs, g0, nG, sh_row, copy_row, sh_stride, sh_flat);
         __syncthreads();
     }
     float V[16], PM[16];
