@@ -99,6 +99,34 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int copy_row = inf.sh_channel_major ? M * 3 : sh_rowf;
     const int sh_stride = sh_flat ? M * 3 : (copy_row | 1);
     const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? M : 1;
+    // this thread's own inputs are requested BEFORE the SH staging, so that their round trip overlaps it
+    // (clamped index: threads past P load Gaussian P-1 and drop it)
+    const size_t il = (size_t)min(i, P - 1);
+    float V[16], PM[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PM[k] = projmatrix[k]; }
+    if (inf.tanfov_dev) { tanfovx = inf.tanfov_dev[0]; tanfovy = inf.tanfov_dev[1]; }  // device-resident tan(fov/2)
+    const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
+    const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];
+    const float opac = opacities[il];
+    float cin[6], rin[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cov3D_precomp) {
+        if (inf.cov_stride == 9) {
+            const float* c9 = cov3D_precomp + 9 * il;
+            cin[0] = c9[0]; cin[1] = c9[1]; cin[2] = c9[2]; cin[3] = c9[4]; cin[4] = c9[5]; cin[5] = c9[8];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cin[k] = cov3D_precomp[6 * il + k];
+        }
+    } else {
+        cin[0] = scales[3 * il]; cin[1] = scales[3 * il + 1]; cin[2] = scales[3 * il + 2];
+        cin[3] = cin[4] = cin[5] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) rin[k] = rotations[4 * il + k];
+    }
+    const float aux_in = aux_precomp ? aux_precomp[il] : 0.f;
+    float cp_in[3] = {0.f, 0.f, 0.f};
+    if (colors_precomp) { cp_in[0] = colors_precomp[3 * il]; cp_in[1] = colors_precomp[3 * il + 1]; cp_in[2] = colors_precomp[3 * il + 2]; }
     if (shs) {
         const size_t g0 = (size_t)blockIdx.x * blockDim.x;
         const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
@@ -107,9 +135,6 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         __syncthreads();
     }
     if (i >= P) return;
-    float V[16], PM[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PM[k] = projmatrix[k]; }
 
     // defaults for a culled Gaussian
     int rad_out = 0;
@@ -120,24 +145,15 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // call-site fusion: the reference's 1/near renormalisation (means·s, cov·s², scales·s — cuda_splatting.py:
     // 66-73) and its upper-triangle gather out of [P,3,3] covariances (:116,124) happen on load.  One fp32
     // multiply per value, exactly what the torch ops of the unfused call site do.
-    if (inf.tanfov_dev) { tanfovx = inf.tanfov_dev[0]; tanfovy = inf.tanfov_dev[1]; }  // device-resident tan(fov/2)
-    const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
-    const float p0 = in_s * means3D[3 * i], p1 = in_s * means3D[3 * i + 1], p2 = in_s * means3D[3 * i + 2];
+    const float p0 = in_s * m0, p1 = in_s * m1, p2 = in_s * m2;
     float cov6[6];
     if (cov3D_precomp) {
         const float s2 = in_s * in_s;
-        if (inf.cov_stride == 9) {
-            const float* c9 = cov3D_precomp + 9 * (size_t)i;
-            cov6[0] = c9[0] * s2; cov6[1] = c9[1] * s2; cov6[2] = c9[2] * s2;
-            cov6[3] = c9[4] * s2; cov6[4] = c9[5] * s2; cov6[5] = c9[8] * s2;
-        } else {
 #pragma unroll
-            for (int k = 0; k < 6; k++) cov6[k] = cov3D_precomp[6 * (size_t)i + k] * s2;
-        }
+        for (int k = 0; k < 6; k++) cov6[k] = cin[k] * s2;
     } else {
-        float sc[3] = {in_s * scales[3 * i], in_s * scales[3 * i + 1], in_s * scales[3 * i + 2]};
-        float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
-        cov3d_from_scale_rot(sc, scale_modifier, q, cov6);
+        float sc[3] = {in_s * cin[0], in_s * cin[1], in_s * cin[2]};
+        cov3d_from_scale_rot(sc, scale_modifier, rin, cov6);
 #pragma unroll
         for (int k = 0; k < 6; k++) cov3D_out[6 * (size_t)i + k] = cov6[k];
     }
@@ -198,7 +214,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             if (area != 0) {
                 float rgb[3];
                 if (colors_precomp) {
-                    rgb[0] = colors_precomp[3 * i]; rgb[1] = colors_precomp[3 * i + 1]; rgb[2] = colors_precomp[3 * i + 2];
+                    rgb[0] = cp_in[0]; rgb[1] = cp_in[1]; rgb[2] = cp_in[2];
                 } else {
                     const int deg = D > 3 ? 3 : D;
                     float d0 = p0 - campos[0], d1 = p1 - campos[1], d2 = p2 - campos[2];
@@ -221,13 +237,13 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 tiles_out = (uint32_t)area;
                 rect_out = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
                 s0 = make_float4(px, py, con0, con1);
-                s1 = make_float4(con2, opacities[i], rgb[0], rgb[1]);
+                s1 = make_float4(con2, opac, rgb[0], rgb[1]);
                 // 4th blended feature: the caller's aux value, or view z, or (fused GGRt depth pass, :240-269)
                 // max(a + b·z_unscaled, 0) with z_unscaled = z / s
                 float feat = t2;
-                if (aux_precomp) feat = aux_precomp[i];
+                if (aux_precomp) feat = aux_in;
                 else if (inf.aux_affine) feat = fmaxf(inf.aux_a + inf.aux_b * (t2 / in_s), 0.f);
-                s2 = make_float4(rgb[2], feat, 2.f * logf(255.f * opacities[i]), 0.f);  // .z = qmax for the box cull
+                s2 = make_float4(rgb[2], feat, 2.f * logf(255.f * opac), 0.f);  // .z = qmax for the box cull
             }
         }
     }

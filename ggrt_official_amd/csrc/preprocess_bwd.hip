@@ -80,13 +80,25 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? M : 1;
     if (inf.tanfov_dev) { tanfovx = inf.tanfov_dev[0]; tanfovy = inf.tanfov_dev[1]; }  // device-resident tan(fov/2)
     const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
+    // this thread's own inputs are requested BEFORE the SH staging, so that their round trip overlaps it
+    float V[16], PM[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PM[k] = projmatrix[k]; }
+    const size_t il = (size_t)min(i, P - 1);
+    const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];
+    float cin[6];
+    if (cov_is_input && inf.cov_stride == 9) {
+        const float* c9 = cov3D + 9 * il;
+        cin[0] = c9[0]; cin[1] = c9[1]; cin[2] = c9[2]; cin[3] = c9[4]; cin[4] = c9[5]; cin[5] = c9[8];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cin[k] = cov3D[6 * il + k];
+    }
+    const uint32_t clamp_in = clamped[il];
     if (use_sh) {
         stage_sh_rows(sh_lds, shs, g0, nG, sh_row, copy_row, sh_stride, sh_flat);
         __syncthreads();
     }
-    float V[16], PM[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PM[k] = projmatrix[k]; }
 
     float dmean[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -99,22 +111,13 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int K = (deg + 1) * (deg + 1);
 
     if (live) {
-        const float p0 = in_s * means3D[3 * i], p1 = in_s * means3D[3 * i + 1], p2 = in_s * means3D[3 * i + 2];
+        const float p0 = in_s * m0, p1 = in_s * m1, p2 = in_s * m2;
         float cov6[6];
-        if (cov_is_input) {  // the caller's covariances, in the caller's form (preprocess_fwd applies the same)
-            const float s2 = in_s * in_s;
-            if (inf.cov_stride == 9) {
-                const float* c9 = cov3D + 9 * (size_t)i;
-                cov6[0] = c9[0] * s2; cov6[1] = c9[1] * s2; cov6[2] = c9[2] * s2;
-                cov6[3] = c9[4] * s2; cov6[4] = c9[5] * s2; cov6[5] = c9[8] * s2;
-            } else {
+        // the caller's covariances come in the caller's form (preprocess_fwd applies the same); on the scale /
+        // rotation path they are what preprocess_fwd stored (already scaled)
+        const float s2 = cov_is_input ? in_s * in_s : 1.0f;
 #pragma unroll
-                for (int k = 0; k < 6; k++) cov6[k] = cov3D[6 * (size_t)i + k] * s2;
-            }
-        } else {  // scale / rotation path: what preprocess_fwd stored (already scaled)
-#pragma unroll
-            for (int k = 0; k < 6; k++) cov6[k] = cov3D[6 * (size_t)i + k];
-        }
+        for (int k = 0; k < 6; k++) cov6[k] = cin[k] * s2;
         const float dcon0 = r1.y, dcon1 = r1.z, dcon2 = r1.w;
 
         const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
@@ -233,7 +236,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (has_colors_precomp) {
             dL_dcolors_precomp[3 * i] = dc0; dL_dcolors_precomp[3 * i + 1] = dc1; dL_dcolors_precomp[3 * i + 2] = dc2;
         } else {
-            const uint32_t cl = clamped[i];
+            const uint32_t cl = clamp_in;
             if (cl & 1u) dc0 = 0.f;
             if (cl & 2u) dc1 = 0.f;
             if (cl & 4u) dc2 = 0.f;
