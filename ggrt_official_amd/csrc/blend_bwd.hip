@@ -113,11 +113,14 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const int vi = lane & 7;
     const int my_slot = lane >> 3;
 
+    // the list ids of a batch are requested one batch ahead (id → record is a chain of two global round trips)
+    uint32_t g_next = tid < top ? point_list[range.x + top - 1 - tid] : 0u;
     for (int hi_ = top; hi_ > 0; hi_ -= BATCH) {
         const int nb = min(BATCH, hi_);
         __syncthreads();
+        const uint32_t g = g_next;
+        if (hi_ - BATCH - 1 - tid >= 0) g_next = point_list[range.x + hi_ - BATCH - 1 - tid];
         if (tid < nb) {
-            const uint32_t g = point_list[range.x + hi_ - 1 - tid];
             const float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1];
             float4 c = splat[3 * (size_t)g + 2];
             c.w = __uint_as_float(g);

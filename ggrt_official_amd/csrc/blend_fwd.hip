@@ -51,12 +51,16 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     if (lane == 0) wave_done[wave] = quad_live ? 0 : 1;
     bool wdone = !quad_live;
 
+    // the list ids of a batch are requested one batch ahead: id → record is a chain of two global round trips,
+    // only the second is left on the batch's critical path
+    uint32_t g_next = tid < total ? point_list[range.x + tid] : 0u;
     for (int b0 = 0; b0 < total; b0 += BATCH) {
         __syncthreads();  // previous batch fully consumed; wave_done visible
         if (wave_done[0] & wave_done[1] & wave_done[2] & wave_done[3]) break;
         const int nb = min(BATCH, total - b0);
+        const uint32_t g = g_next;
+        if (b0 + BATCH + tid < total) g_next = point_list[range.x + b0 + BATCH + tid];
         if (tid < nb) {
-            const uint32_t g = point_list[range.x + b0 + tid];
             const float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1], c = splat[3 * (size_t)g + 2];
             stage[tid].a = a;
             stage[tid].b = b;
