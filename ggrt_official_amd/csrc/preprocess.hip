@@ -97,8 +97,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // channel-major rows ([3][M], GGRt's harmonics layout): coefficient k of channel c sits at c·M + k, so the
     // whole row is staged; k-major rows ([M][3], upstream) only need their first 3K floats
     const int copy_row = inf.sh_channel_major ? M * 3 : sh_rowf;
-    const int sh_stride = sh_flat ? M * 3 : (copy_row | 1);
-    const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? M : 1;
+    const bool sh_compact = M * 3 > sh_rowf && M * 3 <= 128 && (sh_flat || inf.sh_channel_major);
+    const int sh_stride = sh_compact ? (sh_rowf | 1) : sh_flat ? M * 3 : (copy_row | 1);
+    const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? (sh_compact ? sh_rowf / 3 : M) : 1;
     // this thread's own inputs are requested BEFORE the SH staging, so that their round trip overlaps it
     // (clamped index: threads past P load Gaussian P-1 and drop it)
     const size_t il = (size_t)min(i, P - 1);
@@ -131,7 +132,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const size_t g0 = (size_t)blockIdx.x * blockDim.x;
         const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
         const size_t row = (size_t)M * 3;
-        stage_sh_rows(sh_lds, shs, g0, nG, row, copy_row, sh_stride, sh_flat);
+        if (sh_compact) stage_sh_rows_compact(sh_lds, shs, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
+        else stage_sh_rows(sh_lds, shs, g0, nG, row, copy_row, sh_stride, sh_flat);
         __syncthreads();
     }
     if (i >= P) return;
@@ -271,7 +273,9 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     const int deg = D > 3 ? 3 : D;
     const bool flat = ((3 * M) & 1) && (reinterpret_cast<uintptr_t>(shs) & 15) == 0;  // same predicate as the kernel
     const size_t copy_row = inf.sh_channel_major ? (size_t)(3 * M) : (size_t)(3 * (deg + 1) * (deg + 1));
-    const size_t row_stride = flat ? (size_t)(3 * M) : (copy_row | 1);
+    const size_t rowf = (size_t)(3 * (deg + 1) * (deg + 1));
+    const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
+    const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
     const size_t lds = shs ? (size_t)threads * row_stride * sizeof(float) : 0;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,

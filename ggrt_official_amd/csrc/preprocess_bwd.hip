@@ -76,8 +76,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const bool sh_flat = (sh_row & 1) != 0 && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
     // (input forms as in preprocess_fwd: channel-major rows are staged — and their gradient written — whole)
     const int copy_row = inf.sh_channel_major ? (int)sh_row : sh_rowf;
-    const int sh_stride = sh_flat ? (int)sh_row : (copy_row | 1);
-    const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? M : 1;
+    // rows longer than what is used (GGRt: 25 coefficients, 16 used): only the used 3K floats live in LDS
+    const bool sh_compact = (int)sh_row > sh_rowf && sh_row <= 128 && (sh_flat || inf.sh_channel_major);
+    const int sh_stride = sh_compact ? (sh_rowf | 1) : sh_flat ? (int)sh_row : (copy_row | 1);
+    const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? (sh_compact ? sh_rowf / 3 : M) : 1;
     if (inf.tanfov_dev) { tanfovx = inf.tanfov_dev[0]; tanfovy = inf.tanfov_dev[1]; }  // device-resident tan(fov/2)
     const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
     // this thread's own inputs are requested BEFORE the SH staging, so that their round trip overlaps it
@@ -96,7 +98,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     }
     const uint32_t clamp_in = clamped[il];
     if (use_sh) {
-        stage_sh_rows(sh_lds, shs, g0, nG, sh_row, copy_row, sh_stride, sh_flat);
+        if (sh_compact) stage_sh_rows_compact(sh_lds, shs, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
+        else stage_sh_rows(sh_lds, shs, g0, nG, sh_row, copy_row, sh_stride, sh_flat);
         __syncthreads();
     }
 
@@ -332,7 +335,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         // culled Gaussian: all gradients are zero
         if (use_sh) {
             float* dsh = sh_lds + threadIdx.x * sh_stride;
-            for (int k = 0; k < (sh_flat ? (int)sh_row : copy_row); k++) dsh[k] = 0.f;
+            for (int k = 0; k < (sh_compact ? sh_rowf : sh_flat ? (int)sh_row : copy_row); k++) dsh[k] = 0.f;
         }
         if (has_colors_precomp) { dL_dcolors_precomp[3 * i] = 0.f; dL_dcolors_precomp[3 * i + 1] = 0.f; dL_dcolors_precomp[3 * i + 2] = 0.f; }
         if (scales && dL_dscales) {
@@ -342,7 +345,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     }
     if (use_sh) {
         // coalesced write-out of dL/dSH: the first 3K floats of every row from LDS, the rest zero
-        if (live && inf.sh_channel_major) {  // unused coefficients (k ≥ K) of every channel get zero gradient
+        if (sh_compact) {
+            // nothing to clear: the compact row holds used coefficients only
+        } else if (live && inf.sh_channel_major) {  // unused coefficients (k ≥ K) of every channel get zero gradient
             float* dsh = sh_lds + threadIdx.x * sh_stride;
             for (int c = 0; c < 3; c++)
                 for (int k = K; k < M; k++) dsh[c * M + k] = 0.f;
@@ -351,7 +356,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             for (int k = sh_rowf; k < (int)sh_row; k++) dsh[k] = 0.f;
         }
         __syncthreads();
-        if (sh_flat) {
+        if (sh_compact) {
+            write_sh_rows_compact(dL_dsh, sh_lds, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
+        } else if (sh_flat) {
             const size_t total = (size_t)nG * sh_row;
             float* dst = dL_dsh + g0 * sh_row;
             const int n4 = (int)(total >> 2);
@@ -453,7 +460,9 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     const int deg = D > 3 ? 3 : D;
     const bool flat = ((3 * M) & 1) && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
     const size_t copy_row = inf.sh_channel_major ? (size_t)(3 * M) : (size_t)(3 * (deg + 1) * (deg + 1));
-    const size_t row_stride = flat ? (size_t)(3 * M) : (copy_row | 1);
+    const size_t rowf = (size_t)(3 * (deg + 1) * (deg + 1));
+    const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
+    const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
     const size_t lds = (!has_colors_precomp && shs) ? (size_t)256 * row_stride * sizeof(float) : 0;
     if (pose_acc) {
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,

@@ -66,4 +66,58 @@ __device__ __forceinline__ void stage_sh_rows(float* __restrict__ sh_lds, const 
     }
 }
 
+// Compact variant: only the 3K floats a row contributes are kept in LDS (stride 3K|1) although the row holds 3M > 3K
+// (GGRt: M = 25, K = 16 → 49 instead of 75 floats per Gaussian = 3 instead of 2 resident blocks per CU).  One wave
+// per row, lanes along the row (4-B loads, 256-B coalesced segments), eight rows = 16 loads in flight.
+// k-major rows keep columns < 3K; channel-major rows keep (col mod M) < K, stored as [c][K].
+__device__ __forceinline__ void stage_sh_rows_compact(float* __restrict__ sh_lds, const float* __restrict__ shs,
+                                                      size_t g0, int nG, int M, int K, int stride, bool channel_major) {
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int row = 3 * M;
+    // this lane's two columns and where (if anywhere) they go
+    int col[2] = {ln, ln + 64}, dst[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (col[h] >= row) dst[h] = -1;
+        else if (channel_major) { const int c = col[h] / M, k = col[h] - c * M; dst[h] = k < K ? c * K + k : -1; }
+        else dst[h] = col[h] < 3 * K ? col[h] : -1;
+    }
+    const int c0 = min(col[0], row - 1), c1 = min(col[1], row - 1);
+    for (int gb = wv * 8; gb < nG; gb += 32) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const size_t g = g0 + (size_t)min(gb + r, nG - 1);
+            v[2 * r] = shs[g * row + c0];
+            v[2 * r + 1] = shs[g * row + c1];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (gb + r < nG) {
+                if (dst[0] >= 0) sh_lds[(gb + r) * stride + dst[0]] = v[2 * r];
+                if (dst[1] >= 0) sh_lds[(gb + r) * stride + dst[1]] = v[2 * r + 1];
+            }
+        }
+    }
+}
+
+// Inverse of the compact staging for the gradient rows: dL/dSH row g = the 3K compact LDS values at their columns,
+// zero everywhere else (coefficients k ≥ K get no gradient), written with coalesced 4-B stores along the row.
+__device__ __forceinline__ void write_sh_rows_compact(float* __restrict__ dL_dsh, const float* __restrict__ sh_lds,
+                                                      size_t g0, int nG, int M, int K, int stride, bool channel_major) {
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int row = 3 * M;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int col = ln + 64 * h;
+        if (col >= row) continue;
+        int dst;
+        if (channel_major) { const int c = col / M, k = col - c * M; dst = k < K ? c * K + k : -1; }
+        else dst = col < 3 * K ? col : -1;
+#pragma unroll 8
+        for (int g = wv; g < nG; g += 4)
+            dL_dsh[(g0 + g) * row + col] = dst >= 0 ? sh_lds[g * stride + dst] : 0.f;
+    }
+}
+
 }  // namespace ggr
