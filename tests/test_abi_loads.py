@@ -75,3 +75,33 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert not re.search(r"#\s*include[^\n]*oracle", src), f
                 assert "libggr_oracle" not in src and "c_oracle" not in src and "torch_raster" not in src, f
+
+
+def test_error_paths_return_codes_and_messages_without_touching_a_gpu():
+    """Argument validation happens before any HIP call: bad calls come back with a non-zero code and a
+    thread-local message (the error behaviour a binding maps to exceptions), and the upstream wording for the
+    "exactly one of" checks is kept."""
+    import ctypes as C
+    lib = _lib.load()
+    err = lambda: (lib.ggr_last_error() or b"").decode()
+    assert lib.ggr_forward(None, None, None, _lib.ALLOC_FN(lambda c, n: None), None, None) != 0 and "null" in err()
+    assert lib.ggr_backward(None, None, None, None) != 0 and err()
+    st = _lib.GgrSettings(image_height=16, image_width=16, sh_degree=0, sh_stride=0, num_points=4, tanfovx=1.0, tanfovy=1.0,
+                          scale_modifier=1.0)
+    fin = _lib.GgrForwardIn()           # neither SHs nor colours
+    fout = _lib.GgrForwardOut()
+    cb = _lib.ALLOC_FN(lambda c, n: None)
+    assert lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, None) != 0
+    assert "excatly one of either SHs or precomputed colors" in err()          # (sic, upstream's spelling)
+    fin = _lib.GgrForwardIn(means3D=1, colors_precomp=1, opacities=1)          # colours, but no covariance form
+    assert lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, None) != 0
+    assert "exactly one of either scale/rotation pair or precomputed 3D covariance" in err()
+    fin = _lib.GgrForwardIn(means3D=1, shs=1, opacities=1, cov3D_precomp=1)
+    st.sh_degree, st.sh_stride = 3, 4                                          # 4 coefficients cannot hold degree 3
+    assert lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, None) != 0 and "sh_stride" in err()
+    st.sh_degree, st.sh_stride, st.image_width = 0, 1, 16 * 70000              # beyond the packed-rect range
+    assert lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, None) != 0 and err()
+    assert lib.ggr_camera_setup(2, None, None, None, None, 1, None, None, None, None, None, None) != 0 and err()
+    assert lib.ggr_forward_status(None, 4, None, None, None) != 0 and err()
+    # a successful query clears nothing it should not: size queries never fail
+    assert lib.ggr_geom_bytes(0) > 0 and lib.ggr_backward_scratch_bytes(0) > 0
