@@ -119,14 +119,14 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int pass,
                       uint32_t ntiles, uint32_t* __restrict__ hist, const uint2* __restrict__ gather_src,
                       uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
-    __shared__ uint32_t wcount[4][GGR_RADIX];  // per-wave digit counters, later per-wave output bases
+    constexpr int NW = GGR_SORT_THREADS / 64;
+    __shared__ uint32_t wcount[NW][GGR_RADIX];  // per-wave digit counters, later per-wave output bases
     __shared__ uint32_t tile_sh;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int shift = pass * GGR_RADIX_BITS;
     if (tid == 0) tile_sh = atomicAdd(&hist[GGR_HIST_TICKETS + pass], 1u);
-#pragma unroll
-    for (int w = 0; w < 4; w++) wcount[w][tid] = 0;
+    for (int x = tid; x < NW * GGR_RADIX; x += GGR_SORT_THREADS) (&wcount[0][0])[x] = 0;
     __syncthreads();
     const uint32_t tile = tile_sh;
     uint32_t* status = hist + GGR_HIST_STATUS + (size_t)pass * ntiles * GGR_RADIX;
@@ -180,10 +180,12 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
         rank[r] = prev + before;
     }
     __syncthreads();
-    // thread d owns digit d: publish the tile aggregate, look back, publish the inclusive prefix
-    {
-        const uint32_t c0 = wcount[0][tid], c1 = wcount[1][tid], c2 = wcount[2][tid], c3 = wcount[3][tid];
-        const uint32_t total = c0 + c1 + c2 + c3;
+    // thread d < 256 owns digit d: publish the tile aggregate, look back, publish the inclusive prefix
+    uint32_t cw[NW], g = 0;
+    if (tid < GGR_RADIX) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) { cw[w] = wcount[w][tid]; total += cw[w]; }
         uint32_t* mine = status + (size_t)tile * GGR_RADIX + tid;
         __hip_atomic_store(mine, ((tile == 0 ? GGR_FLAG_INCL : GGR_FLAG_AGG) << 30) | total, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -206,12 +208,13 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
             __hip_atomic_store(mine, (GGR_FLAG_INCL << 30) | ((excl + total) & GGR_COUNT_MASK), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
-        const uint32_t g = hist[GGR_HIST_BASES + pass * GGR_RADIX + tid] + excl;
-        __syncthreads();
-        wcount[0][tid] = g;
-        wcount[1][tid] = g + c0;
-        wcount[2][tid] = g + c0 + c1;
-        wcount[3][tid] = g + c0 + c1 + c2;
+        g = hist[GGR_HIST_BASES + pass * GGR_RADIX + tid] + excl;
+    }
+    __syncthreads();
+    if (tid < GGR_RADIX) {
+        uint32_t run = g;
+#pragma unroll
+        for (int w = 0; w < NW; w++) { wcount[w][tid] = run; run += cw[w]; }
     }
     __syncthreads();
 #pragma unroll

@@ -34,9 +34,10 @@
 #define GGR_ALPHA_MAX 0.99f
 #define GGR_T_MIN 0.0001f
 
-// radix sort geometry: 256 threads × 16 items
-#define GGR_SORT_THREADS 256
-#define GGR_SORT_ITEMS 16
+// radix sort geometry: 512 threads × 8 items = 4096 keys per tile (8 ranking rounds per wave instead of 16 with
+// 256 × 16: the rounds are a chain of dependent LDS round trips, and a tile per CU leaves room for 8 waves)
+#define GGR_SORT_THREADS 512
+#define GGR_SORT_ITEMS 8
 #define GGR_SORT_TILE (GGR_SORT_THREADS * GGR_SORT_ITEMS)
 #define GGR_RADIX_BITS 8
 #define GGR_RADIX 256
