@@ -431,7 +431,14 @@ pose_finish_kernel(const float* __restrict__ pose_acc, int nblocks, float* __res
     __shared__ float sh[256];
     const int k = blockIdx.x, tid = threadIdx.x;
     float acc = 0.f;
-    for (int b = tid; b < nblocks; b += 256) acc += pose_acc[64 + (size_t)b * 64 + k];
+    // sixteen rows per trip, all loads issued before the first add (clamped index, masked add)
+    for (int b0 = 0; b0 < nblocks; b0 += 16 * 256) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = pose_acc[64 + (size_t)min(b0 + u * 256 + tid, nblocks - 1) * 64 + k];
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc += b0 + u * 256 + tid < nblocks ? v[u] : 0.f;
+    }
     sh[tid] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
