@@ -2,7 +2,8 @@
 //
 // Replaces `RasterizeGaussiansCUDA` / `RasterizeGaussiansBackwardCUDA` of the extension GGRt
 // imports at reference ggrt/model/pixelsplat/decoder/cuda_splatting.py:6-9.
-// No global mutable state: the only static is a thread_local error string.
+// No global mutable state: the only statics are thread_local — an error string and, per device, one pinned word +
+// one event for the num_rendered read-back.
 #include "../../include/ggr_raster.h"
 #include "ggr_common.h"
 
@@ -74,6 +75,27 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
     if (tiles > (1 << 24)) return fail(GGR_E_LIMIT, "image has %lld tiles; at most 2^24 supported", (long long)tiles);
     if (st->image_width > 65535 * GGR_TILE || st->image_height > 65535 * GGR_TILE) return fail(GGR_E_LIMIT, "image too large");
     return GGR_OK;
+}
+
+// per host thread and device: one pinned word + one event for the num_rendered read-back of the exact mode (a
+// thread has at most one forward between its launch and its sync, so the slot is never shared; never freed — a
+// thread_local destructor could run after the HIP runtime is gone)
+struct ReadbackSlot {
+    uint32_t* host = nullptr;
+    hipEvent_t ev = nullptr;
+};
+ReadbackSlot* readback_slot() {
+    static thread_local ReadbackSlot slots[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    ReadbackSlot& r = slots[dev];
+    if (!r.host) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); return nullptr; }
+        r.host = (uint32_t*)p;
+    }
+    return &r;
 }
 
 InputForm input_form(const GgrSettings* st, const GgrForwardIn* in) {
@@ -154,9 +176,14 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     const bool sync_free = out->binning_capacity > 0 && out->binning_buffer != nullptr;
     if (out->binning_capacity >= 0x7FFFFFFF) return fail(GGR_E_LIMIT, "binning_capacity too large");
     const uint32_t capacity = sync_free ? (uint32_t)out->binning_capacity : 0xFFFFFFFFu;
+    // exact mode: num_rendered travels to the host through a pinned word written by the scan kernel, with an
+    // event right behind that kernel — the host wakes up while the last scan kernel still runs and has the list
+    // buffer allocated and the scatter queued by the time the GPU gets there (a device→host memcpy into pageable
+    // memory + stream sync left the GPU idle for that long)
+    ReadbackSlot* rb = (!sync_free && P > 0) ? readback_slot() : nullptr;
     if (P > 0) {
         ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, capacity, s,
-                                    /*rects_gathered=*/true);
+                                    /*rects_gathered=*/true, rb ? rb->host : nullptr, rb ? rb->ev : nullptr);
     } else {
         HIP_TRY(hipMemsetAsync(im.ranges, 0, (tiles ? tiles : 1) * sizeof(uint2), s));
         HIP_TRY(hipMemsetAsync(g.counters, 0, 8, s));
@@ -165,8 +192,13 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     uint32_t num_rendered = 0;
     uint32_t* point_list = nullptr;
     if (!sync_free) {
-        HIP_TRY(hipMemcpyAsync(&num_rendered, g.counters, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));  // the single host sync of forward
+        if (rb) {
+            HIP_TRY(hipEventSynchronize(rb->ev));  // the single host sync of forward
+            num_rendered = *(volatile uint32_t*)rb->host;
+        } else {
+            HIP_TRY(hipMemcpyAsync(&num_rendered, g.counters, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
         if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
         out->num_rendered = (int64_t)num_rendered;
         tm.mark();

@@ -186,7 +186,9 @@ TileListPlan plan_tile_lists(size_t P, size_t T);
 void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                             const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, uint32_t capacity,
                             hipStream_t s, bool rects_gathered = false /*the depth sort already filled rect_sorted
-                            and cleared the per-tile totals (tile_list_gather_targets)*/);
+                            and cleared the per-tile totals (tile_list_gather_targets)*/,
+                            uint32_t* host_total = nullptr /*pinned, device-visible: also receives N …*/,
+                            hipEvent_t after_scan = nullptr /*… and this event is recorded right behind the scan*/);
 // where the depth sort's last pass should put the rects in depth order / which words it should clear
 void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint2** rect_sorted,
                               uint32_t** zero_area, uint32_t* zero_words);
