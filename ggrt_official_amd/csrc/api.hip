@@ -221,7 +221,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
 
     // 5. blend
     ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, st->bg, out->out_color, im.final_T, im.n_contrib,
-                          out->out_depth, s);
+                          out->out_depth, im.ckpt, im.ckpt_slots, im.tile_top, s);
     KCHECK(dbg, s, "blend_fwd");
     tm.mark();
     tm.finish();
@@ -268,7 +268,8 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
 
     if (in->num_rendered != 0) {  // (-1: sync-free forward, count known on the device only)
         ggr::launch_blend_bwd(W, H, im.ranges, point_list, g.splat, st->bg, im.final_T, im.n_contrib,
-                              in->dL_dout_color, in->dL_dout_depth, sc.grad2d, s);
+                              in->dL_dout_color, in->dL_dout_depth, sc.grad2d, im.tile_top, im.ckpt,
+                              im.ckpt_slots, im.bwd_segments, s);
         KCHECK(dbg, s, "blend_bwd");
     }
     tm.mark();

@@ -69,13 +69,19 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
                  const float* __restrict__ bg, const float* __restrict__ final_T,
                  const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                 const float* __restrict__ dL_ddepth, float* __restrict__ grad2d) {
+                 const float* __restrict__ dL_ddepth, float* __restrict__ grad2d,
+                 const uint32_t* __restrict__ tile_top, const float* __restrict__ ckpt, int ckpt_slots,
+                 int segments) {
     __shared__ StagedSplat stage[BATCH];
-    __shared__ uint32_t wave_last_sh[4];
     __shared__ __attribute__((aligned(16))) uint16_t surv[4][BATCH];  // per wave: stage indices of the entries that survive its quadrant cull
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = xcd_tile((int)blockIdx.x, grid_x * ((H + GGR_TILE - 1) / GGR_TILE));
+    // workgroup = (depth segment, tile), segment-major: all tiles' segment 0 first.  (Tile-major order interleaves
+    // the loaded and the empty segments with a fixed period, and the dispatcher's round robin then puts all loaded
+    // workgroups on the same fraction of the CUs: C3 with 2 segments per tile ran 0.75 ms instead of 0.43.)
+    const int ntiles = grid_x * ((H + GGR_TILE - 1) / GGR_TILE);
+    const int seg = segments > 1 ? (int)blockIdx.x / xcd_grid(ntiles) : 0;
+    const int tile = xcd_tile((int)blockIdx.x - seg * xcd_grid(ntiles), ntiles);
     if (tile < 0) return;  // padding workgroup (before any barrier)
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int qx0 = tile_x * GGR_TILE + (wave & 1) * 8, qy0 = tile_y * GGR_TILE + (wave >> 1) * 8;
@@ -89,6 +95,19 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const float rx1 = (float)min(qx0 + 7, W - 1), ry1 = (float)min(qy0 + 7, H - 1);
 
     const uint2 range = ranges[tile];
+    // entries [0, top) are replayed: nothing behind the tile's last contributor (left by the forward) can matter
+    const int top = (int)min(tile_top[tile], range.y - range.x);
+    // ---- depth segment [seg_lo, seg_hi) of the replayed entries ---------------------------------------------------
+    // One segment = the whole list unless the forward left checkpoints (ggr_common.h, ImageLayout).  Then segment
+    // s is checkpoint interval s of this tile's list; the workgroups of intervals behind `top` leave here, having
+    // read two words.
+    int seg_lo = 0, seg_hi = top, stride = 0;
+    if (segments > 1) {
+        stride = ckpt_stride((int)(range.y - range.x), ckpt_slots, ntiles);
+        seg_lo = seg * stride;
+        seg_hi = min(top, seg_lo + stride);
+    }
+    if (seg_lo >= seg_hi) return;  // (block-uniform, before any barrier)
     const size_t hw = (size_t)H * W;
     const size_t pid = inside ? (size_t)py * W + px : 0;
 
@@ -102,17 +121,24 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
-    // wave / block maxima of `last`: nothing behind them can matter
+    // wave maximum of `last`: nothing behind it can matter to this quadrant
     uint32_t wl = last;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, off));
-    if (lane == 0) wave_last_sh[wave] = wl;
-    __syncthreads();
-    const uint32_t block_last = max(max(wave_last_sh[0], wave_last_sh[1]), max(wave_last_sh[2], wave_last_sh[3]));
-    const int top = (int)min(block_last, range.y - range.x);  // entries [0, top) are replayed
 
     float T = T_final;
     float R = T_final * bg_dot;  // everything behind the current entry, dotted with dL/dpixel (see the slot body)
+
+    // A pixel whose list goes on behind this segment starts from the forward's checkpoint there: T as the forward
+    // had it, and R = (final sums − checkpoint sums)·dL/dpixel + T_final·(bg·dL/dpixel) — the same "everything
+    // behind" that the single-segment replay accumulates entry by entry.
+    if (seg_hi < top && last > (uint32_t)seg_hi) {
+        const float* ck = ckpt + (size_t)(seg_hi / stride) * GGR_CKPT_FLOATS * hw + pid;
+        const float* fin = ckpt + pid;
+        T = ck[0];
+        R += (fin[hw] - ck[hw]) * dp0 + (fin[2 * hw] - ck[2 * hw]) * dp1 + (fin[3 * hw] - ck[3 * hw]) * dp2;
+        if (HAS_DEPTH) R += (fin[4 * hw] - ck[4 * hw]) * dpz;
+    }
 
     // which of the 9 (10) values this lane commits: value index vi = lane & 7 for the first atomic
     // instruction; lanes with (lane & 7) == 0 also commit value 8 (opacity) and 9 (depth) afterwards
@@ -120,12 +146,12 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const int my_slot = lane >> 3;
 
     // the list ids of a batch are requested one batch ahead (id → record is a chain of two global round trips)
-    uint32_t g_next = tid < top ? point_list[range.x + top - 1 - tid] : 0u;
-    for (int hi_ = top; hi_ > 0; hi_ -= BATCH) {
-        const int nb = min(BATCH, hi_);
+    uint32_t g_next = tid < seg_hi - seg_lo ? point_list[range.x + seg_hi - 1 - tid] : 0u;
+    for (int hi_ = seg_hi; hi_ > seg_lo; hi_ -= BATCH) {
+        const int nb = min(BATCH, hi_ - seg_lo);
         __syncthreads();
         const uint32_t g = g_next;
-        if (hi_ - BATCH - 1 - tid >= 0) g_next = point_list[range.x + hi_ - BATCH - 1 - tid];
+        if (hi_ - BATCH - 1 - tid >= seg_lo) g_next = point_list[range.x + hi_ - BATCH - 1 - tid];
         if (tid < nb) {
             const float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1];
             float4 c = splat[3 * (size_t)g + 2];
@@ -270,15 +296,20 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, const float* final_T, const uint32_t* n_contrib,
-                      const float* dL_dpix, const float* dL_ddepth, float* grad2d, hipStream_t s) {
+                      const float* dL_dpix, const float* dL_ddepth, float* grad2d, const uint32_t* tile_top,
+                      const float* ckpt, int ckpt_slots, int segments, hipStream_t s) {
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
     if (gx * gy == 0) return;
+    // one workgroup per (checkpoint interval, tile): `segments` == the forward's slot count, or 1 without checkpoints
+    segments = (ckpt && ckpt_slots >= 2) ? ckpt_slots : 1;
     if (dL_ddepth)
-        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(xcd_grid(gx * gy)), dim3(256), 0, s, W, H, gx, ranges, point_list,
-                           splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d);
+        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(xcd_grid(gx * gy) * segments), dim3(256), 0, s, W, H, gx, ranges,
+                           point_list, splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d, tile_top, ckpt,
+                           ckpt_slots, segments);
     else
-        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(xcd_grid(gx * gy)), dim3(256), 0, s, W, H, gx, ranges, point_list,
-                           splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d);
+        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(xcd_grid(gx * gy) * segments), dim3(256), 0, s, W, H, gx, ranges,
+                           point_list, splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d, tile_top, ckpt,
+                           ckpt_slots, segments);
 }
 
 }  // namespace ggr

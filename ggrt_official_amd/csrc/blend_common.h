@@ -14,7 +14,15 @@ __device__ __forceinline__ int xcd_tile(int block, int tiles) {
     const int t = (block & 7) * per + (block >> 3);
     return t < min((block & 7) * per + per, tiles) ? t : -1;
 }
-static inline int xcd_grid(int tiles) { return ((tiles + 7) >> 3) * 8; }
+__host__ __device__ static inline int xcd_grid(int tiles) { return ((tiles + 7) >> 3) * 8; }
+
+// Checkpoints (ggr_common.h, ImageLayout): list positions between two checkpoints of a tile whose list has `len`
+// entries — a multiple of the staging batch, large enough that slots 1 … slots−1 cover the whole list.
+// Images with ≥ 1024 tiles already bring ≥ 4 waves per SIMD: there a segment is at least two batches, so that
+// short lists are not cut into pieces that mostly pay the workgroup prologue.
+__device__ __forceinline__ int ckpt_stride(int len, int slots, int ntiles) {
+    return GGR_BATCH * max(ntiles >= 1024 ? 2 : 1, (len + slots * GGR_BATCH - 1) / (slots * GGR_BATCH));
+}
 
 // One staged list entry in LDS: 3 × 16 B, read back as wave-uniform (broadcast) ds_read_b128.
 struct __attribute__((aligned(16))) StagedSplat {

@@ -25,9 +25,11 @@ __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
                  const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
-                 uint32_t* __restrict__ n_contrib, float* __restrict__ out_depth) {
+                 uint32_t* __restrict__ n_contrib, float* __restrict__ out_depth, float* __restrict__ ckpt,
+                 int ckpt_slots, uint32_t* __restrict__ tile_top) {
     __shared__ StagedSplat stage[BATCH];
     __shared__ int wave_done[4];
+    __shared__ uint32_t wave_last[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_tile((int)blockIdx.x, grid_x * ((H + GGR_TILE - 1) / GGR_TILE));
@@ -44,6 +46,12 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
+    // images with few tiles: per-pixel checkpoints every `ck_every` list positions let the backward replay the
+    // list in independent depth segments (ggr_common.h, ImageLayout).  A pixel that is done keeps its final
+    // state, which is all the backward can ask of it (it never looks behind a pixel's last contributor).
+    const size_t hw = (size_t)H * W;
+    const size_t pid = inside ? (size_t)py * W + px : 0;
+    const int ck_every = ckpt ? ckpt_stride(total, ckpt_slots, grid_x * ((H + GGR_TILE - 1) / GGR_TILE)) : 0;
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
     uint32_t last = 0;
@@ -67,6 +75,10 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             stage[tid].c = c;
         }
         __syncthreads();
+        if (ckpt && b0 > 0 && b0 % ck_every == 0 && !wdone && inside) {
+            float* ck = ckpt + (size_t)(b0 / ck_every) * GGR_CKPT_FLOATS * hw + pid;
+            ck[0] = T; ck[hw] = C0; ck[2 * hw] = C1; ck[3 * hw] = C2; ck[4 * hw] = Dz;
+        }
         if (!wdone) {
             for (int s0 = 0; s0 < nb; s0 += 64) {
                 // lane-per-entry cull against this wave's quadrant
@@ -120,9 +132,18 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             if (wdone && lane == 0) wave_done[wave] = 1;
         }
     }
+    // the tile's last contributor: the backward replays the list entries before it (and nothing else)
+    uint32_t wl = last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, off));
+    if (lane == 0) wave_last[wave] = wl;
+    __syncthreads();
+    if (tid == 0) tile_top[tile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
     if (inside) {
-        const size_t pid = (size_t)py * W + px;
-        const size_t hw = (size_t)H * W;
+        if (ckpt) {  // slot 0: the final sums (what lies behind a checkpoint = final − checkpoint)
+            float* ck = ckpt + pid;
+            ck[hw] = C0; ck[2 * hw] = C1; ck[3 * hw] = C2; ck[4 * hw] = Dz;
+        }
         final_T[pid] = T;
         n_contrib[pid] = last;
         out_color[pid] = C0 + T * bg[0];
@@ -134,11 +155,11 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
-                      float* out_depth, hipStream_t s) {
+                      float* out_depth, float* ckpt, int ckpt_slots, uint32_t* tile_top, hipStream_t s) {
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
     if (gx * gy == 0) return;
     hipLaunchKernelGGL(blend_fwd_kernel, dim3(xcd_grid(gx * gy)), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg,
-                       out_color, final_T, n_contrib, out_depth);
+                       out_color, final_T, n_contrib, out_depth, ckpt, ckpt_slots, tile_top);
 }
 
 }  // namespace ggr

@@ -19,7 +19,8 @@
 //   binning buffer (kept for backward)
 //     point_list[N] u32: Gaussian ids, tile by tile, each tile's run in (depth, id) order
 //   image buffer  (kept for backward)
-//     ranges[tiles] (uint2), final_T[H·W] f32, n_contrib[H·W] u32
+//     ranges[tiles] (uint2), final_T[H·W] f32, n_contrib[H·W] u32, tile_top[tiles] u32,
+//     ckpt[16][5][H·W] f32 (images below 4096 tiles only: per-pixel checkpoints for the segmented backward)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -91,10 +92,28 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P) {
 
 static inline size_t ggr_point_list_bytes(size_t N) { return ggr_align((N ? N : 1) * 4); }
 
+// Depth segments of the blend backward (blend_bwd.hip).  An image with few tiles cannot fill 256 CUs with one
+// workgroup per tile (480×352 = 660 tiles = 2.6 waves per SIMD: the backward ran at half the per-entry rate of
+// a 1080p frame), so there the forward leaves per-pixel CHECKPOINTS (T, Σw·c, Σw·z) at up to `slots − 1` list
+// positions per tile (every `ckpt_stride` entries, blend_common.h) and the backward replays each interval in
+// its own workgroup.  The slot count is a function of the image size only (the image-state buffer is sized
+// before anything runs): 16 below 4096 tiles (320 B per pixel, ≤ 0.34 GB), none from there on — a 1080p frame
+// fills the chip as it is (measured: 16 slots at 8160 tiles, 0.44 → 0.48 ms).
+// Blend backward, no checkpoints → 16 slots:  480×352, 1.01 M pixel-aligned Gaussians 0.434 → 0.271 ms;
+// 960×640, 4.9 M: 1.03 → 0.86 ms; 256×256, 10 k: 0.050 → 0.038 ms.  Forward cost of writing them: < 1 %.
+static inline int ggr_ckpt_slots(size_t tiles) {  // slot 0 holds the final sums; 0 = no checkpoints
+    return (tiles == 0 || tiles >= 4096) ? 0 : 16;
+}
+static inline int ggr_bwd_segments(size_t tiles) { const int k = ggr_ckpt_slots(tiles); return k ? k : 1; }
+#define GGR_CKPT_FLOATS 5  // T, Σw·r, Σw·g, Σw·b, Σw·z — each a [H·W] plane: ckpt[(slot·5 + v)·H·W + pixel]
+
 struct ImageLayout {
     uint2* ranges;
     float* final_T;
     uint32_t* n_contrib;
+    uint32_t* tile_top;  // [tiles]: max n_contrib of the tile = list entries the backward replays
+    float* ckpt;         // [slots][5][H·W] or null
+    int ckpt_slots, bwd_segments;
     size_t bytes;
 };
 
@@ -108,6 +127,10 @@ static inline ImageLayout ggr_carve_image(void* base, int W, int H) {
     L.ranges = (uint2*)take(tiles * 8);
     L.final_T = (float*)take(pix * 4);
     L.n_contrib = (uint32_t*)take(pix * 4);
+    L.tile_top = (uint32_t*)take(tiles * 4);
+    L.ckpt_slots = ggr_ckpt_slots(tiles);
+    L.bwd_segments = ggr_bwd_segments(tiles);
+    L.ckpt = L.ckpt_slots ? (float*)take((size_t)L.ckpt_slots * GGR_CKPT_FLOATS * pix * 4) : nullptr;
     L.bytes = o;
     return L;
 }
@@ -199,11 +222,12 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
-                      float* out_depth, hipStream_t s);
+                      float* out_depth, float* ckpt /*or null*/, int ckpt_slots, uint32_t* tile_top, hipStream_t s);
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, const float* final_T, const uint32_t* n_contrib,
                       const float* dL_dpix, const float* dL_ddepth /*or null*/, float* grad2d /*[P][16], zeroed*/,
+                      const uint32_t* tile_top, const float* ckpt /*or null*/, int ckpt_slots, int segments,
                       hipStream_t s);
 
 void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs,
