@@ -262,7 +262,7 @@ def main():
         # WRITE_SIZE in separate passes, FETCH ×2 per the gfx950 correction — scripts/profile_bench.sh,
         # scripts/pmc_summary.py); only valid for the configuration it was collected on (C3)
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_v14_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_v15_pmc_traffic.json")
         if args.config == "C3" and os.path.exists(pmc_path):
             kname = {"bwd_blend": "blend_bwd_kernel", "fwd_blend": "blend_fwd_kernel",
                      "fwd_preprocess": "preprocess_fwd_kernel", "bwd_preprocess": "preprocess_bwd_kernel"}[dom]
