@@ -269,6 +269,15 @@ def main():
             for k, v in json.load(open(pmc_path)).items():
                 if kname in k:
                     traffic = int(v["hbm_bytes_per_launch"])
+        # measured VALU issue occupancy of the two blend kernels (SQ_ACTIVE_INST_VALU ÷ SIMD quad-cycles of the
+        # launch, rocprofv3 PMC passes of this command at C3 — profiles/r01_v15_pmc_sq.json): the bound that matters
+        valu_busy = {}
+        sq_path = os.path.join(ROOT, "profiles", "r01_v15_pmc_sq.json")
+        if args.config == "C3" and os.path.exists(sq_path):
+            for k, v in json.load(open(sq_path)).items():
+                for short, kn in (("fwd", "blend_fwd_kernel"), ("bwd", "blend_bwd_kernel")):
+                    if kn in k:
+                        valu_busy[short] = v["valu_busy_frac_at_2p4GHz"]
         rec = {
             "metric": "Gaussian raster fwd+bwd Mpix/s @1M Gaussians 1080p",
             "value": round(world * W * H * args.steps / elapsed / 1e6, 3),
@@ -296,7 +305,7 @@ def main():
             # that backward.  The exact quadrant cull skips most of those evaluations, so the "algorithmic"
             # rate may exceed the 157.3 TFLOP/s peak — that excess is the cull, not a faster ALU.
             "blend_valu_roofline": {
-                "peak_tflops": 157.3,
+                "peak_tflops": 157.3, "valu_busy_frac_pmc": valu_busy or None,
                 "fwd": {"algorithmic_flops": 20 * N * 256, "tflops": round(20 * N * 256 / (kernel_ms["fwd_blend"] * 1e-3) / 1e12, 1)},
                 "bwd": {"algorithmic_flops": 50 * N * 256, "tflops": round(50 * N * 256 / (kernel_ms["bwd_blend"] * 1e-3) / 1e12, 1)},
             },

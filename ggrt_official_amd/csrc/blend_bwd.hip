@@ -153,8 +153,9 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         const uint32_t g = g_next;
         if (hi_ - BATCH - 1 - tid >= seg_lo) g_next = point_list[range.x + hi_ - BATCH - 1 - tid];
         if (tid < nb) {
-            const float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1];
+            float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1];
             float4 c = splat[3 * (size_t)g + 2];
+            stage_scale_conic(a, b, c);  // (blend_common.h: the pixel loop works on k·q, k = log2(e)/2)
             c.w = __uint_as_float(g);
             stage[tid].a = a;
             stage[tid].b = b;
@@ -174,7 +175,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             if (e < nb && (uint32_t)(hi_ - 1 - e) < wl) {
                 const float4 a = stage[e].a;
                 const float4 b = stage[e].b;
-                keep = box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
+                keep = staged_box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
             }
             const uint64_t mk = __ballot(keep);
             if (keep) my_surv[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)e;
@@ -216,11 +217,10 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                         const float4 a = stage[e2].a;
                         const float4 b = stage[e2].b;
                         const float4 c = stage[e2].c;
-                        const float dx = a.x - pixx, dy = a.y - pixy;
-                        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                        const float G = __expf(power);
+                        const float q2 = staged_q2(a, b, a.x - pixx, a.y - pixy);  // = −power·log2(e)
+                        const float G = __builtin_amdgcn_exp2f(-q2);
                         const float alpha_raw = fminf(GGR_ALPHA_MAX, b.y * G);
-                        const bool valid = ok_sl[sl] && idx < last && power <= 0.0f && alpha_raw >= GGR_ALPHA_MIN;
+                        const bool valid = ok_sl[sl] && idx < last && q2 >= 0.0f && alpha_raw >= GGR_ALPHA_MIN;
                         const float alpha = valid ? alpha_raw : 0.f;
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32 (1 ulp); __frcp_rn would expand to a 10-instruction IEEE division
                         T = T * inv;
@@ -276,8 +276,9 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                         case 0: val = t_r; break;
                         case 1: val = t_g; break;
                         case 2: val = t_b; break;
-                        case 3: val = -op * (a.z * Sx + a.w * Sy) * ddelx_dx; break;
-                        case 4: val = -op * (b.x * Sy + a.w * Sx) * ddely_dy; break;
+                        // (the staged conic is k·cxx, 2k·cxy, k·cyy: back to the plain one with 1/k)
+                        case 3: val = -op * GGR_INV_KQ * (a.z * Sx + 0.5f * a.w * Sy) * ddelx_dx; break;
+                        case 4: val = -op * GGR_INV_KQ * (b.x * Sy + 0.5f * a.w * Sx) * ddely_dy; break;
                         case 5: val = -0.5f * op * (ox * (Sx - Mx) + Mxx); break;
                         case 6: val = -0.5f * op * (ox * Sy - oy * Mx + Mxy); break;
                         default: val = -0.5f * op * (oy * (Sy - My) + Myy); break;

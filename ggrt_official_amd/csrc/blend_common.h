@@ -58,4 +58,29 @@ __device__ __forceinline__ bool box_may_contribute(const float4 a, const float4 
     return qmin * 0.999f <= qmax + 1e-3f;
 }
 
+// ---- staged form of the conic ---------------------------------------------------------------------------------
+// The blend kernels evaluate G = exp(−q/2), q = cxx·dx² + 2·cxy·dx·dy + cyy·dy², once per (entry, pixel).  The
+// thread that stages an entry pre-multiplies the conic by k = log2(e)/2, so that the pixel loop needs
+//     u = fma(sxx, dx, sxy2·dy);  q2 = fma(syy·dy, dy, u·dx);  G = v_exp_f32(−q2)          (5 ops + exp)
+// instead of the reference's −½(cxx·dx² + cyy·dy²) − cxy·dx·dy followed by the ·log2(e) of expf (8 ops + exp).
+// `power > 0` (reference: skip) ⇔ q2 < 0.  The record in HBM keeps the plain conic (bit-exact with the oracle).
+#define GGR_KQ 0.72134752f         // log2(e) / 2
+#define GGR_INV_KQ 1.38629436f     // 2·ln 2
+__device__ __forceinline__ void stage_scale_conic(float4& a, float4& b, float4& c) {
+    a.z *= GGR_KQ;          // sxx  = k·cxx
+    a.w *= 2.f * GGR_KQ;    // sxy2 = 2k·cxy
+    b.x *= GGR_KQ;          // syy  = k·cyy
+    c.z *= GGR_KQ;          // k·qmax
+}
+__device__ __forceinline__ float staged_q2(const float4 a, const float4 b, float dx, float dy) {
+    const float u = fmaf(a.z, dx, a.w * dy);
+    return fmaf(b.x * dy, dy, u * dx);
+}
+// box_may_contribute on a staged entry (the test is homogeneous in the conic, so it runs on k·q directly)
+__device__ __forceinline__ bool staged_box_may_contribute(const float4 a, const float4 b, float kqmax, float x0,
+                                                          float y0, float x1, float y1) {
+    const float qmin = box_min_q(a.x, a.y, a.z, 0.5f * a.w, b.x, x0, y0, x1, y1);
+    return qmin * 0.999f <= kqmax + 1e-3f;
+}
+
 }  // namespace ggr

@@ -69,7 +69,8 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         const uint32_t g = g_next;
         if (b0 + BATCH + tid < total) g_next = point_list[range.x + b0 + BATCH + tid];
         if (tid < nb) {
-            const float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1], c = splat[3 * (size_t)g + 2];
+            float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1], c = splat[3 * (size_t)g + 2];
+            stage_scale_conic(a, b, c);  // (blend_common.h: the pixel loop works on k·q, k = log2(e)/2)
             stage[tid].a = a;
             stage[tid].b = b;
             stage[tid].c = c;
@@ -87,7 +88,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 if (e < nb) {
                     const float4 a = stage[e].a;
                     const float4 b = stage[e].b;
-                    keep = box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
+                    keep = staged_box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
                 }
                 uint64_t m = __ballot(keep);
                 while (m) {
@@ -103,24 +104,23 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                         e4[u] = s0 + (has[u] ? __builtin_ctzll(m) : 0);
                         m &= m - 1;  // (0 stays 0)
                     }
-                    float alpha[U], power[U];
+                    float alpha[U], q2[U];
                     float4 rb[U], rc[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         const float4 a = stage[e4[u]].a;
                         rb[u] = stage[e4[u]].b;
                         rc[u] = stage[e4[u]].c;
-                        const float dx = a.x - pixx, dy = a.y - pixy;
-                        power[u] = -0.5f * (a.z * dx * dx + rb[u].x * dy * dy) - a.w * dx * dy;
-                        alpha[u] = fminf(GGR_ALPHA_MAX, rb[u].y * __expf(power[u]));
+                        q2[u] = staged_q2(a, rb[u], a.x - pixx, a.y - pixy);  // = −power·log2(e)
+                        alpha[u] = fminf(GGR_ALPHA_MAX, rb[u].y * __builtin_amdgcn_exp2f(-q2[u]));
                     }
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        bool ok = has[u] && !done && power[u] <= 0.0f && alpha[u] >= GGR_ALPHA_MIN;
-                        const float test_T = T * (1.f - alpha[u]);
+                        bool ok = has[u] && !done && q2[u] >= 0.0f && alpha[u] >= GGR_ALPHA_MIN;
+                        const float w = alpha[u] * T;
+                        const float test_T = T - w;  // T·(1−α)
                         if (ok && test_T < GGR_T_MIN) { done = true; ok = false; }
                         if (ok) {
-                            const float w = alpha[u] * T;
                             C0 += rb[u].z * w; C1 += rb[u].w * w; C2 += rc[u].x * w; Dz += rc[u].y * w;
                             T = test_T;
                             last = (uint32_t)(b0 + e4[u] + 1);
