@@ -98,7 +98,9 @@ typedef struct GgrForwardOut {
     float* out_depth;      /* [H,W]  Σ f·α·T with f = view z (or aux_precomp): third value of the 3-tuple
                               unpacked at :118; may be NULL */
     void* geom_buffer;     /* ggr_geom_bytes(P) bytes, caller-allocated, kept for backward */
-    void* image_buffer;    /* ggr_image_bytes(W,H) bytes, caller-allocated, kept for backward */
+    void* image_buffer;    /* ggr_image_bytes(W,H) bytes, caller-allocated, kept for backward: tile ranges,
+                              final T, contributor counts and — for images below 4096 tiles — the forward's
+                              per-pixel checkpoints for the segmented backward (320 B per pixel) */
     void* binning_buffer;  /* OUT: what the allocator returned (kept by the caller for backward).
                               IN (sync-free mode): the caller's own list buffer, see binning_capacity */
     int64_t num_rendered;  /* OUT: Σ tiles touched = length of the sorted (tile, Gaussian) list; -1 in sync-free mode */
