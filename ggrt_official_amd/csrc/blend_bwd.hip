@@ -28,7 +28,10 @@ namespace ggr {
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    // every lane has a source under these controls (rotations / permutations inside a row), so `old` is never
+    // used: passing the value itself with bound_ctrl lets the compiler fold the move into the consuming
+    // v_add_f32_dpp instead of materialising a zero and a v_mov_b32_dpp (12 of 33 per batch did not fold)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
 // Transposing reduction of v[0..7] over the 8 pixel ROWS of the quadrant (lane = 8·row + column).  Returns,
@@ -60,6 +63,9 @@ __device__ __forceinline__ float sum_cols8(float s) {
     s += dpp_mov<0xB1>(s);   // quad_perm [1,0,3,2]
     s += dpp_mov<0x4E>(s);   // quad_perm [2,3,0,1]
     s += dpp_mov<0x141>(s);  // row_half_mirror
+    // keep this add where it is: sunk into the commit branch it can no longer fold with its DPP move (a DPP read
+    // cannot move under a narrower exec mask), which left 9 v_mov_b32_dpp + 9 v_add per batch instead of 9 v_add_dpp
+    asm volatile("" : "+v"(s));
     return s;
 }
 
