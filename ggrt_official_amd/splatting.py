@@ -357,7 +357,10 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
                                            aux_precomp=aux, **kw)
         colors.append(out[0])
         depths.append(out[2])
-    return torch.stack(colors), (torch.stack(depths) if depth_mode is not None else None)
+    # one view (GGRt's usual call): a view of the rasterizer's output instead of a stack — no copy kernel forward,
+    # none backward
+    stack = lambda ts: ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)
+    return stack(colors), (stack(depths) if depth_mode is not None else None)
 
 
 class DecoderSplattingCUDA(nn.Module):
