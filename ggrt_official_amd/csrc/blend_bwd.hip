@@ -267,17 +267,25 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 const float Myy = sum_cols8(transpose_rows8(g_myy, lane));
                 float t_z = 0.f;
                 if (HAS_DEPTH) t_z = sum_cols8(transpose_rows8(g_z, lane));
-                // ---- commit: lane (slot, vi) finishes and adds value vi of its slot ---------------------
-                if (my_e >= 0) {
-                    const float4 a = stage[my_e].a;
-                    const float4 b = stage[my_e].b;
-                    const size_t g = __float_as_uint(stage[my_e].c.w);
+                // ---- commit: lane (slot, vi) finishes value vi of its slot ---------------------------------
+                // A slot has 9 (10) values but only 8 lanes.  Sending values 8, 9 in a second instruction of their
+                // own made two 64-B line transactions per slot; instead the 8-lane groups of an even and an odd
+                // slot (the two halves of a 16-lane row) help each other: instruction A carries the even slots'
+                // values 0–7 from their own lanes and their values 8, 9 from lanes 0, 1 of the odd neighbour
+                // group (fetched with one row_ror:8 move each), instruction B the odd slots' — every slot's values
+                // leave in ONE instruction, one line transaction per slot, still two atomic instructions per batch.
+                float val = 0.f;
+                uint32_t gid = 0u;
+                {
+                    const int e = max(my_e, 0);
+                    const float4 a = stage[e].a;
+                    const float4 b = stage[e].b;
+                    gid = __float_as_uint(stage[e].c.w);
                     const float op = b.y;
                     // shift the moments from the quadrant centre to the Gaussian's mean: d = mean − pixel = o − p',
                     // o = mean − quadrant centre, p' the centred pixel coordinates
                     const float ox = a.x - qcx, oy = a.y - qcy;
                     const float Sx = ox * S0 - Mx, Sy = oy * S0 - My;
-                    float val;
                     switch (vi) {
                         case 0: val = t_r; break;
                         case 1: val = t_g; break;
@@ -289,14 +297,29 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                         case 6: val = -0.5f * op * (ox * Sy - oy * Mx + Mxy); break;
                         default: val = -0.5f * op * (oy * (Sy - My) + Myy); break;
                     }
-                    float* rec = grad2d + GGR_G2D_STRIDE * g;  // all of a slot's atomics land in one 64-B line
-                    if (val != 0.f) atomicAdd(rec + vi, val);
-                    // values 8 (opacity) and 9 (depth) go out in ONE more vector atomic, from lanes vi = 0 and 1: a
-                    // third instruction — a third line transaction per slot — cost the depth variant 45 %
-                    // (C3: 0.44 → 0.645 ms; the atomics are cheap only as long as there are two per slot)
-                    static_assert(GGR_G2D_Z == GGR_G2D_OPACITY + 1, "opacity and depth are committed as one pair");
-                    const float v2 = (HAS_DEPTH && vi == 1) ? t_z : S0;
-                    if (vi < (HAS_DEPTH ? 2 : 1) && v2 != 0.f) atomicAdd(rec + GGR_G2D_OPACITY + vi, v2);
+                }
+                if (my_e < 0) val = 0.f;
+                // (a third atomic instruction — a third line transaction per slot — once cost the depth variant 45 %:
+                //  C3 0.44 → 0.645 ms; the atomics are cheap only while there are few line transactions per slot)
+                static_assert(GGR_G2D_Z == GGR_G2D_OPACITY + 1, "opacity and depth are committed as one pair");
+                constexpr int NPAIR = HAS_DEPTH ? 2 : 1;
+                const float pair_own = my_e < 0 ? 0.f : ((HAS_DEPTH && vi == 1) ? t_z : S0);
+                // the other half of the 16-lane row: its slot's pair value (same vi) and record
+                const float pair_nb = dpp_mov<0x128>(pair_own);
+                const uint32_t gid_nb = __float_as_uint(dpp_mov<0x128>(__uint_as_float(gid)));
+                const bool odd = (my_slot & 1) != 0;
+                float* const rec_own = grad2d + GGR_G2D_STRIDE * (size_t)gid;
+                float* const rec_nb = grad2d + GGR_G2D_STRIDE * (size_t)gid_nb;
+                const bool help = vi < NPAIR && pair_nb != 0.f;  // (an empty neighbour slot has pair value 0)
+                {   // instruction A: the even slots' records
+                    float* const p = odd ? rec_nb + GGR_G2D_OPACITY + vi : rec_own + vi;
+                    const float v = odd ? pair_nb : val;
+                    if (odd ? help : v != 0.f) atomicAdd(p, v);
+                }
+                {   // instruction B: the odd slots' records
+                    float* const p = odd ? rec_own + vi : rec_nb + GGR_G2D_OPACITY + vi;
+                    const float v = odd ? val : pair_nb;
+                    if (odd ? v != 0.f : help) atomicAdd(p, v);
                 }
             }
         }
