@@ -262,7 +262,7 @@ def main():
         # WRITE_SIZE in separate passes, FETCH ×2 per the gfx950 correction — scripts/profile_bench.sh,
         # scripts/pmc_summary.py); only valid for the configuration it was collected on (C3)
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_v15_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_v16_pmc_traffic.json")
         if args.config == "C3" and os.path.exists(pmc_path):
             kname = {"bwd_blend": "blend_bwd_kernel", "fwd_blend": "blend_fwd_kernel",
                      "fwd_preprocess": "preprocess_fwd_kernel", "bwd_preprocess": "preprocess_bwd_kernel"}[dom]
@@ -270,9 +270,9 @@ def main():
                 if kname in k:
                     traffic = int(v["hbm_bytes_per_launch"])
         # measured VALU issue occupancy of the two blend kernels (SQ_ACTIVE_INST_VALU ÷ SIMD quad-cycles of the
-        # launch, rocprofv3 PMC passes of this command at C3 — profiles/r01_v15_pmc_sq.json): the bound that matters
+        # launch, rocprofv3 PMC passes of this command at C3 — profiles/r01_v16_pmc_sq.json): the bound that matters
         valu_busy = {}
-        sq_path = os.path.join(ROOT, "profiles", "r01_v15_pmc_sq.json")
+        sq_path = os.path.join(ROOT, "profiles", "r01_v16_pmc_sq.json")
         if args.config == "C3" and os.path.exists(sq_path):
             for k, v in json.load(open(sq_path)).items():
                 for short, kn in (("fwd", "blend_fwd_kernel"), ("bwd", "blend_bwd_kernel")):
