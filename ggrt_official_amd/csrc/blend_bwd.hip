@@ -8,14 +8,16 @@
 // address.  Here each wave64 owns an 8×8 pixel quadrant of the tile and
 //   * drops, wave-wide, every list entry that cannot reach α ≥ 1/255 anywhere in its quadrant (exact
 //     ellipse-vs-box test, lane-per-entry + ballot) or that lies behind every pixel's last contributor;
-//   * processes the survivors in batches of 8: the 9 per-pixel partial sums of the 8 entries (72
-//     registers) are reduced across the 64 lanes with a TRANSPOSING tree — v_permlane32_swap,
-//     v_permlane16_swap, then DPP row_ror:8 / row_half_mirror / quad_perm adds — that costs ≈2.3
-//     VALU ops per (entry, value) instead of 12 for nine independent butterflies;
-//   * ends with lane l holding the wave total of value (l & 7 | 8) of batch slot l >> 3, so the whole
-//     batch is committed with two vector atomic instructions (72 atomics, 64 + 8 lanes) — into ONE 64-byte
-//     record per Gaussian (ggr_common.h GGR_G2D_*): with the nine values spread over four arrays the kernel
-//     was bound by atomic cache-line transactions (C3: 0.89 ms → 0.56 ms with the packed record).
+//   * processes the survivors in batches of 8: per (entry, pixel) only Σw·dL/dc (3), Σm, Σm·y′, Σm·y′² are formed
+//     (moments about the quadrant centre, SEPARABLE in the lane's pixel coordinates); these six arrays of 8
+//     values are reduced over the 8 pixel rows with a TRANSPOSING tree — v_permlane32_swap, v_permlane16_swap,
+//     DPP row_ror:8 — the x-moments are products of the column sums with the lane's x′, and three DPP
+//     butterflies over the 8 columns finish the nine (ten) totals of a slot in all 8 lanes of its group;
+//   * commits a batch with two vector atomic instructions into ONE 64-byte record per Gaussian
+//     (ggr_common.h GGR_G2D_*), every slot's values in ONE of the two — one line transaction per slot: the
+//     device sustains only ≈ 20 G atomic line transactions/s (tools/atomic_line_bench.hip), and with the values
+//     spread over four arrays (0.89 ms at C3), or with a second / third instruction per slot, the kernel was
+//     bound by that, not by arithmetic.
 // Tried and rejected (round 1, measured): taking the nine sums on the idle MATRIX pipe instead — two
 // v_mfma_f32_16x16x4_f32 stages with polynomial pixel weights, layout pinned by tools/mfma_reduce_test.hip —
 // is exact but slower (0.70 ms vs 0.56 ms): 6 dependent MFMAs per entry serialise the wave.
