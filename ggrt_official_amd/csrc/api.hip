@@ -183,12 +183,18 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     ReadbackSlot* rb = (!sync_free && P > 0) ? readback_slot() : nullptr;
     if (P > 0) {
         ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, capacity, s,
-                                    /*rects_gathered=*/true, rb ? rb->host : nullptr, rb ? rb->ev : nullptr);
+                                    /*rects_gathered=*/true, rb ? rb->host : nullptr, rb ? rb->ev : nullptr,
+                                    ggr::radix_sort_fault_word(g.hist));
     } else {
         HIP_TRY(hipMemsetAsync(im.ranges, 0, (tiles ? tiles : 1) * sizeof(uint2), s));
         HIP_TRY(hipMemsetAsync(g.counters, 0, 8, s));
     }
     KCHECK(dbg, s, "tile_list_count");
+    if (dbg && sync_free && P > 0) {  // debug mode may sync: check the sort's fault bit right here
+        uint32_t two[2] = {0u, 0u};
+        HIP_TRY(hipMemcpy(two, g.counters, 8, hipMemcpyDeviceToHost));
+        if (two[1] & 2u) return fail(GGR_E_HIP, "depth sort: a look-back spin hit its bound; frame not rendered");
+    }
     uint32_t num_rendered = 0;
     uint32_t* point_list = nullptr;
     if (!sync_free) {
@@ -196,9 +202,13 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
             HIP_TRY(hipEventSynchronize(rb->ev));  // the single host sync of forward
             num_rendered = *(volatile uint32_t*)rb->host;
         } else {
-            HIP_TRY(hipMemcpyAsync(&num_rendered, g.counters, 4, hipMemcpyDeviceToHost, s));
+            uint32_t two[2] = {0u, 0u};
+            HIP_TRY(hipMemcpyAsync(two, g.counters, 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            num_rendered = (two[1] & 2u) ? 0xFFFFFFFFu : two[0];
         }
+        if (num_rendered == 0xFFFFFFFFu)  // raised by the scan kernel, see bin_tile_scan_kernel
+            return fail(GGR_E_HIP, "depth sort: a look-back spin hit its bound (GPU preempted or halted?); frame not rendered");
         if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
         out->num_rendered = (int64_t)num_rendered;
         tm.mark();
@@ -308,7 +318,9 @@ int ggr_forward_status(const void* geom_buffer, int32_t P, int64_t* num_rendered
     HIP_TRY(hipMemcpyAsync(host, g.counters, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (num_rendered) *num_rendered = (int64_t)host[0];
-    if (overflow) *overflow = (int32_t)host[1];
+    if (overflow) *overflow = (int32_t)(host[1] & 1u);
+    if (host[1] & 2u)
+        return fail(GGR_E_HIP, "depth sort: a look-back spin hit its bound (GPU preempted or halted?); the frame is invalid");
     return GGR_OK;
 }
 

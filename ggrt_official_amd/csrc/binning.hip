@@ -230,6 +230,8 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     }
 }
 
+const uint32_t* radix_sort_fault_word(const uint32_t* hist) { return hist + GGR_HIST_TICKETS + 8; }
+
 size_t radix_hist_words(size_t n) { return GGR_HIST_STATUS + 4 * ggr_sort_blocks(n ? n : 1) * GGR_RADIX; }
 
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
@@ -262,15 +264,5 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
     *keys_out = kin;
     *vals_out = vin;
 }
-
-__global__ void iota_kernel(uint32_t* v, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = (uint32_t)i;
-}
-void launch_iota(uint32_t* v, size_t n, hipStream_t s) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n);
-}
-
 
 }  // namespace ggr

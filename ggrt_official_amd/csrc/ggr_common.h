@@ -196,8 +196,6 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
                       uint2* gather_dst = nullptr, uint32_t* zero_area = nullptr /*and clears these words*/,
                       uint32_t zero_words = 0);
 
-void launch_iota(uint32_t* v, size_t n, hipStream_t s);
-
 // tile-list builder (tile_lists.hip)
 struct TileListPlan {
     uint32_t nchunks, nbands, band_tiles, nsbands, sband_tiles, groups, chunks_per_group;
@@ -211,7 +209,11 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
                             hipStream_t s, bool rects_gathered = false /*the depth sort already filled rect_sorted
                             and cleared the per-tile totals (tile_list_gather_targets)*/,
                             uint32_t* host_total = nullptr /*pinned, device-visible: also receives N …*/,
-                            hipEvent_t after_scan = nullptr /*… and this event is recorded right behind the scan*/);
+                            hipEvent_t after_scan = nullptr /*… and this event is recorded right behind the scan*/,
+                            const uint32_t* sort_fault = nullptr /*device word the depth sort raises when a look-back
+                            spin hit its bound: folded into total_out[1] (bit 1) and host_total (~0u)*/);
+// the depth sort's fault word inside its work area (binning.hip)
+const uint32_t* radix_sort_fault_word(const uint32_t* hist);
 // where the depth sort's last pass should put the rects in depth order / which words it should clear
 void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint2** rect_sorted,
                               uint32_t** zero_area, uint32_t* zero_words);

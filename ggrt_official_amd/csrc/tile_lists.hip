@@ -160,7 +160,8 @@ __global__ void __launch_bounds__(1024)
 bin_tile_scan_kernel(uint32_t T, uint32_t* __restrict__ tile_start /*in: totals, out: starts*/,
                      uint2* __restrict__ ranges, uint32_t* __restrict__ total_out /*[0] = N, [1] = overflow*/,
                      uint32_t capacity /*entries the caller's list buffer holds (sync-free mode); ~0u = exact*/,
-                     uint32_t* __restrict__ host_total /*pinned host word that also receives N, or NULL*/) {
+                     uint32_t* __restrict__ host_total /*pinned host word that also receives N, or NULL*/,
+                     const uint32_t* __restrict__ sort_fault /*the depth sort's look-back timeout word, or NULL*/) {
     // each thread owns E CONSECUTIVE tiles (E = ⌈T/1024⌉ rounded up to a multiple of 8, ≤ 64 per slab): local
     // sums, ONE block-wide scan of the 1024 partials, then the running starts — instead of T/1024 sequential
     // 1024-wide scans (16 µs → a few µs at 8160 tiles)
@@ -206,10 +207,14 @@ bin_tile_scan_kernel(uint32_t T, uint32_t* __restrict__ tile_start /*in: totals,
         __syncthreads();
     }
     if (tid == 0) {
+        // a look-back spin of the depth sort that ran into its bound leaves a mis-sorted order behind: the frame
+        // must not be used.  Status word: bit 0 = list overflow, bit 1 = sort fault; the exact mode's host word
+        // carries ~0u instead of N (ggr_forward fails with GGR_E_HIP on it).
+        const bool fault = sort_fault && *sort_fault != 0u;
         total_out[0] = carry;
-        total_out[1] = carry > capacity ? 1u : 0u;
+        total_out[1] = (carry > capacity ? 1u : 0u) | (fault ? 2u : 0u);
         if (host_total) {
-            __hip_atomic_store(host_total, carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_total, fault ? 0xFFFFFFFFu : carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -455,7 +460,8 @@ void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint
 
 void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                             const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, uint32_t capacity,
-                            hipStream_t s, bool rects_gathered, uint32_t* host_total, hipEvent_t after_scan) {
+                            hipStream_t s, bool rects_gathered, uint32_t* host_total, hipEvent_t after_scan,
+                            const uint32_t* sort_fault) {
     const WorkArea w = carve_work(pl, work, T);
     if (T == 0 || P == 0) {
         (void)hipMemsetAsync(total_out, 0, 8, s);
@@ -472,7 +478,7 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
                        pl.chunks_per_group, w.gsum, w.tile_start);
     hipLaunchKernelGGL(bin_tile_scan_kernel, dim3(1), dim3(1024), 0, s, (uint32_t)T, w.tile_start, ranges, total_out,
-                       capacity, host_total);
+                       capacity, host_total, sort_fault);
     if (after_scan) (void)hipEventRecord(after_scan, s);
     hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
                        pl.chunks_per_group, w.gsum, w.tile_start);

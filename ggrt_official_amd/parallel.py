@@ -71,9 +71,14 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
 def allreduce_gradients(params: Iterable[torch.nn.Parameter]) -> None:
     """Flatten → one all-reduce → scatter back, for the modules that stay on stock PyTorch
     (encoder, pose network) and for the camera-pose gradients the rasterizer produces."""
-    ps: Sequence[torch.nn.Parameter] = [p for p in params if p.grad is not None]
+    ps: Sequence[torch.nn.Parameter] = [p for p in params if p.requires_grad]
     if not ps or not dist.is_initialized() or dist.get_world_size() == 1:
         return
+    # the SAME layout on every rank: a parameter that got no gradient on this rank (unused for this frame) counts
+    # as zeros — filtering on `p.grad is not None` would give ranks different message sizes (hang / mixed grads)
+    for p in ps:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
     flat = torch.cat([p.grad.reshape(-1) for p in ps])
     allreduce_mean_(flat)
     o = 0

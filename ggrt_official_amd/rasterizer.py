@@ -25,6 +25,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import threading
+import weakref
 from typing import NamedTuple, Optional
 
 import torch
@@ -208,7 +209,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 prof.fwd_calls += 1
             _check(lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream), "ggr_forward")
 
-        _tls.last_forward = (geom, P)
+        _tls.last_forward = (weakref.ref(geom), P)  # weak: the ≈100 MB geometry buffer lives as long as its graph
         ctx.raster_settings = rs
         ctx.num_rendered = int(fout.num_rendered)
         ctx.dims = (P, M, H, W)
@@ -321,7 +322,9 @@ def last_forward_status():
     last = getattr(_tls, "last_forward", None)
     if last is None:
         raise RuntimeError("no forward has run on this thread")
-    geom, P = last
+    geom, P = last[0](), last[1]
+    if geom is None:
+        raise RuntimeError("the most recent forward's buffers have been released (its autograd graph is gone)")
     lib = _lib.load()
     n, ov = C.c_int64(0), C.c_int32(0)
     with torch.cuda.device(geom.device):

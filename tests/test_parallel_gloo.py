@@ -39,10 +39,17 @@ def _worker(rank, world, port, out):
     for p in list(lin.parameters()) + [pose]:
         p.grad = torch.full_like(p, float(10 * (rank + 1)))
     parallel.allreduce_gradients(list(lin.parameters()) + [pose])
+    # 3b. a parameter that got no gradient on ONE rank (unused for that rank's frame) must not change the message
+    #     layout: it counts as zeros there (ranks would otherwise all-reduce different sizes)
+    extra = torch.nn.Parameter(torch.zeros(5))
+    if rank == 1:
+        extra.grad = torch.full_like(extra, 8.0)
+    parallel.allreduce_gradients([extra, pose])
     # 4. timing reduction used by bench.py
     t = parallel.max_over_ranks(0.5 + rank, "cpu")
     parallel.barrier()
-    out[rank] = dict(frames=mine, buf=float(buf[0]), grad=float(lin.weight.grad[0, 0]), pose=float(pose.grad[3, 3]), t=t)
+    out[rank] = dict(frames=mine, buf=float(buf[0]), grad=float(lin.weight.grad[0, 0]), pose=float(pose.grad[3, 3]), t=t,
+                     extra=float(extra.grad[2]))
     parallel.shutdown()
 
 
@@ -59,6 +66,7 @@ def test_two_rank_gloo():
         assert out[r]["buf"] == pytest.approx(1.5)
         assert out[r]["grad"] == pytest.approx(15.0) and out[r]["pose"] == pytest.approx(15.0)
         assert out[r]["t"] == pytest.approx(1.5)
+        assert out[r]["extra"] == pytest.approx(4.0)
 
 
 def test_single_process_is_a_noop():
