@@ -69,6 +69,8 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
     if (st->num_points > 0 && ((!has_sr && in->cov3D_precomp == nullptr) || (any_sr && in->cov3D_precomp != nullptr)))
         return fail(GGR_E_INVALID,
                     "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (st->sh_max_degree != 0 && st->sh_max_degree != 3 && st->sh_max_degree != 4)
+        return fail(GGR_E_INVALID, "sh_max_degree must be 0 (default), 3 or 4");
     if (in->shs && st->sh_stride < (st->sh_degree > 3 ? 16 : (st->sh_degree + 1) * (st->sh_degree + 1)))
         return fail(GGR_E_INVALID, "sh_stride %d too small for sh_degree %d", st->sh_stride, st->sh_degree);
     const int64_t tiles = (int64_t)((st->image_width + GGR_TILE - 1) / GGR_TILE) * ((st->image_height + GGR_TILE - 1) / GGR_TILE);
@@ -107,6 +109,7 @@ InputForm input_form(const GgrSettings* st, const GgrForwardIn* in) {
     f.aux_affine = (in->aux_affine && !in->aux_precomp) ? 1 : 0;
     f.aux_a = in->aux_a;
     f.aux_b = in->aux_b;
+    f.sh_cap = st->sh_max_degree == 3 ? 3 : 4;
     return f;
 }
 

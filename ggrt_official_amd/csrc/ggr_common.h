@@ -175,7 +175,16 @@ struct InputForm {
     int aux_affine;            // 1: blended feature = max(aux_a + aux_b·z/s, 0) instead of z — GGRt's depth pass
     float aux_a, aux_b;        //    (:240-269: depth as a degree-0 SH coefficient) without a per-Gaussian tensor
     const float* tanfov_dev;   // device float[2] overriding tanfovx / tanfovy, or NULL (GgrSettings.tanfov_dev)
+    int sh_cap;                // highest SH band evaluated: 4 (GGRt's fork as recollected, default) or 3 (graphdeco)
 };
+
+// SH bands actually evaluated: min(D, cap), and never more than a row of M coefficients holds
+__host__ __device__ static inline int ggr_sh_degree(int D, int M, int cap) {
+    int deg = D < cap ? D : cap;
+    if (deg < 0) deg = 0;
+    while (deg > 0 && (deg + 1) * (deg + 1) > M) deg--;
+    return deg;
+}
 
 // ---- kernel launchers (defined in the .hip translation units) -------------------------------
 namespace ggr {

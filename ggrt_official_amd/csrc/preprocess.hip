@@ -19,6 +19,9 @@ __device__ __constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920
 __device__ __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
                                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                            -0.5900435899266435f};
+__device__ __constant__ float kSH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f,
+                                           -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f,
+                                           0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
 #define SH_C0 0.28209479177387814f
 #define SH_C1 0.4886025119029199f
 
@@ -46,7 +49,7 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, 
     cov6[0] = S[0]; cov6[1] = S[1]; cov6[2] = S[2]; cov6[3] = S[4]; cov6[4] = S[5]; cov6[5] = S[8];
 }
 
-// SH basis in the rasterizer's sign convention; B must hold 16 floats
+// SH basis in the rasterizer's sign convention; B must hold 25 floats (band 4: see oracle/ggr_oracle.c header)
 __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* B) {
     B[0] = SH_C0;
     if (deg > 0) {
@@ -63,6 +66,17 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
                 B[13] = kSH_C3[4] * x * (4.0f * zz - xx - yy);
                 B[14] = kSH_C3[5] * z * (xx - yy);
                 B[15] = kSH_C3[6] * x * (xx - 3.0f * yy);
+                if (deg > 3) {
+                    B[16] = kSH_C4[0] * xy * (xx - yy);
+                    B[17] = kSH_C4[1] * yz * (3.0f * xx - yy);
+                    B[18] = kSH_C4[2] * xy * (7.0f * zz - 1.0f);
+                    B[19] = kSH_C4[3] * yz * (7.0f * zz - 3.0f);
+                    B[20] = kSH_C4[4] * (zz * (35.0f * zz - 30.0f) + 3.0f);
+                    B[21] = kSH_C4[5] * xz * (7.0f * zz - 3.0f);
+                    B[22] = kSH_C4[6] * (xx - yy) * (7.0f * zz - 1.0f);
+                    B[23] = kSH_C4[7] * xz * (xx - 3.0f * yy);
+                    B[24] = kSH_C4[8] * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+                }
             }
         }
     }
@@ -88,7 +102,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     for (uint32_t wz = (uint32_t)i; wz < zero_words; wz += gridDim.x * blockDim.x) zero_area[wz] = 0u;
     // Cooperative, coalesced staging of the block's SH rows (the per-Gaussian row is 12·K bytes: read
     // lane-per-Gaussian it would touch 64 different cache lines per load instruction).
-    const int sh_deg = D > 3 ? 3 : D;
+    const int sh_deg = ggr_sh_degree(D, shs ? M : 25, inf.sh_cap);
     const int sh_rowf = 3 * (sh_deg + 1) * (sh_deg + 1);
     // odd row length (GGRt: 3·M = 75 floats): the block's rows are ONE contiguous, 16-B aligned region (g0 is
     // a multiple of 256) → copy it flat with float4 loads; an odd LDS stride is already conflict-free for
@@ -218,11 +232,11 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 if (colors_precomp) {
                     rgb[0] = cp_in[0]; rgb[1] = cp_in[1]; rgb[2] = cp_in[2];
                 } else {
-                    const int deg = D > 3 ? 3 : D;
+                    const int deg = sh_deg;
                     float d0 = p0 - campos[0], d1 = p1 - campos[1], d2 = p2 - campos[2];
                     const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
                     d0 /= len; d1 /= len; d2 /= len;
-                    float B[16];
+                    float B[25];
                     sh_basis(deg, d0, d1, d2, B);
                     const int K = (deg + 1) * (deg + 1);
                     const float* sh = sh_lds + threadIdx.x * sh_stride;
@@ -270,7 +284,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     const uint32_t zero_words = (uint32_t)ggr_sort_hist_words((size_t)P);  // the depth sort's work area (binning.hip)
     const int threads = 256;
     const int blocks = (P + threads - 1) / threads;
-    const int deg = D > 3 ? 3 : D;
+    const int deg = ggr_sh_degree(D, shs ? M : 25, inf.sh_cap);
     const bool flat = ((3 * M) & 1) && (reinterpret_cast<uintptr_t>(shs) & 15) == 0;  // same predicate as the kernel
     const size_t copy_row = inf.sh_channel_major ? (size_t)(3 * M) : (size_t)(3 * (deg + 1) * (deg + 1));
     const size_t rowf = (size_t)(3 * (deg + 1) * (deg + 1));

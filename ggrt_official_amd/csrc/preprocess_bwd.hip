@@ -19,6 +19,10 @@ __device__ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
                                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                            -0.5900435899266435f};
 
+__device__ __constant__ float bSH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f,
+                                           -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f,
+                                           0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
+
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_take(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
@@ -66,8 +70,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         dL_dopacity[i] = r2.x;
     }
     // coalesced staging of the block's SH rows (same reason as in preprocess_fwd)
-    const int sh_rowf = 3 * ((D > 3 ? 3 : D) + 1) * ((D > 3 ? 3 : D) + 1);
     const bool use_sh = !has_colors_precomp && shs != nullptr;
+    const int deg = ggr_sh_degree(D, use_sh ? M : 25, inf.sh_cap);
+    const int sh_rowf = 3 * (deg + 1) * (deg + 1);
     const size_t g0 = (size_t)blockIdx.x * blockDim.x;
     const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
     const size_t sh_row = (size_t)M * 3;
@@ -110,7 +115,6 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll
         for (int k = 0; k < 16; k++) { dV[k] = 0.f; dPM[k] = 0.f; }
     }
-    const int deg = D > 3 ? 3 : D;
     const int K = (deg + 1) * (deg + 1);
 
     if (live) {
@@ -282,6 +286,19 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                         SH_TERM(14, bSH_C3[5] * z * (xx - yy), bSH_C3[5] * 2.f * xz, bSH_C3[5] * -2.f * yz,
                                 bSH_C3[5] * (xx - yy))
                         SH_TERM(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)
+                        if (deg > 3) {  // band 4 (oracle/ggr_oracle.c header): plain polynomial derivatives
+                            const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f, c21 = 21.f * zz - 3.f;
+                            const float xmy = xx - yy, x3y = xx - 3.f * yy, y3x = 3.f * xx - yy;
+                            SH_TERM(16, bSH_C4[0] * xy * xmy, bSH_C4[0] * y * y3x, bSH_C4[0] * x * x3y, 0.f)
+                            SH_TERM(17, bSH_C4[1] * yz * y3x, bSH_C4[1] * 6.f * xy * z, bSH_C4[1] * 3.f * z * xmy, bSH_C4[1] * y * y3x)
+                            SH_TERM(18, bSH_C4[2] * xy * a7, bSH_C4[2] * y * a7, bSH_C4[2] * x * a7, bSH_C4[2] * 14.f * xy * z)
+                            SH_TERM(19, bSH_C4[3] * yz * b7, 0.f, bSH_C4[3] * z * b7, bSH_C4[3] * y * c21)
+                            SH_TERM(20, bSH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f), 0.f, 0.f, bSH_C4[4] * z * (140.f * zz - 60.f))
+                            SH_TERM(21, bSH_C4[5] * xz * b7, bSH_C4[5] * z * b7, 0.f, bSH_C4[5] * x * c21)
+                            SH_TERM(22, bSH_C4[6] * xmy * a7, bSH_C4[6] * 2.f * x * a7, bSH_C4[6] * -2.f * y * a7, bSH_C4[6] * 14.f * z * xmy)
+                            SH_TERM(23, bSH_C4[7] * xz * x3y, bSH_C4[7] * 3.f * z * xmy, bSH_C4[7] * -6.f * xy * z, bSH_C4[7] * x * x3y)
+                            SH_TERM(24, bSH_C4[8] * (xx * x3y - yy * y3x), bSH_C4[8] * 4.f * x * x3y, bSH_C4[8] * -4.f * y * y3x, 0.f)
+                        }
                     }
                 }
             }
@@ -464,7 +481,7 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            float* dL_dcampos, InputForm inf, int cov_is_input, hipStream_t s) {
     if (P <= 0) return;
     const int blocks = (P + 255) / 256;
-    const int deg = D > 3 ? 3 : D;
+    const int deg = ggr_sh_degree(D, (!has_colors_precomp && shs) ? M : 25, inf.sh_cap);
     const bool flat = ((3 * M) & 1) && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
     const size_t copy_row = inf.sh_channel_major ? (size_t)(3 * M) : (size_t)(3 * (deg + 1) * (deg + 1));
     const size_t rowf = (size_t)(3 * (deg + 1) * (deg + 1));

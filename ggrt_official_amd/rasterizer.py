@@ -58,6 +58,9 @@ class GaussianRasterizationSettings(NamedTuple):
     sh_channel_major: bool = False              # shs given as [P,3,M] (GGRt's harmonics layout) instead of [P,M,3]
     aux_affine: Optional[tuple] = None          # (a, b): depth output = Σ max(a + b·z/s, 0)·α·T (GGRt's depth pass)
     tanfov: Optional[torch.Tensor] = None       # device [2]: overrides tanfovx / tanfovy without a read-back (camera_setup)
+    sh_max_degree: int = 4  # highest SH band evaluated.  4: GGRt's rasterizer fork as recollected (sh_degree = 4 with 25
+    #                         coefficients evaluates the nine degree-4 terms; unverifiable here);
+    #                         3: graphdeco upstream (coefficients 16.. ignored, zero gradient)
 
 
 class StageProfile:
@@ -137,7 +140,8 @@ def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view
         image_height=int(rs.image_height), image_width=int(rs.image_width), sh_degree=int(rs.sh_degree),
         sh_stride=int(M), num_points=int(P), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
         scale_modifier=float(rs.scale_modifier), bg=_ptr(bg), viewmatrix=_ptr(view), projmatrix=_ptr(proj),
-        campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfov_dev=_ptr(tf))
+        campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfov_dev=_ptr(tf),
+        sh_max_degree=int(getattr(rs, "sh_max_degree", 4) or 4))
 
 
 class _RasterizeGaussians(torch.autograd.Function):

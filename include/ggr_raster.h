@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 2
+#define GGR_ABI_VERSION 3
 
 enum {
     GGR_OK = 0,
@@ -49,7 +49,8 @@ enum {
 typedef struct GgrSettings {
     int32_t image_height;
     int32_t image_width;
-    int32_t sh_degree;      /* D; bands 0..min(D,3) are evaluated (GGRt passes D=4, M=25) */
+    int32_t sh_degree;      /* D; bands 0..min(D, sh_max_degree) are evaluated, and never more than sh_stride holds
+                               (GGRt passes D=4, M=25) */
     int32_t sh_stride;      /* M = coefficients per Gaussian in `shs` (0 with colors_precomp) */
     int32_t num_points;     /* P */
     float tanfovx;
@@ -63,6 +64,11 @@ typedef struct GgrSettings {
     int32_t debug;           /* 1: synchronise + check after every kernel */
     const float* tanfov_dev; /* device float[2] or NULL.  When given it overrides tanfovx / tanfovy, so that a host
                                 that derived them on the device (ggr_camera_setup) never has to read them back */
+    int32_t sh_max_degree;   /* 0 = default (4).  4: the nine degree-4 terms are evaluated and differentiated when
+                                D >= 4 and M >= 25 — what GGRt's rasterizer fork (dcharatan/diff-gaussian-
+                                rasterization-modified, reference README.md:17-18) does to the builder's recollection;
+                                NOT verifiable in this build.  3: graphdeco upstream — coefficients
+                                16.. are ignored and get zero gradient. */
 } GgrSettings;
 
 /* Inputs of GaussianRasterizer.forward (cuda_splatting.py:118-125).
@@ -146,7 +152,7 @@ typedef struct GgrBackwardIn {
 typedef struct GgrBackwardOut {
     float* dL_dmeans3D;        /* [P,3] */
     float* dL_dmeans2D;        /* [P,3] (x,y in NDC units, z = 0) — the `mean_gradients` sink of :95 */
-    float* dL_dshs;            /* [P,M,3] (zero for coefficients ≥ 16) or NULL */
+    float* dL_dshs;            /* [P,M,3] (zero for coefficients of bands that were not evaluated) or NULL */
     float* dL_dcolors_precomp; /* [P,3] or NULL */
     float* dL_dopacities;      /* [P] */
     float* dL_dcov3D;          /* [P,6]; always required (scratch for the scale/rot path too) */

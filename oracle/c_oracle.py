@@ -74,7 +74,9 @@ class OracleState:
 
 def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy,
             sh_degree=0, shs=None, colors_precomp=None, cov3D_precomp=None, scales=None,
-            rotations=None, scale_modifier=1.0) -> OracleState:
+            rotations=None, scale_modifier=1.0, sh_cap=4) -> OracleState:
+    """``sh_cap``: highest SH band evaluated (4 = GGRt's fork as recollected, 3 = graphdeco upstream; see the
+    header of ggr_oracle.c)."""
     L = lib()
     means3D = _f32(means3D)
     P = means3D.shape[0]
@@ -103,7 +105,7 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfov
         C.c_int(P), C.c_int(sh_degree), C.c_int(M), _p(means3D), _p(shs), _p(colors_precomp), _p(opac),
         _p(scales), _p(rotations), C.c_float(scale_modifier), _p(cov3D_precomp), _p(V), _p(PM), _p(cam),
         C.c_int(W), C.c_int(H), C.c_float(tanfovx), C.c_float(tanfovy), _p(depth), _p(radii), _p(xy),
-        _p(co), _p(rgb), _p(clamped), _p(tiles), _p(cov_used))
+        _p(co), _p(rgb), _p(clamped), _p(tiles), _p(cov_used), C.c_int(sh_cap))
     gx, gy = (W + 15) // 16, (H + 15) // 16
     point_list = np.zeros(max(N, 1), np.uint32)
     keys = np.zeros(max(N, 1), np.uint64)
@@ -124,7 +126,7 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfov
         inputs=dict(means3D=means3D, opac=opac, shs=shs, colors_precomp=colors_precomp,
                     cov3D_precomp=cov3D_precomp, scales=scales, rotations=rotations,
                     scale_modifier=float(scale_modifier), V=V, PM=PM, cam=cam, bg=bg,
-                    tanfovx=float(tanfovx), tanfovy=float(tanfovy)))
+                    tanfovx=float(tanfovx), tanfovy=float(tanfovy), sh_cap=int(sh_cap)))
 
 
 def backward(st: OracleState, dL_dcolor) -> dict:
@@ -155,7 +157,7 @@ def backward(st: OracleState, dL_dcolor) -> dict:
         _p(inp["scales"]), _p(inp["rotations"]), C.c_float(inp["scale_modifier"]), _p(st.cov3D), _p(inp["V"]),
         _p(inp["PM"]), _p(inp["cam"]), C.c_int(W), C.c_int(H), C.c_float(inp["tanfovx"]),
         C.c_float(inp["tanfovy"]), _p(st.radii), _p(st.clamped), _p(d2), _p(dcon), _p(drgb), _p(dmeans3D),
-        _p(dmeans2D), _p(dsh), _p(dcp), _p(dcov), _p(dsc), _p(drot))
+        _p(dmeans2D), _p(dsh), _p(dcp), _p(dcov), _p(dsc), _p(drot), C.c_int(inp["sh_cap"]))
     return dict(means3D=dmeans3D, means2D=dmeans2D, shs=dsh, colors_precomp=dcp,
                 opacities=dop.astype(np.float32).reshape(P, 1), cov3D_precomp=None if has_sr else dcov,
                 scales=dsc, rotations=drot, _dL_dconic=dcon.astype(np.float32), _dL_drgb=drgb.astype(np.float32),

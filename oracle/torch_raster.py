@@ -37,6 +37,18 @@ SH_C1 = 0.4886025119029199
 SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
 SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
          -0.4570457994644658, 1.445305721320277, -0.5900435899266435)
+SH_C4 = (2.5033429417967046, -1.7701307697799304, 0.9461746957575601, -0.6690465435572892, 0.10578554691520431,
+         -0.6690465435572892, 0.47308734787878004, -1.7701307697799304, 0.6258357354491761)
+# Highest SH band evaluated.  graphdeco's rasterizer stops at 3; GGRt passes sh_degree = 4 with 25 coefficients
+# through dcharatan's fork which (recollected, unverifiable here — see oracle/ggr_oracle.c) evaluates band 4.
+SH_CAP = 4
+
+
+def sh_eff_degree(D: int, M: int, cap: int = SH_CAP) -> int:
+    deg = max(min(D, cap), 0)
+    while deg > 0 and (deg + 1) ** 2 > M:
+        deg -= 1
+    return deg
 
 
 def sh_basis(deg: int, d: torch.Tensor) -> torch.Tensor:
@@ -52,6 +64,11 @@ def sh_basis(deg: int, d: torch.Tensor) -> torch.Tensor:
         B += [SH_C3[0] * y * (3 * xx - yy), SH_C3[1] * xy * z, SH_C3[2] * y * (4 * zz - xx - yy),
               SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy), SH_C3[4] * x * (4 * zz - xx - yy),
               SH_C3[5] * z * (xx - yy), SH_C3[6] * x * (xx - 3 * yy)]
+    if deg > 3:
+        B += [SH_C4[0] * xy * (xx - yy), SH_C4[1] * yz * (3 * xx - yy), SH_C4[2] * xy * (7 * zz - 1),
+              SH_C4[3] * yz * (7 * zz - 3), SH_C4[4] * (zz * (35 * zz - 30) + 3), SH_C4[5] * xz * (7 * zz - 3),
+              SH_C4[6] * (xx - yy) * (7 * zz - 1), SH_C4[7] * xz * (xx - 3 * yy),
+              SH_C4[8] * (xx * (xx - 3 * yy) - yy * (3 * xx - yy))]
     return torch.stack(B, -1)
 
 
@@ -67,7 +84,7 @@ def cov3d_from_scale_rot(scales, rotations, mod=1.0):
 
 def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh_degree=0,
                shs=None, colors_precomp=None, cov3D_precomp=None, scales=None, rotations=None,
-               scale_modifier=1.0, depth_grad=False):
+               scale_modifier=1.0, depth_grad=False, sh_cap=None):
     """``depth_grad``: keep view-space z differentiable as the blended depth FEATURE (the "w-depth"
     forks' out_depth gradient); its use as a sort key never carries gradient."""
     dt = means3D.dtype
@@ -122,7 +139,7 @@ def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx
         rgb = colors_precomp
         clamped = torch.zeros(P, 3, dtype=torch.bool)
     else:
-        deg = min(sh_degree, 3)
+        deg = sh_eff_degree(sh_degree, shs.shape[1], SH_CAP if sh_cap is None else sh_cap)
         K = (deg + 1) ** 2
         d = means3D - campos.to(dt)[None]
         d = d / d.norm(dim=-1, keepdim=True)
@@ -249,12 +266,13 @@ def blend(pre, point_list, ranges, bg, W, H, want_depth=True, tile_filter=None, 
 
 def rasterize(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, sh_degree=0,
               shs=None, colors_precomp=None, cov3D_precomp=None, scales=None, rotations=None,
-              scale_modifier=1.0, return_state=False, tile_filter=None, aux=None, depth_grad=False):
+              scale_modifier=1.0, return_state=False, tile_filter=None, aux=None, depth_grad=False, sh_cap=None):
     """Full forward.  Returns (color[3,H,W], radii[P], depth[H,W]) like the boundary's 3-tuple.
     ``tile_filter(tx, ty) -> bool`` restricts the blend to a subset of tiles (bounded CPU-baseline
     samples only; the other tiles are left at the background colour)."""
     pre = preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh_degree,
-                     shs, colors_precomp, cov3D_precomp, scales, rotations, scale_modifier, depth_grad=depth_grad)
+                     shs, colors_precomp, cov3D_precomp, scales, rotations, scale_modifier, depth_grad=depth_grad,
+                     sh_cap=sh_cap)
     point_list, ranges, keys, N = bin_tiles(pre, W, H)
     color, final_T, n_contrib, depth_img = blend(pre, point_list, ranges, bg, W, H, tile_filter=tile_filter, aux=aux)
     if return_state:

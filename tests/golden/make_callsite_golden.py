@@ -173,6 +173,10 @@ def main():
          (32, 32), "depth", dict(mode="disparity")),
         ("depth_relative_disparity", dict(seed=6, b=1, g_count=220, d_sh=1, h=32, w=32, near_vals=[1.2],
                                           far_vals=[50.0]), (32, 32), "depth", dict(mode="relative_disparity")),
+        # reference cuda_splatting.py:251-252: `minimum(near).maximum(far).log()` — as written this clamps every
+        # depth to `far` (the reference's quirk); the golden pins exactly that
+        ("depth_log", dict(seed=7, b=2, g_count=240, d_sh=1, h=32, w=40, near_vals=[0.9, 1.4],
+                           far_vals=[30.0, 55.0]), (32, 40), "depth", dict(mode="log")),
     ]
     for name, ikw, shape, kind, extra in cases:
         RECORD.clear()
@@ -200,5 +204,47 @@ def main():
         print(f"{name}: {len(RECORD)} boundary calls, out {tuple(out.shape)}, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def deferred_backprop_golden(cs):
+    """The call pattern of the reference's fine-tune loop (finetune_ggrt_stable.py:112-142, "deferred
+    back-propagation"): render the whole frame without a graph, take dL/d(rgb) of the image loss, then for every
+    cell (i, j) of a crop_size × crop_size grid render again WITH a graph, slice the cell out of the image and
+    call `.backward(rgb_pred_grad[cell])` on the slice.  `random_crop` at :31-43 leaves the target camera alone, so
+    at the rasterizer boundary each cell is a full-frame forward whose backward sees an upstream gradient that is
+    zero outside the cell.  Recorded: the input gradients each cell produces when the boundary is served by the
+    oracle (torch autograd)."""
+    RECORD.clear()
+    h, w, crop = 48, 64, 2
+    inp = make_inputs(seed=11, b=1, g_count=320, d_sh=25, h=h, w=w, near_vals=[0.8], far_vals=[70.0], cx=0.47, cy=0.54)
+    g = torch.Generator().manual_seed(99)
+    target = torch.rand(1, 3, h, w, generator=g)
+    names = ("gaussian_means", "gaussian_covariances", "gaussian_sh_coefficients", "gaussian_opacities")
+
+    def render(leaves):
+        return cs.render_cuda(inp["extrinsics"], inp["intrinsics"], inp["near"], inp["far"], (h, w),
+                              inp["background_color"], *leaves)
+
+    with torch.no_grad():
+        rgb = render([inp[n] for n in names])
+    rgb.requires_grad_(True)
+    ((rgb - target) ** 2).mean().backward()  # MaskedL2ImageLoss without a mask (reference ggrt/loss/criterion.py)
+    rgb_pred_grad = rgb.grad
+    oh, ow = h // crop, w // crop
+    blob = {f"in_{k}": v for k, v in to_np(inp).items()}
+    blob.update(image_shape=np.asarray((h, w)), crop_size=np.asarray(crop), target=target.numpy(),
+                rgb=rgb.detach().numpy(), rgb_pred_grad=rgb_pred_grad.numpy())
+    for i in range(crop):
+        for j in range(crop):
+            leaves = [inp[n].clone().requires_grad_(True) for n in names]
+            patch = render(leaves)[:, :, oh * i: oh * (i + 1), ow * j: ow * (j + 1)]
+            patch.backward(rgb_pred_grad[:, :, oh * i: oh * (i + 1), ow * j: ow * (j + 1)])
+            for n, t in zip(names, leaves):
+                blob[f"cell{i}{j}_grad_{n}"] = t.grad.numpy()
+    path = os.path.join(HERE, "deferred_backprop_d25.npz")
+    np.savez_compressed(path, **blob)
+    print(f"deferred_backprop_d25: {crop * crop} cells, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     main()
+    install_stubs()
+    deferred_backprop_golden(load_reference())

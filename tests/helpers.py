@@ -8,7 +8,49 @@ from ggrt_official_amd.synthetic import Scene
 from oracle import c_oracle
 
 
-def oracle_forward(sc: Scene, use_sh=True, use_cov=True, colors=None):
+# ---- parity bars (BASELINE.json north_star: images "within 1e-4", gradients within 1e-3 rel-L2) -----------------
+# The bars below are ONE ORDER above what the HIP path measures against the C oracle on an MI355X (round 2:
+# image PSNR ≈ 146 dB, per-tensor gradient rel-L2 5e-7 … 2e-6), not the north-star's loose ones: a regression of
+# an order of magnitude fails.  A threshold flip (α within an ulp of 1/255, T·(1-α) of 1e-4) moves one pixel by at
+# most ≈ 4e-3·|c|; ≤ 0.02 % such pixels are allowed, everything else must agree to FWD_ATOL.
+FWD_ATOL = 1e-4
+FLIP_FRACTION = 2e-4
+PSNR_MIN = 120.0
+GRAD_RTOL = 2e-5
+
+
+def record_metric(tag: str, **kv):
+    """Appends measured parity figures to gpurun_out/parity_metrics.jsonl (scratch; the bars above are set from
+    these).  Never fails a test."""
+    try:
+        import json
+        import os
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_metrics.jsonl"), "a") as f:
+            f.write(json.dumps(dict(tag=tag, **{k: float(v) for k, v in kv.items()})) + "\n")
+    except Exception:
+        pass
+
+
+def check_image(img, ref, name="color", tag="", psnr_min=None, flip_fraction=None):
+    d = np.abs(np.asarray(img, np.float64) - np.asarray(ref, np.float64))
+    bad = float((d > FWD_ATOL).mean())
+    p = psnr(img, ref)
+    record_metric(tag or name, kind=0, psnr=min(p, 999.0), flip_frac=bad, max_abs=float(d.max()))
+    assert bad <= (FLIP_FRACTION if flip_fraction is None else flip_fraction), f"{name}: {bad:.2e} of pixels differ by > {FWD_ATOL}"
+    assert d.max() <= 0.02 * max(1.0, float(np.abs(ref).max())), f"{name}: max abs diff {d.max()}"
+    assert p >= (PSNR_MIN if psnr_min is None else psnr_min), f"{name}: PSNR {p:.1f} dB"
+
+
+def check_grads(grads, ref, keys, tag="", rtol=None):
+    for k in keys:
+        r = rel_l2(grads[k], ref[k])
+        record_metric(f"{tag}:{k}", kind=1, rel_l2=r)
+        assert r <= (GRAD_RTOL if rtol is None else rtol), f"grad {k}: rel-L2 {r:.3e}"
+
+
+def oracle_forward(sc: Scene, use_sh=True, use_cov=True, colors=None, sh_cap=4):
     n = lambda t: t.detach().cpu().numpy()
     kw = {}
     if use_sh:
@@ -21,7 +63,8 @@ def oracle_forward(sc: Scene, use_sh=True, use_cov=True, colors=None):
         kw["scales"] = n(sc.scales)
         kw["rotations"] = n(sc.rotations)
     return c_oracle.forward(n(sc.means3D), n(sc.opacities), n(sc.viewmatrix), n(sc.projmatrix), n(sc.campos),
-                            n(sc.bg), sc.width, sc.height, sc.tanfovx, sc.tanfovy, sh_degree=sc.sh_degree, **kw)
+                            n(sc.bg), sc.width, sc.height, sc.tanfovx, sc.tanfovy, sh_degree=sc.sh_degree,
+                            sh_cap=sh_cap, **kw)
 
 
 def rel_l2(a, b) -> float:
@@ -36,7 +79,7 @@ def psnr(a, b) -> float:
 
 
 def hip_forward_backward(sc: Scene, dL_dcolor: torch.Tensor, use_sh=True, use_cov=True, colors=None,
-                         dL_ddepth=None, pose=False):
+                         dL_ddepth=None, pose=False, sh_max_degree=4):
     """Runs the product path (GaussianRasterizer on cuda:0).  Returns (color, radii, depth, grads)."""
     from ggrt_official_amd import GaussianRasterizer
     dev = torch.device("cuda:0")
@@ -54,7 +97,7 @@ def hip_forward_backward(sc: Scene, dL_dcolor: torch.Tensor, use_sh=True, use_co
     else:
         leaves["scales"] = kw["scales"] = leaf(s.scales)
         leaves["rotations"] = kw["rotations"] = leaf(s.rotations)
-    rs = s.settings()
+    rs = s.settings()._replace(sh_max_degree=sh_max_degree)
     if pose:
         view, proj, cam = leaf(s.viewmatrix), leaf(s.projmatrix), leaf(s.campos)
         rs = rs._replace(viewmatrix=view, projmatrix=proj, campos=cam)

@@ -1,0 +1,77 @@
+"""The reference's deferred back-propagation call pattern (finetune_ggrt_stable.py:112-142) against a golden
+recorded from the reference's own call site (tests/golden/make_callsite_golden.py::deferred_backprop_golden).
+
+Per cell (i, j) of a crop_size × crop_size grid the fine-tune loop renders the frame again, slices the cell out of
+the image and back-propagates the matching slice of a gradient taken earlier without a graph — at the rasterizer
+boundary: a full-frame forward whose backward sees an upstream gradient that is zero outside a window, with an
+off-centre principal point.  CPU: the build's call-site layer served by the oracle reproduces the recorded input
+gradients; GPU (-m gpu): the same through the HIP kernels, and the cells add up to the whole-frame backward.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ggrt_official_amd import splatting
+from tests.helpers import rel_l2
+from tests.test_callsite_golden import _OracleRasterizer
+
+PATH = os.path.join(os.path.dirname(__file__), "golden", "deferred_backprop_d25.npz")
+NAMES = ("gaussian_means", "gaussian_covariances", "gaussian_sh_coefficients", "gaussian_opacities")
+
+
+def _load():
+    z = np.load(PATH, allow_pickle=False)
+    inp = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    return z, inp, tuple(int(v) for v in z["image_shape"]), int(z["crop_size"])
+
+
+def _cells(z, inp, shape, crop, dev):
+    h, w = shape
+    oh, ow = h // crop, w // crop
+    t = {k: v.to(dev) for k, v in inp.items()}
+    grad_img = torch.from_numpy(z["rgb_pred_grad"]).to(dev)
+
+    def render(leaves):
+        return splatting.render_cuda(t["extrinsics"], t["intrinsics"], t["near"], t["far"], shape,
+                                     t["background_color"], *leaves)
+
+    with torch.no_grad():
+        rgb = render([t[n] for n in NAMES])
+    out = {}
+    for i in range(crop):
+        for j in range(crop):
+            leaves = [t[n].clone().requires_grad_(True) for n in NAMES]
+            patch = render(leaves)[:, :, oh * i: oh * (i + 1), ow * j: ow * (j + 1)]
+            patch.backward(grad_img[:, :, oh * i: oh * (i + 1), ow * j: ow * (j + 1)])
+            out[(i, j)] = [l.grad.detach().cpu().numpy() for l in leaves]
+    # the whole frame in one backward: must equal the sum over the cells (the backward is linear in dL/dcolor)
+    leaves = [t[n].clone().requires_grad_(True) for n in NAMES]
+    render(leaves).backward(grad_img)
+    whole = [l.grad.detach().cpu().numpy() for l in leaves]
+    return rgb.detach().cpu().numpy(), out, whole
+
+
+def test_deferred_backprop_cells_cpu(monkeypatch):
+    z, inp, shape, crop = _load()
+    monkeypatch.setattr(splatting, "GaussianRasterizer", _OracleRasterizer)
+    rgb, cells, whole = _cells(z, inp, shape, crop, "cpu")
+    np.testing.assert_allclose(rgb, z["rgb"], atol=2e-5)
+    for (i, j), grads in cells.items():
+        for n, g in zip(NAMES, grads):
+            assert rel_l2(g, z[f"cell{i}{j}_grad_{n}"]) < 1e-5, (i, j, n)
+
+
+@pytest.mark.gpu
+def test_deferred_backprop_cells_hip():
+    z, inp, shape, crop = _load()
+    rgb, cells, whole = _cells(z, inp, shape, crop, "cuda:0")
+    d = np.abs(rgb - z["rgb"])
+    assert (d > 1e-5).mean() <= 2e-4 and d.max() <= 0.02
+    for (i, j), grads in cells.items():
+        for n, g in zip(NAMES, grads):
+            assert rel_l2(g, z[f"cell{i}{j}_grad_{n}"]) < 2e-5, (i, j, n)
+    for k, n in enumerate(NAMES):
+        total = sum(cells[c][k].astype(np.float64) for c in cells)
+        assert rel_l2(total, whole[k]) < 1e-5, n

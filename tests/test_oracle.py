@@ -126,13 +126,28 @@ def test_sh_dc_and_degree4_stride25():
     st3 = oracle_forward(sc)
     sh25 = torch.zeros(400, 25, 3)
     sh25[:, :16] = sc.shs
-    sh25[:, 16:] = 123.0  # must be ignored
     n = lambda t: t.numpy()
-    st4 = c_oracle.forward(n(sc.means3D), n(sc.opacities), n(sc.viewmatrix), n(sc.projmatrix), n(sc.campos), n(sc.bg),
-                           sc.width, sc.height, sc.tanfovx, sc.tanfovy, sh_degree=4, shs=n(sh25), cov3D_precomp=n(sc.cov3D))
+    fwd = lambda sh, **kw: c_oracle.forward(n(sc.means3D), n(sc.opacities), n(sc.viewmatrix), n(sc.projmatrix),
+                                            n(sc.campos), n(sc.bg), sc.width, sc.height, sc.tanfovx, sc.tanfovy,
+                                            sh_degree=4, shs=n(sh), cov3D_precomp=n(sc.cov3D), **kw)
+    # band 4 with zero coefficients adds exact zeros: same image as degree 3 over 16 coefficients
+    assert np.array_equal(st3.color, fwd(sh25).color)
+    # graphdeco behaviour (sh_cap = 3): coefficients 16.. are ignored whatever they hold, and get no gradient
+    sh25[:, 16:] = 123.0
+    st4 = fwd(sh25, sh_cap=3)
     assert np.array_equal(st3.color, st4.color)
     g4 = c_oracle.backward(st4, upstream_gradient(48, 40).numpy())
     assert np.all(g4["shs"][:, 16:] == 0)
+    # GGRt's fork as recollected (sh_cap = 4, the default): band 4 is evaluated and differentiated
+    st4b = fwd(sh25)
+    assert not np.array_equal(st3.color, st4b.color)
+    g4b = c_oracle.backward(st4b, upstream_gradient(48, 40).numpy())
+    assert np.any(g4b["shs"][:, 16:] != 0)
+    # a degree-4 request over 16 coefficients falls back to degree 3 (never reads past the row)
+    st_short = c_oracle.forward(n(sc.means3D), n(sc.opacities), n(sc.viewmatrix), n(sc.projmatrix), n(sc.campos),
+                                n(sc.bg), sc.width, sc.height, sc.tanfovx, sc.tanfovy, sh_degree=4, shs=n(sc.shs),
+                                cov3D_precomp=n(sc.cov3D))
+    assert np.array_equal(st3.color, st_short.color)
     # degree 0: rgb = max(0, 0.5 + C0·sh0)
     sc0 = make_scene(50, 32, 32, sh_degree=0, seed=1)
     st0 = oracle_forward(sc0)
@@ -140,7 +155,22 @@ def test_sh_dc_and_degree4_stride25():
     np.testing.assert_allclose(st0.rgb[vis], np.maximum(0.5 + C0 * sc0.shs[:, 0].numpy()[vis], 0), atol=1e-6)
 
 
-@pytest.mark.parametrize("D,use_cov,seed", [(3, True, 0), (1, False, 1), (0, True, 2)])
+def test_sh_basis_is_orthonormal_up_to_degree_4():
+    """Pins the 25 basis polynomials and their constants (SH_C0 … SH_C4): real spherical harmonics are orthonormal
+    on the unit sphere.  Gauss-Legendre in cos θ × uniform φ integrates polynomials of degree ≤ 8 exactly."""
+    xs, ws = np.polynomial.legendre.leggauss(12)
+    phi = (np.arange(24) + 0.5) * (2 * np.pi / 24)
+    ct, ph = np.meshgrid(xs, phi, indexing="ij")
+    st_ = np.sqrt(1 - ct ** 2)
+    d = torch.from_numpy(np.stack([st_ * np.cos(ph), st_ * np.sin(ph), ct], -1).reshape(-1, 3))
+    w = torch.from_numpy((ws[:, None] * np.full_like(ph, 2 * np.pi / 24)).reshape(-1))
+    B = tr.sh_basis(4, d)
+    assert B.shape[1] == 25
+    gram = (B * w[:, None]).T @ B
+    np.testing.assert_allclose(gram.numpy(), np.eye(25), atol=1e-12)
+
+
+@pytest.mark.parametrize("D,use_cov,seed", [(3, True, 0), (1, False, 1), (0, True, 2), (4, True, 3)])
 def test_c_oracle_matches_torch_autograd(D, use_cov, seed):
     sc = make_scene(1500, 80, 64, sh_degree=D, profile="A", seed=seed)
     dL = upstream_gradient(80, 64, seed=seed)
