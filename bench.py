@@ -4,17 +4,28 @@
 A "step" = one forward + one backward of the rasterizer over one synthetic frame whose inputs are
 already resident in HBM (BASELINE.json config 3: 1 M Gaussians, 1920×1080, SH degree 3, profile A —
 ``ggrt_official_amd/synthetic.py``).  The backward produces the reference's gradient set (means3D, cov3D,
-SH, opacity, means2D) plus the camera gradient (viewmatrix / projmatrix / campos).  With N > 1 ranks
-every rank renders its OWN frame (frames shard one-per-GPU, SURVEY.md §8e: the per-frame Gaussians are
-never exchanged) and the step ends with the path's one exchange: a mean all-reduce of the camera
-gradient over RCCL.  ``--grad-buffer-floats 65000000`` additionally all-reduces a stand-in for GGRt's
-encoder + pose-network gradients (≈260 MB); that is off by default because those modules
-are outside the measured path.
+SH, opacity, means2D) plus the camera gradient (viewmatrix / projmatrix / campos).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying two extra objects:
-  "roofline":     the dominant kernel's algorithmic bytes / its live HIP-event duration vs 8 TB/s
-  "cpu_baseline": the PyTorch-CPU restatement (oracle/torch_raster.py) timed on this host on a bounded
-                  sample of the same workload (rank 0, N = 1 only)
+N > 1 ranks (reference train_ggrt_stable.py:322-328, ggrt/base/trainer.py:115-117): every rank
+renders its OWN frame (frames shard one-per-GPU; per-frame Gaussians are never exchanged) and every step ends
+with the path's one exchange — ONE mean all-reduce over RCCL of a flat fp32 buffer holding the stand-in for
+GGRt's encoder + pose-network parameter gradients (``--grad-buffer-floats``, default 65 M floats ≈ 260 MB,
+SURVEY.md §5) with the 35 floats of camera gradient this step produced in its tail.  The timed loop issues the
+all-reduce asynchronously (it overlaps the NEXT frame's rasterization, two buffers alternate; every all-reduce
+has completed when the timed region closes); ``--exchange-mode serial`` waits for it inside each step.  After
+the timed region the record's ``multi_gpu`` object adds, each measured on its own: ``raster_ms`` (no exchange),
+``allreduce_ms`` (the exchange alone), ``serial_ms_per_step`` and ``overlapped_ms_per_step``.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying extra objects:
+  "roofline"      the dominant kernel's algorithmic bytes ÷ its HIP-event duration (events on the stream the
+                  kernels are launched on) vs 8 TB/s; ``traffic`` comes from a rocprofv3 PMC profile of this same
+                  command committed under profiles/ and says so (``traffic_source``) — it is NOT measured in-run
+  "cpu_baseline"  oracle/ggr_oracle.c (the C restatement, OpenMP) timed on this host on the WHOLE frame of the
+                  same workload, no extrapolation (rank 0, N = 1 only); "cpu_baseline_torch" keeps the PyTorch
+                  restatement's bounded-sample figure beside it
+  "secondary"     the other BASELINE shapes measured the same way (N = 1 only): C5' (GGRt's per-rank training
+                  shape, fwd+bwd), C4' (GGRt's LLFF eval shape, forward only, frames/s) and C3 with the upper half
+                  of the frame empty — each with its own stage times and roofline
 
 Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
                  --master-port P bench.py --gpus N --steps K --warmup W
@@ -22,6 +33,7 @@ Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N -
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -32,12 +44,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (≈6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (≈6.3 TB/s achievable)
+# non-packed fp32 VALU issue peak: 256 CUs × 4 SIMDs, one wave64 instruction per 4 cycles at 2.4 GHz
+VALU_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4
 
 
 def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int) -> dict:
@@ -53,16 +68,168 @@ def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int) -> dict:
     }
 
 
-def cpu_baseline(cfg: dict, seed: int, budget_s: float = 20.0) -> dict:
-    """Times the PyTorch-CPU restatement (fwd + autograd bwd) on a bounded sample of the SAME scene:
-    the full preprocess + key sort, and the blend fwd+bwd on an evenly strided subset of tiles sized
-    from a 4-tile probe so the whole leg stays within ~budget_s.  The per-frame time is
-    t_pre+sort + t_blend(sample)·tiles/sample and is reported as such (``sample``)."""
+def percentiles(ms: list) -> dict:
+    s = sorted(ms)
+    q = lambda f: s[min(len(s) - 1, max(0, int(round(f * (len(s) - 1)))))]
+    return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "n": len(s)}
+
+
+def newest_profile(pattern: str):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one workload = one resident scene + its step function
+# ---------------------------------------------------------------------------------------------------------
+class Workload:
+    def __init__(self, name: str, cfg: dict, dev, seed: int = 0, fwd_only: bool = False, pose: bool = True,
+                 keep_cpu_scene: bool = False):
+        from ggrt_official_amd import GaussianRasterizer
+        from ggrt_official_amd.synthetic import make_scene, upstream_gradient
+        self.name, self.cfg, self.dev, self.fwd_only = name, cfg, dev, fwd_only
+        sc_cpu = make_scene(seed=seed, **cfg)
+        self.sc_cpu = sc_cpu if keep_cpu_scene else None
+        sc = sc_cpu.to(dev)                      # inputs resident in HBM before anything is timed
+        self.sc = sc
+        self.W, self.H, self.P = sc.width, sc.height, sc.means3D.shape[0]
+        self.dL = upstream_gradient(self.W, self.H, seed=1234 + seed, device=dev)
+        need = not fwd_only
+        leaf = lambda t: t.clone().requires_grad_(need)
+        # camera tensors are leaves too: the step produces dL/d(viewmatrix, projmatrix, campos) — the one
+        # gradient of this path that data-parallel ranks share (the per-frame Gaussians are not shared)
+        self.view, self.proj, self.campos = (leaf(sc.viewmatrix), leaf(sc.projmatrix), leaf(sc.campos)) if pose else \
+            (sc.viewmatrix, sc.projmatrix, sc.campos)
+        self.rs = sc.settings()._replace(viewmatrix=self.view, projmatrix=self.proj, campos=self.campos)
+        self.rast = GaussianRasterizer(self.rs)
+        self.means, self.cov, self.op, self.shs = leaf(sc.means3D), leaf(sc.cov3D), leaf(sc.opacities), leaf(sc.shs)
+        self.means2D = torch.zeros_like(self.means, requires_grad=need)
+        self.leaves = (self.means, self.cov, self.op, self.shs, self.means2D) + ((self.view, self.proj, self.campos) if pose else ())
+        self.pose = pose
+
+    def step(self):
+        if self.fwd_only:
+            with torch.no_grad():
+                color, _, _ = self.rast(means3D=self.means, means2D=self.means2D, opacities=self.op, shs=self.shs,
+                                        cov3D_precomp=self.cov)
+            return color
+        for t in self.leaves:
+            t.grad = None
+        color, _, _ = self.rast(means3D=self.means, means2D=self.means2D, opacities=self.op, shs=self.shs,
+                                cov3D_precomp=self.cov)
+        color.backward(self.dL)  # the upstream gradient dL/dcolor goes straight into the rasterizer's backward
+        return color
+
+    def num_rendered(self) -> int:
+        from ggrt_official_amd.rasterizer import debug_forward_state
+        sc = self.sc
+        return debug_forward_state(sc.means3D, sc.opacities, sc.settings(), shs=sc.shs, cov3D_precomp=sc.cov3D)["num_rendered"]
+
+    def stage_times(self, n: int) -> dict:
+        """per-stage HIP-event timing on the launch stream (the library brackets its stages with hipEvents on the
+        stream it launches on; profiling mode synchronises per call, so these steps are never part of a timed loop)"""
+        from ggrt_official_amd.rasterizer import profile_stages
+        with profile_stages() as prof:
+            for _ in range(max(n, 1)):
+                self.step()
+        torch.cuda.synchronize(self.dev)
+        d = prof.as_dict()
+        if self.fwd_only:
+            d = {k: v for k, v in d.items() if k.startswith("fwd_")}
+        return d
+
+    def rooflines(self, stages: dict, N: int) -> dict:
+        D = self.cfg["sh_degree"]
+        M = self.sc.shs.shape[1]
+        deg = min(D, 4)
+        while (deg + 1) ** 2 > M:
+            deg -= 1
+        K = (deg + 1) ** 2
+        ab = algorithmic_bytes(self.P, N, self.W, self.H, K, M)
+        kernel_ms = {"fwd_preprocess": stages["fwd_preprocess_ms"], "fwd_blend": stages["fwd_blend_ms"]}
+        if not self.fwd_only:
+            kernel_ms.update({"bwd_blend": stages["bwd_blend_ms"], "bwd_preprocess": stages["bwd_preprocess_ms"]})
+        dom = max(kernel_ms, key=kernel_ms.get)
+        achieved = ab[dom] / (kernel_ms[dom] * 1e-3) / 1e9
+        t_fwd = sum(v for k, v in stages.items() if k.startswith("fwd_"))
+        b_fwd = ab["fwd_preprocess"] + ab["fwd_binning"] + ab["fwd_blend"]
+        out = {
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes": ab[dom], "kernel_ms": round(kernel_ms[dom], 4)},
+            "render_forward": {"ms": round(t_fwd, 4), "algorithmic_bytes": b_fwd,
+                               "hbm_frac": round(b_fwd / (t_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+        }
+        if not self.fwd_only:
+            t_bwd = sum(v for k, v in stages.items() if k.startswith("bwd_"))
+            b_bwd = ab["bwd_blend"] + ab["bwd_preprocess"]
+            out["render_backward"] = {"ms": round(t_bwd, 4), "algorithmic_bytes": b_bwd,
+                                      "hbm_frac": round(b_bwd / (t_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        return out
+
+
+def timed_steps(fn, steps: int, warmup: int, dev, barrier=None, finish=None):
+    """`warmup` untimed calls, then EXACTLY `steps` calls bracketed by barrier + synchronize on both sides.
+    Returns (wall seconds of the bracket, per-step ms from HIP events recorded on the launch stream)."""
+    for i in range(warmup):
+        fn(i)
+    if finish:
+        finish()
+    torch.cuda.synchronize(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    if barrier:
+        barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        fn(warmup + i)
+        ev[i + 1].record()
+    if finish:
+        finish()
+    torch.cuda.synchronize(dev)
+    if barrier:
+        barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only; test infrastructure used as the reported baseline, never as the product)
+# ---------------------------------------------------------------------------------------------------------
+def cpu_baseline_c_oracle(sc, dL_cpu, reps: int = 2) -> dict:
+    """oracle/ggr_oracle.c on the WHOLE frame: preprocess + 64-bit key sort + blend forward + blend backward +
+    per-Gaussian backward, OpenMP over Gaussians / pixel rows / tiles (the key sort is sequential)."""
+    from oracle import c_oracle
+    from tests.helpers import oracle_forward
+    cores = int(c_oracle.lib().ggo_num_threads())
+    best = None
+    for r in range(reps + 1):  # the first repetition warms the page cache / thread pool
+        t0 = time.perf_counter()
+        st = oracle_forward(sc)
+        t_f = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        c_oracle.backward(st, dL_cpu)
+        t_b = time.perf_counter() - t0
+        log(f"cpu_baseline (C oracle, {cores} threads) rep {r}: fwd {t_f:.2f}s bwd {t_b:.2f}s")
+        if r > 0 and (best is None or t_f + t_b < best[0] + best[1]):
+            best = (t_f, t_b)
+    t_f, t_b = best
+    return {"value": round(sc.width * sc.height / (t_f + t_b) / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle/ggr_oracle.c (C restatement, OpenMP, {cores} threads) on the WHOLE frame of the same "
+                       f"workload, fwd+bwd, best of {reps} after one warm-up: fwd {t_f:.2f}s + bwd {t_b:.2f}s; nothing "
+                       f"extrapolated"),
+            "fwd_s": round(t_f, 3), "bwd_s": round(t_b, 3)}
+
+
+def cpu_baseline_torch(cfg: dict, seed: int, budget_s: float = 8.0) -> dict:
+    """The PyTorch-CPU restatement (fwd + autograd bwd) on a bounded sample of the SAME scene: the full
+    preprocess + key sort, and the blend fwd+bwd on an evenly strided subset of tiles sized from a 4-tile
+    probe so the whole leg stays within ~budget_s.  The per-frame time is t_pre+sort + t_blend(sample)·tiles/sample
+    and is reported as such (``sample``) — an extrapolation, kept only next to the C oracle's whole-frame figure."""
     from ggrt_official_amd.synthetic import make_scene, upstream_gradient
     from oracle import torch_raster as tr
 
-    # per-tile tensors are small ([list, 256]); beyond a few dozen threads torch's intra-op
-    # parallelism only adds synchronisation cost, so cap the thread count and report what was used
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     sc = make_scene(seed=seed, **cfg)
@@ -76,7 +243,6 @@ def cpu_baseline(cfg: dict, seed: int, budget_s: float = 20.0) -> dict:
                         sc.sh_degree, shs=sh, cov3D_precomp=cov)
     point_list, ranges, keys, N = tr.bin_tiles(pre, W, H)
     t_prebin = time.perf_counter() - t0
-    log(f"cpu_baseline: threads={cores} preprocess+sort {t_prebin:.2f}s N={N}")
     dL = upstream_gradient(W, H)
 
     def run(stride, offset):
@@ -89,10 +255,8 @@ def cpu_baseline(cfg: dict, seed: int, budget_s: float = 20.0) -> dict:
         (color * dL).sum().backward(retain_graph=True)
         return n, t_f, time.perf_counter() - t0
 
-    # probe: ~4 tiles spread over the image (the backward includes the per-Gaussian autograd pass)
     n_p, tf_p, tb_p = run(max(1, ntiles // 4), (ntiles // 8) % max(1, ntiles // 4))
-    per_tile = (tf_p + max(tb_p - 0.0, 0.0)) / max(n_p, 1)
-    log(f"cpu_baseline: probe {n_p} tiles fwd {tf_p:.2f}s bwd {tb_p:.2f}s")
+    per_tile = (tf_p + tb_p) / max(n_p, 1)
     n_target = int(max(4, min(ntiles, budget_s / max(per_tile, 1e-4))))
     stride = max(1, ntiles // n_target)
     for t in (m, cov, op, sh):
@@ -100,15 +264,32 @@ def cpu_baseline(cfg: dict, seed: int, budget_s: float = 20.0) -> dict:
     n_s, t_f, t_b = run(stride, 0)
     frac = n_s / ntiles
     t_frame = t_prebin + (t_f + t_b) / frac
-    log(f"cpu_baseline: sample {n_s}/{ntiles} tiles fwd {t_f:.2f}s bwd {t_b:.2f}s -> frame {t_frame:.1f}s")
-    return {
-        "value": round(W * H / t_frame / 1e6, 6), "unit": "Mpix/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle/torch_raster.py (PyTorch CPU fp32, {cores} threads, autograd bwd) on the same scene: "
-                   f"full preprocess+sort of P={cfg['num_points']} / N={N} ({t_prebin:.2f}s) + blend fwd+bwd on "
-                   f"{n_s}/{ntiles} tiles (every {stride}th; {t_f:.2f}s + {t_b:.2f}s, bwd includes the per-Gaussian "
-                   f"autograd), scaled by {1 / frac:.1f} to one frame"),
-        "frame_s_estimated": round(t_frame, 3),
-    }
+    log(f"cpu_baseline_torch: {cores} threads, sample {n_s}/{ntiles} tiles -> frame {t_frame:.1f}s (extrapolated)")
+    return {"value": round(W * H / t_frame / 1e6, 6), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle/torch_raster.py (PyTorch CPU fp32, {cores} threads, autograd bwd): full preprocess+sort "
+                       f"({t_prebin:.2f}s) + blend fwd+bwd on {n_s}/{ntiles} tiles (every {stride}th; {t_f:.2f}s + "
+                       f"{t_b:.2f}s) EXTRAPOLATED by {1 / frac:.1f} to one frame"),
+            "frame_s_estimated": round(t_frame, 3)}
+
+
+# ---------------------------------------------------------------------------------------------------------
+def secondary_record(name: str, cfg: dict, dev, steps: int, warmup: int, fwd_only: bool) -> dict:
+    """Another BASELINE shape measured like the headline one: per-step HIP events (median / p10 / p90), stage times,
+    the dominant kernel's roofline and the render-forward / -backward HBM fractions of THIS shape."""
+    wl = Workload(name, cfg, dev, seed=0, fwd_only=fwd_only, pose=not fwd_only)
+    _, per_step = timed_steps(lambda i: wl.step(), steps, warmup, dev)
+    stages = wl.stage_times(3)
+    N = wl.num_rendered()
+    pc = percentiles(per_step)
+    rec = {"workload": (f"{name}: {wl.P} Gaussians, {wl.W}x{wl.H}, SH deg {cfg['sh_degree']} (M={wl.sc.shs.shape[1]}), "
+                        f"profile {cfg['profile']}" + (f", layout {cfg['layout']}" if cfg.get("layout") else "") +
+                        (", forward only (torch.no_grad)" if fwd_only else ", fwd+bwd incl. camera gradient")),
+           "num_rendered": N, "ms_per_step": pc, "mpix_s": round(wl.W * wl.H / pc["median"] / 1e3, 1),
+           "frames_per_s": round(1e3 / pc["median"], 1), "stages_ms": {k: round(v, 4) for k, v in stages.items()}}
+    rec.update(wl.rooflines(stages, N))
+    del wl
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -120,10 +301,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the informational HIP-graph replay leg")
     ap.add_argument("--no-callsite", action="store_true", help="skip the informational GGRt-shape call-site leg")
-    ap.add_argument("--grad-buffer-floats", type=int, default=0,
-                    help="N>1 only: ALSO all-reduce a flat fp32 buffer of this size per step, a stand-in for GGRt's "
-                         "encoder + pose-network gradients (≈65_000_000, SURVEY.md §5); off by default because those "
-                         "modules are outside the measured path and nothing in this benchmark could overlap it")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C5'/C4'/non-uniform-C3 records (N = 1 only)")
+    ap.add_argument("--grad-buffer-floats", type=int, default=65_000_000,
+                    help="N>1: size of the flat fp32 stand-in for GGRt's encoder + pose-network gradients that is "
+                         "mean-all-reduced every step together with the camera gradient (SURVEY.md §5: ≈65 M floats "
+                         "≈ 260 MB).  0 = exchange the 35 floats of camera gradient only")
+    ap.add_argument("--exchange-mode", choices=("overlap", "serial"), default="overlap",
+                    help="N>1, the timed loop: `overlap` issues each step's all-reduce asynchronously so that it runs "
+                         "behind the next frame's rasterization (all of them complete inside the timed region); "
+                         "`serial` waits for it inside the step.  Both are reported in `multi_gpu` either way")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra untimed steps with per-stage HIP events")
     ap.add_argument("--dist-backend", default=None,
                     help="debug: process-group backend (default: nccl = RCCL).  `gloo` together with `--device 0` "
@@ -132,9 +318,9 @@ def main():
     args = ap.parse_args()
 
     from ggrt_official_amd import GaussianRasterizer
-    from ggrt_official_amd.rasterizer import profile_stages
-    from ggrt_official_amd.synthetic import CONFIGS, make_scene, upstream_gradient
+    from ggrt_official_amd.synthetic import CONFIGS
     from ggrt_official_amd import parallel
+    import torch.distributed as dist
 
     rank, world, local = parallel.init_from_env(args.gpus, backend=args.dist_backend)
     if args.device is not None:
@@ -142,65 +328,77 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     cfg = CONFIGS[args.config]
-    sc = make_scene(seed=rank, **cfg).to(dev)       # one frame per rank, inputs resident in HBM
-    W, H = sc.width, sc.height
-    dL = upstream_gradient(W, H, seed=1234 + rank, device=dev)
-    # camera tensors are leaves too: the step produces dL/d(viewmatrix, projmatrix, campos) — the one
-    # gradient of this path that data-parallel ranks share (the per-frame Gaussians are not shared)
-    view = sc.viewmatrix.clone().requires_grad_(True)
-    proj = sc.projmatrix.clone().requires_grad_(True)
-    campos = sc.campos.clone().requires_grad_(True)
-    rs = sc.settings()._replace(viewmatrix=view, projmatrix=proj, campos=campos)
-    rast = GaussianRasterizer(rs)
-    means = sc.means3D.clone().requires_grad_(True)
-    cov = sc.cov3D.clone().requires_grad_(True)
-    op = sc.opacities.clone().requires_grad_(True)
-    shs = sc.shs.clone().requires_grad_(True)
-    means2D = torch.zeros_like(means, requires_grad=True)
-    leaves = (means, cov, op, shs, means2D, view, proj, campos)
-    pose_buf = torch.zeros(35, device=dev)
-    grad_buf = torch.zeros(args.grad_buffer_floats, device=dev) if (world > 1 and args.grad_buffer_floats) else None
+    wl = Workload(args.config, cfg, dev, seed=rank, keep_cpu_scene=(rank == 0 and world == 1))  # one frame per rank
+    W, H, P = wl.W, wl.H, wl.P
 
-    def step():
-        for t in leaves:
-            t.grad = None
-        color, radii, depth = rast(means3D=means, means2D=means2D, opacities=op, shs=shs, cov3D_precomp=cov)
-        color.backward(dL)  # the upstream gradient dL/dcolor goes straight into the rasterizer's backward
+    # ---- the exchange (N > 1): ONE flat buffer = stand-in parameter gradients + this step's camera gradient -----
+    G = max(int(args.grad_buffer_floats), 0)
+    bufs, pending = [], [None, None]
+    use_avg = world > 1 and dist.get_backend() == "nccl"   # RCCL averages in the collective; gloo: sum, then scale
+    if world > 1:
+        bufs = [torch.zeros(G + 35, device=dev) for _ in range(2)]
+
+    def exchange(i: int, blocking: bool):
+        k = i & 1
+        if pending[k] is not None:       # the all-reduce issued two steps ago on this buffer
+            pending[k].wait()
+            pending[k] = None
+        buf = bufs[k]
+        torch.cat([wl.view.grad.reshape(-1), wl.proj.grad.reshape(-1), wl.campos.grad.reshape(-1)], out=buf[G:])
+        work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, async_op=True)
+        if blocking:
+            work.wait()
+            if not use_avg:
+                buf.div_(world)
+        else:
+            pending[k] = work
+
+    def drain():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+                if not use_avg:
+                    bufs[k].div_(world)
+
+    blocking = args.exchange_mode == "serial"
+
+    def step(i: int):
+        wl.step()
         if world > 1:
-            # the path's exchange step: mean all-reduce of the camera gradient over RCCL/xGMI
-            torch.cat([view.grad.reshape(-1), proj.grad.reshape(-1), campos.grad.reshape(-1)], out=pose_buf)
-            parallel.allreduce_mean_(pose_buf)
-            if grad_buf is not None:  # optional stand-in for the encoder + pose-network gradients
-                parallel.allreduce_mean_(grad_buf)
-        return color
+            exchange(i, blocking)
 
-    log(f"scene {args.config} resident on {dev}; warmup {args.warmup}")
-    for i in range(args.warmup):
-        t_w = time.perf_counter()
-        step()
-        torch.cuda.synchronize(dev)
-        log(f"warmup step {i}: {(time.perf_counter() - t_w) * 1e3:.2f} ms")
-    parallel.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    parallel.barrier()
-    elapsed = time.perf_counter() - t0
+    log(f"scene {args.config} resident on {dev}; world {world}; warmup {args.warmup}")
+    elapsed, per_step = timed_steps(step, args.steps, args.warmup, dev, barrier=parallel.barrier,
+                                    finish=drain if world > 1 else None)
     elapsed = parallel.max_over_ranks(elapsed, dev)
     log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.3f} ms/step")
 
-    # per-stage HIP-event timing on the launch stream (untimed extra steps)
-    with profile_stages() as prof:
-        for _ in range(max(args.profile_steps, 1)):
-            step()
-    torch.cuda.synchronize(dev)
-    stages = prof.as_dict()
+    # ---- N > 1: the pieces of the step, each measured on its own (after the timed region) -------------------
+    multi = None
+    if world > 1:
+        def leg(fn, fin=None):
+            t, _ = timed_steps(fn, args.steps, 2, dev, barrier=parallel.barrier, finish=fin)
+            return parallel.max_over_ranks(t, dev) / args.steps * 1e3
+
+        raster_ms = leg(lambda i: wl.step())
+        wl.step()
+        allreduce_ms = leg(lambda i: exchange(i, True))
+        serial_ms = leg(lambda i: (wl.step(), exchange(i, True)))
+        overlap_ms = leg(lambda i: (wl.step(), exchange(i, False)), drain)
+        nbytes = (G + 35) * 4
+        multi = {"exchange": f"one mean all-reduce per step of {G} stand-in parameter-gradient floats + 35 camera-gradient "
+                             f"floats ({nbytes / 1e6:.1f} MB), backend {dist.get_backend()}",
+                 "timed_loop_mode": args.exchange_mode, "raster_ms": round(raster_ms, 4),
+                 "allreduce_ms": round(allreduce_ms, 4), "serial_ms_per_step": round(serial_ms, 4),
+                 "overlapped_ms_per_step": round(overlap_ms, 4),
+                 "allreduce_busbw_GBps": round(2 * (world - 1) / world * nbytes / (allreduce_ms * 1e-3) / 1e9, 1),
+                 "raster_only_mpix_s": round(world * W * H / raster_ms / 1e3, 1)}
+        log(f"multi-GPU legs: {multi}")
+
+    stages = wl.stage_times(args.profile_steps)
     log("stages: " + ", ".join(f"{k}={v:.3f}" for k, v in stages.items()))
-    # num_rendered of this rank's frame
-    from ggrt_official_amd.rasterizer import debug_forward_state
-    N = debug_forward_state(sc.means3D, sc.opacities, rs, shs=sc.shs, cov3D_precomp=sc.cov3D)["num_rendered"]
+    N = wl.num_rendered()  # num_rendered of this rank's frame
 
     # informational: the same step with the sync-free forward (list buffer sized 1.25·N up front) captured in ONE
     # HIP graph and replayed — no host sync, no per-kernel launch cost.  Not the headline value: the default,
@@ -210,13 +408,15 @@ def main():
         try:
             from ggrt_official_amd.rasterizer import last_forward_status
             cap = int(N * 1.25) + 4096
-            rast_g = GaussianRasterizer(rs._replace(list_capacity=cap))
+            rast_g = GaussianRasterizer(wl.rs._replace(list_capacity=cap))
+            keep = {}
 
             def step_g():
-                for t in leaves:
+                for t in wl.leaves:
                     t.grad = None
-                color, _, _ = rast_g(means3D=means, means2D=means2D, opacities=op, shs=shs, cov3D_precomp=cov)
-                color.backward(dL)
+                color, _, _ = rast_g(means3D=wl.means, means2D=wl.means2D, opacities=wl.op, shs=wl.shs, cov3D_precomp=wl.cov)
+                keep["color"] = color  # keeps the forward's buffers alive for last_forward_status()
+                color.backward(wl.dL, retain_graph=False)
 
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -235,49 +435,52 @@ def main():
                 graph.replay()
             torch.cuda.synchronize(dev)
             g_ms = (time.perf_counter() - t0) / args.steps * 1e3
-            n_g, overflow = last_forward_status()
+            try:
+                n_g, overflow = last_forward_status()
+            except RuntimeError:
+                n_g, overflow = None, None
             graph_rec = {"ms_per_step": round(g_ms, 4), "mpix_s": round(W * H / g_ms / 1e3, 1), "list_capacity": cap,
                          "num_rendered": n_g, "overflow": overflow,
                          "note": "sync-free forward + backward captured in one HIP graph, replayed; informational"}
             log(f"hip graph replay: {g_ms:.3f} ms/step")
+            del graph, keep
         except Exception as e:  # never let the informational leg break the contract line
             log(f"hip graph leg skipped: {type(e).__name__}: {e}")
 
     if rank == 0:
-        P = cfg["num_points"]
         D = cfg["sh_degree"]
-        K = (min(D, 3) + 1) ** 2
-        M = sc.shs.shape[1]
-        ab = algorithmic_bytes(P, N, W, H, K, M)
-        kernel_ms = {"fwd_preprocess": stages["fwd_preprocess_ms"], "fwd_blend": stages["fwd_blend_ms"],
-                     "bwd_blend": stages["bwd_blend_ms"], "bwd_preprocess": stages["bwd_preprocess_ms"]}
-        dom = max(kernel_ms, key=kernel_ms.get)
-        achieved = ab[dom] / (kernel_ms[dom] * 1e-3) / 1e9
-        t_fwd = sum(v for k, v in stages.items() if k.startswith("fwd_"))
-        t_bwd = sum(v for k, v in stages.items() if k.startswith("bwd_"))
-        b_fwd = ab["fwd_preprocess"] + ab["fwd_binning"] + ab["fwd_blend"]
-        b_bwd = ab["bwd_blend"] + ab["bwd_preprocess"]
         ms_per_step = elapsed / args.steps * 1e3
-        # HBM bytes of the dominant kernel from the rocprofv3 PMC passes of this same command (FETCH_SIZE and
-        # WRITE_SIZE in separate passes, FETCH ×2 per the gfx950 correction — scripts/profile_bench.sh,
-        # scripts/pmc_summary.py); only valid for the configuration it was collected on (C3)
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_v16_pmc_traffic.json")
-        if args.config == "C3" and os.path.exists(pmc_path):
-            kname = {"bwd_blend": "blend_bwd_kernel", "fwd_blend": "blend_fwd_kernel",
-                     "fwd_preprocess": "preprocess_fwd_kernel", "bwd_preprocess": "preprocess_bwd_kernel"}[dom]
+        rf = wl.rooflines(stages, N)
+        dom = rf["roofline"]["kernel"]
+        kname = {"bwd_blend": "blend_bwd_kernel", "fwd_blend": "blend_fwd_kernel",
+                 "fwd_preprocess": "preprocess_fwd_kernel", "bwd_preprocess": "preprocess_bwd_kernel"}[dom]
+        # HBM bytes of the dominant kernel: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 PMC passes of this same
+        # command (scripts/profile_bench.sh + scripts/pmc_summary.py: FETCH ×2, the guide's gfx950 correction),
+        # committed under profiles/.  NOT measured by this run — the source file is named in the record.
+        pmc_path = newest_profile("r*_pmc_traffic.json") if args.config == "C3" else None
+        if pmc_path:
             for k, v in json.load(open(pmc_path)).items():
                 if kname in k:
-                    traffic = int(v["hbm_bytes_per_launch"])
-        # measured VALU issue occupancy of the two blend kernels (SQ_ACTIVE_INST_VALU ÷ SIMD quad-cycles of the
-        # launch, rocprofv3 PMC passes of this command at C3 — profiles/r01_v16_pmc_sq.json): the bound that matters
-        valu_busy = {}
-        sq_path = os.path.join(ROOT, "profiles", "r01_v16_pmc_sq.json")
-        if args.config == "C3" and os.path.exists(sq_path):
+                    rf["roofline"]["traffic"] = int(v["hbm_bytes_per_launch"])
+            rf["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmc_path)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                f"passes of this command, collected separately — not measured in this run")
+        rf["roofline"]["note"] = ("blend kernels are fp32-VALU-issue-bound (≈160 flop per list-entry byte), not HBM-bound; "
+                                  "see blend_valu_issue and DESIGN.md §4")
+        # the bound that matters for the two blend kernels: wave-level VALU instructions actually EXECUTED
+        # (SQ_INSTS_VALU, rocprofv3 PMC passes of this command at C3 — scripts/pmc_sq.sh) ÷ the non-packed fp32 issue
+        # peak (1024 SIMDs × 2.4 GHz ÷ 4 cycles per wave64 instruction) over the kernel's HIP-event time of THIS run
+        valu = None
+        sq_path = newest_profile("r*_pmc_sq.json") if args.config == "C3" else None
+        if sq_path:
+            valu = {"peak_wave_insts_per_s": VALU_WAVE_INSTS_PER_S,
+                    "source": f"profiles/{os.path.basename(sq_path)} (instruction counts; collected separately, not in this run)"}
             for k, v in json.load(open(sq_path)).items():
-                for short, kn in (("fwd", "blend_fwd_kernel"), ("bwd", "blend_bwd_kernel")):
-                    if kn in k:
-                        valu_busy[short] = v["valu_busy_frac_at_2p4GHz"]
+                for short, kn, st_key in (("fwd", "blend_fwd_kernel", "fwd_blend_ms"), ("bwd", "blend_bwd_kernel", "bwd_blend_ms")):
+                    if kn in k and v.get("insts_valu"):
+                        t_s = stages[st_key] * 1e-3
+                        valu[short] = {"insts_valu": int(v["insts_valu"]), "kernel_ms": round(stages[st_key], 4),
+                                       "issue_frac": round(v["insts_valu"] / t_s / VALU_WAVE_INSTS_PER_S, 4),
+                                       "valu_busy_frac_pmc": v.get("valu_busy_frac_at_2p4GHz")}
         rec = {
             "metric": "Gaussian raster fwd+bwd Mpix/s @1M Gaussians 1080p",
             "value": round(world * W * H * args.steps / elapsed / 1e6, 3),
@@ -286,30 +489,17 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH deg {D}, profile {cfg['profile']}, "
                                    f"fwd+bwd incl. camera gradient, 1 frame per GPU" +
-                                   (", RCCL all-reduce of the camera gradient" if world > 1 else "") +
-                                   (f" + of {args.grad_buffer_floats} stand-in fp32 grads"
-                                    if world > 1 and args.grad_buffer_floats else ""),
+                                   (f", one RCCL mean all-reduce per step of {G} stand-in parameter-gradient floats + the "
+                                    f"camera gradient ({args.exchange_mode})" if world > 1 else ""),
                        "num_rendered": N, "parallelism": f"frames x{world}"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes": ab[dom], "kernel_ms": round(kernel_ms[dom], 4),
-                         "note": "blend kernels are fp32-VALU/exp-bound (≈160 flop per list-entry byte), not "
-                                 "HBM-bound; see DESIGN.md §4"},
-            "render_forward": {"ms": round(t_fwd, 4), "algorithmic_bytes": b_fwd,
-                               "hbm_frac": round(b_fwd / (t_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-            "render_backward": {"ms": round(t_bwd, 4), "algorithmic_bytes": b_bwd,
-                                "hbm_frac": round(b_bwd / (t_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "step_ms_hip_events": percentiles(per_step),
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
-            # informational: the blend kernels against the fp32 VECTOR roofline (they are VALU-, not HBM-bound).
-            # Algorithmic flops are SURVEY.md §8(d)'s: 20 flop per (list entry, pixel of its tile) forward, 2.5x
-            # that backward.  The exact quadrant cull skips most of those evaluations, so the "algorithmic"
-            # rate may exceed the 157.3 TFLOP/s peak — that excess is the cull, not a faster ALU.
-            "blend_valu_roofline": {
-                "peak_tflops": 157.3, "valu_busy_frac_pmc": valu_busy or None,
-                "fwd": {"algorithmic_flops": 20 * N * 256, "tflops": round(20 * N * 256 / (kernel_ms["fwd_blend"] * 1e-3) / 1e12, 1)},
-                "bwd": {"algorithmic_flops": 50 * N * 256, "tflops": round(50 * N * 256 / (kernel_ms["bwd_blend"] * 1e-3) / 1e12, 1)},
-            },
         }
+        rec.update(rf)
+        if valu:
+            rec["blend_valu_issue"] = valu
+        if multi:
+            rec["multi_gpu"] = multi
         if graph_rec is not None:
             rec["hipgraph_replay"] = graph_rec
         if world == 1 and not args.no_callsite:
@@ -321,8 +511,26 @@ def main():
                 log(f"call site at GGRt's shape: {rec['callsite_ggrt_shape']}")
             except Exception as e:
                 log(f"call-site leg skipped: {type(e).__name__}: {e}")
+        if world == 1 and not args.no_secondary and args.config == "C3":
+            sec = {}
+            for name, fwd_only in (("C5p", False), ("C4p", True), ("C3_lower_half", False)):
+                try:
+                    sec[name] = secondary_record(name, CONFIGS[name], dev, steps=max(10, args.steps), warmup=3, fwd_only=fwd_only)
+                    log(f"secondary {name}: {sec[name]['ms_per_step']} ms, fwd hbm_frac {sec[name]['render_forward']['hbm_frac']}")
+                except Exception as e:
+                    log(f"secondary {name} skipped: {type(e).__name__}: {e}")
+            rec["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(cfg, seed=0)
+            try:
+                rec["cpu_baseline"] = cpu_baseline_c_oracle(wl.sc_cpu, wl.dL.cpu().numpy())
+            except Exception as e:
+                log(f"C-oracle baseline failed ({type(e).__name__}: {e})")
+            try:
+                rec["cpu_baseline_torch"] = cpu_baseline_torch(cfg, seed=0)
+            except Exception as e:
+                log(f"torch baseline skipped: {type(e).__name__}: {e}")
+            if "cpu_baseline" not in rec and "cpu_baseline_torch" in rec:
+                rec["cpu_baseline"] = rec.pop("cpu_baseline_torch")
         print(json.dumps(rec), flush=True)
     parallel.shutdown()
 

@@ -25,7 +25,6 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import threading
-import weakref
 from typing import NamedTuple, Optional
 
 import torch
@@ -213,7 +212,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 prof.fwd_calls += 1
             _check(lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream), "ggr_forward")
 
-        _tls.last_forward = (weakref.ref(geom), P)  # weak: the ≈100 MB geometry buffer lives as long as its graph
+        # exact mode: count known, nothing to keep.  Sync-free mode: count + flags live in the geometry buffer on the
+        # device, so that (≈100 MB at P = 1 M) buffer stays referenced until this thread's next forward
+        _tls.last_forward = (geom, P) if capacity > 0 else (None, int(fout.num_rendered))
         ctx.raster_settings = rs
         ctx.num_rendered = int(fout.num_rendered)
         ctx.dims = (P, M, H, W)
@@ -326,9 +327,9 @@ def last_forward_status():
     last = getattr(_tls, "last_forward", None)
     if last is None:
         raise RuntimeError("no forward has run on this thread")
-    geom, P = last[0](), last[1]
-    if geom is None:
-        raise RuntimeError("the most recent forward's buffers have been released (its autograd graph is gone)")
+    geom, P = last
+    if geom is None:  # exact mode: ggr_forward itself read the count back (and fails on a sort fault)
+        return P, False
     lib = _lib.load()
     n, ov = C.c_int64(0), C.c_int32(0)
     with torch.cuda.device(geom.device):

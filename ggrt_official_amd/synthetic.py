@@ -85,7 +85,10 @@ def camera_matrices(width: int, height: int, fov_x_deg: float = 60.0, near: floa
 
 
 def make_scene(num_points: int, width: int, height: int, sh_degree: int = 3, profile: str = "A", seed: int = 0,
-               sh_stride: int | None = None, c2w: torch.Tensor | None = None, device="cpu") -> Scene:
+               sh_stride: int | None = None, c2w: torch.Tensor | None = None, device="cpu",
+               layout: str = "uniform") -> Scene:
+    """``layout="lower_half"``: the same Gaussians squeezed into the lower half of the frame (upper half empty — a
+    frame with sky): the spatially NON-uniform variant the benchmark reports next to the uniform one."""
     g = torch.Generator().manual_seed(seed)
     P = num_points
     view, full, campos, tanfovx, tanfovy, fx_n, fy_n = camera_matrices(width, height, c2w=c2w)
@@ -113,6 +116,10 @@ def make_scene(num_points: int, width: int, height: int, sh_degree: int = 3, pro
         opacity = torch.softmax(logits, -1).max(-1).values / 3.0
     else:
         raise ValueError(f"unknown profile {profile!r}")
+    if layout == "lower_half":
+        v = 0.5 * height + 0.5 * v
+    elif layout != "uniform":
+        raise ValueError(f"unknown layout {layout!r}")
     z = torch.exp(math.log(1.5) + rand(P) * (math.log(50.0) - math.log(1.5)))
     # unproject (camera frame == world frame for the identity pose; otherwise transform by c2w)
     xc = (u - 0.5 * width) / fpx * z
@@ -162,6 +169,7 @@ CONFIGS = {
     "C1": dict(num_points=10_000, width=256, height=256, sh_degree=0, profile="A"),
     "C2": dict(num_points=200_000, width=504, height=378, sh_degree=3, profile="A"),
     "C3": dict(num_points=1_000_000, width=1920, height=1080, sh_degree=3, profile="A"),
+    "C3_lower_half": dict(num_points=1_000_000, width=1920, height=1080, sh_degree=3, profile="A", layout="lower_half"),
     "C4p": dict(num_points=1_146_880, width=448, height=320, sh_degree=4, profile="B"),
     "C5p": dict(num_points=1_013_760, width=480, height=352, sh_degree=4, profile="B"),
     # Waymo eval shape (reference waymo.py:88-90: 640×960, 5 source views → 4·2·640·960 Gaussians): scale check

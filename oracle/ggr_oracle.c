@@ -42,6 +42,7 @@
  * the *more* accurate side of every comparison.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -713,3 +714,4 @@ void ggo_preprocess_backward(int P, int D, int M, const float* means3D, const fl
 }
 
 int ggo_abi_version(void) { return 2; }
+int ggo_num_threads(void) { return omp_get_max_threads(); }

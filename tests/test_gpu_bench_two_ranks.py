@@ -1,0 +1,45 @@
+"""bench.py's N > 1 control flow on the 1-GPU box (`-m gpu`): two ranks launched exactly as the driver launches
+them (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 …`), sharing device 0 over gloo
+(`--dist-backend gloo --device 0`; RCCL needs one GPU per rank).  Every rank renders its own frame, the step's one
+exchange (stand-in parameter gradients + camera gradient in one flat buffer) runs in both modes, the timing
+reductions and barriers execute, and rank 0 prints the contract line with `n_gpus == 2` and the `multi_gpu` legs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["overlap", "serial"])
+def test_bench_two_ranks_share_one_gpu(mode):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--config", "C2", "--dist-backend", "gloo", "--device", "0", "--grad-buffer-floats", "300000",
+           "--exchange-mode", mode, "--profile-steps", "1"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # ONE JSON line, from rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["parallelism"] == "frames x2"
+    mg = rec["multi_gpu"]
+    assert mg["timed_loop_mode"] == mode
+    for k in ("raster_ms", "allreduce_ms", "serial_ms_per_step", "overlapped_ms_per_step"):
+        assert mg[k] > 0, k
+    assert "cpu_baseline" not in rec and "secondary" not in rec   # rank 0 at N = 1 only
