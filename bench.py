@@ -75,7 +75,9 @@ def percentiles(ms: list) -> dict:
 
 
 def newest_profile(pattern: str):
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    import re
+    nat = lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))]  # r02_v10 > r02_v9
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=nat)
     return files[-1] if files else None
 
 

@@ -1,0 +1,33 @@
+"""Dev tool (GPU box): where does the HIP-vs-oracle gradient difference of a full-size config concentrate?
+usage: python scripts/grad_outliers.py C3"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from ggrt_official_amd.synthetic import CONFIGS, make_scene, upstream_gradient
+from oracle import c_oracle
+from tests.helpers import hip_forward_backward, oracle_forward, rel_l2
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+sc = make_scene(seed=0, **CONFIGS[name])
+dL = upstream_gradient(sc.width, sc.height)
+st = oracle_forward(sc)
+ref = c_oracle.backward(st, dL.numpy())
+color, radii, depth, grads = hip_forward_backward(sc, dL)
+for k in ("means3D", "means2D", "shs", "opacities", "cov3D_precomp"):
+    a, b = grads[k].reshape(len(radii), -1).astype(np.float64), ref[k].reshape(len(radii), -1).astype(np.float64)
+    err = np.linalg.norm(a - b, axis=1)
+    nb = np.linalg.norm(b, axis=1)
+    tot = np.linalg.norm(b)
+    order = np.argsort(-err)[:8]
+    print(f"== {k}: rel_l2 {rel_l2(a, b):.3e}; |ref| {tot:.3e}; top-8 error share "
+          f"{np.sqrt((err[order] ** 2).sum()) / max(np.linalg.norm(err), 1e-300):.3f}")
+    for g in order:
+        print(f"   g={g} err={err[g]:.3e} |ref_g|={nb[g]:.3e} radius={st.radii[g]} depth={st.depth[g]:.4f} "
+              f"xy=({st.xy[g, 0]:.1f},{st.xy[g, 1]:.1f}) opacity={st.conic_opacity[g, 3]:.3f} tiles={st.tiles_touched[g]}")
+    # the same comparison with the 8 worst Gaussians left out
+    mask = np.ones(len(radii), bool)
+    mask[order] = False
+    print(f"   without them: rel_l2 {rel_l2(a[mask], b[mask]):.3e}")

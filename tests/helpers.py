@@ -9,13 +9,15 @@ from oracle import c_oracle
 
 
 # ---- parity bars (BASELINE.json north_star: images "within 1e-4", gradients within 1e-3 rel-L2) -----------------
-# The bars below are ONE ORDER above what the HIP path measures against the C oracle on an MI355X (round 2:
-# image PSNR ≈ 146 dB, per-tensor gradient rel-L2 5e-7 … 2e-6), not the north-star's loose ones: a regression of
-# an order of magnitude fails.  A threshold flip (α within an ulp of 1/255, T·(1-α) of 1e-4) moves one pixel by at
-# most ≈ 4e-3·|c|; ≤ 0.02 % such pixels are allowed, everything else must agree to FWD_ATOL.
+# The bars below are ONE ORDER above what the HIP path measures against the C oracle on an MI355X (round 2,
+# gpurun_out/parity_metrics.jsonl over all -m gpu tests incl. the full-size frames): peak-normalised image PSNR
+# 119 … 148 dB (the full-size frames sit at the low end: a handful of threshold flips out of 2 M pixels dominate
+# their MSE), ≤ 7e-6 of the pixels off by more than 1e-4, per-tensor gradient rel-L2 5e-7 … 4e-6 — not the
+# north-star's loose figures: a regression of an order of magnitude fails.  A threshold flip (α within an ulp of
+# 1/255, T·(1-α) of 1e-4) moves one pixel by at most ≈ 4e-3·|c|; everything else must agree to FWD_ATOL.
 FWD_ATOL = 1e-4
-FLIP_FRACTION = 2e-4
-PSNR_MIN = 120.0
+FLIP_FRACTION = 5e-5
+PSNR_MIN = 110.0
 GRAD_RTOL = 2e-5
 
 
@@ -35,11 +37,12 @@ def record_metric(tag: str, **kv):
 
 def check_image(img, ref, name="color", tag="", psnr_min=None, flip_fraction=None):
     d = np.abs(np.asarray(img, np.float64) - np.asarray(ref, np.float64))
-    bad = float((d > FWD_ATOL).mean())
-    p = psnr(img, ref)
+    peak = max(1.0, float(np.abs(ref).max()))  # depth images are not in [0, 1]: PSNR relative to the peak value
+    bad = float((d > FWD_ATOL * peak).mean())
+    p = psnr(img, ref) + 20.0 * np.log10(peak)
     record_metric(tag or name, kind=0, psnr=min(p, 999.0), flip_frac=bad, max_abs=float(d.max()))
-    assert bad <= (FLIP_FRACTION if flip_fraction is None else flip_fraction), f"{name}: {bad:.2e} of pixels differ by > {FWD_ATOL}"
-    assert d.max() <= 0.02 * max(1.0, float(np.abs(ref).max())), f"{name}: max abs diff {d.max()}"
+    assert bad <= (FLIP_FRACTION if flip_fraction is None else flip_fraction), f"{name}: {bad:.2e} of pixels differ by > {FWD_ATOL * peak}"
+    assert d.max() <= 0.02 * peak, f"{name}: max abs diff {d.max()}"
     assert p >= (PSNR_MIN if psnr_min is None else psnr_min), f"{name}: PSNR {p:.1f} dB"
 
 
