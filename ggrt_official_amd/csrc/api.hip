@@ -167,8 +167,9 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
         uint32_t *zero_area = nullptr, zero_words = 0;
         ggr::tile_list_gather_targets(plan, work, tiles, &rect_sorted, &zero_area, &zero_words);
         // (preprocess already wrote the keys into g.keys_a and the identity permutation into g.vals_a)
-        ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, 32, &dk, &order, s,
-                              /*hist_zeroed=*/true /*by preprocess_fwd*/, g.rect, rect_sorted, zero_area, zero_words);
+        ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, &dk, &order, s,
+                              /*hist_zeroed=*/true /*by preprocess_fwd*/, /*block_max_ready=*/true /*likewise*/, g.rect,
+                              rect_sorted, zero_area, zero_words);
         KCHECK(dbg, s, "depth sort");
     }
     tm.mark();
@@ -211,7 +212,7 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
             num_rendered = (two[1] & 2u) ? 0xFFFFFFFFu : two[0];
         }
         if (num_rendered == 0xFFFFFFFFu)  // raised by the scan kernel, see bin_tile_scan_kernel
-            return fail(GGR_E_HIP, "depth sort: a look-back spin hit its bound (GPU preempted or halted?); frame not rendered");
+            return fail(GGR_E_HIP, "depth sort fault: a look-back spin hit its bound (GPU preempted or halted?) or a view depth >= 6.8e37; frame not rendered");
         if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
         out->num_rendered = (int64_t)num_rendered;
         tm.mark();

@@ -1,4 +1,4 @@
-// binning.hip — the depth pre-sort of the tile binning for gfx950 (stable u32-key radix sort).
+// binning.hip — the depth pre-sort of the tile binning for gfx950 (stable u32-key radix sort, three passes).
 //
 // Part of what replaces the scan / duplicateWithKeys / 64-bit radix sort / identifyTileRanges stages of
 // the rasterizer behind reference cuda_splatting.py:114-125.
@@ -6,29 +6,23 @@
 // MI355X-first reformulation (identical resulting lists, far less traffic):
 //   the reference sorts N = Σ tiles_touched pairs by the 64-bit key (tile << 32 | depth_bits) — ≥6 radix
 //   passes over N·12 B.  Here only the P Gaussians (P ≪ N) are sorted, by depth bits, with the stable
-//   sort below (ties keep ascending id, 4 passes over P·8 B); tile_lists.hip then builds the per-tile
-//   lists from that order with a stable counting sort by tile that never materialises the N pairs.
+//   sort below (ties keep ascending id); tile_lists.hip then builds the per-tile lists from that order with
+//   a stable counting sort by tile that never materialises the N pairs.
 //
-// The radix sort is hand-written for wave64: one upfront histogram of all digits, then per 8-bit digit
-// ONE kernel ("onesweep") that ranks stably with ballot-based digit matching (8 ballots per 64 keys)
-// + per-wave digit counters in LDS and obtains its tile's global offsets by decoupled look-back.
+// Keys arrive as (depth bits − bits of 0.2f) (ggr_common.h GGR_KEY_BASE): the order is the same, the constant
+// high part of the float bits is gone, and so a real scene's keys have ≈ 27 significant bits — THREE passes of
+// ⌈bits/3⌉-bit digits instead of four 8-bit ones.  The digit width is found on the device (no host sync): every
+// preprocess block leaves the maximum of its keys, the histogram kernel reduces them and publishes the width.
+//
+// The sort is hand-written for wave64: one upfront histogram of the three digits, then per digit ONE kernel
+// ("onesweep") that ranks stably with ballot-based digit matching + per-wave digit counters in LDS, scans the
+// digit totals itself (no separate scan launch) and obtains its tile's global offsets by decoupled look-back.
 #include "ggr_common.h"
 
 namespace ggr {
 
-// ---------------------------------------------------------------------------------------------
-// radix sort ("onesweep": one kernel per 8-bit digit, decoupled look-back)
-// ---------------------------------------------------------------------------------------------
-// tile t owns keys [t*4096, (t+1)*4096); wave w of the workgroup owns a contiguous 1024-key slice,
+// tile t owns keys [t*4096, (t+1)*4096); wave w of the workgroup owns a contiguous 512-key slice,
 // round r of the wave covers 64 consecutive keys → order inside the tile is (wave, round, lane).
-//
-// Work area `hist` (u32 words):
-//   [0, 1024)                       digit totals of every pass            (global_hist kernel)
-//   [1024, 2048)                    exclusive digit bases of every pass   (global_scan kernel)
-//   [2048, 2048+64)                 tile tickets, one per pass; [2048+8] = spin-timeout flag
-//   [2112 + p*ntiles*256 ...)       look-back status words of pass p: status[tile][digit]
-// Every word that is polled or atomically incremented is zeroed by ONE hipMemsetAsync per sort
-// (MI355X guide §6 G16: re-initialise every call).
 //
 // Look-back protocol (guide §6 G16, recipe R2 — "the data IS the flag"): a status word is
 // (flag << 30) | count with flag 1 = tile aggregate, 2 = inclusive prefix; it is written with ONE
@@ -36,77 +30,95 @@ namespace ggr {
 // agent-scope atomic loads (bypass the reader's L1), so no fence is needed and no ordering between
 // different words is assumed.  Tiles take their index from an atomic ticket, so a tile only ever
 // waits for tiles whose workgroups are already running: no dispatch-order assumption.
+// A sort tile looks back GGR_LOOKBACK predecessors per trip (all loads in flight together): the ≈ 250 tiles of a
+// 1 M-key sort run in lockstep, a one-predecessor-per-trip chain is then ≈ √(2·tiles) dependent ≈ 1 µs polls long.
 
-#define GGR_HIST_TOTALS 0
-#define GGR_HIST_BASES 1024
-#define GGR_HIST_TICKETS 2048
-#define GGR_HIST_STATUS 2112
 #define GGR_FLAG_AGG 1u
 #define GGR_FLAG_INCL 2u
 #define GGR_COUNT_MASK 0x3FFFFFFFu
-#define GGR_SPIN_LIMIT (1u << 24)
+#define GGR_SPIN_LIMIT (1u << 22)
+#ifndef GGR_LOOKBACK
+#define GGR_LOOKBACK 8
+#endif
+#define GGR_FAULT_SPIN 1u   // a look-back spin hit its bound
+#define GGR_FAULT_RANGE 2u  // a key needs more than 3 × 10 bits (depth ≥ 6.8e37)
 
-// digit totals of all passes in one read of the keys
-__global__ void __launch_bounds__(256)
-radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int npasses, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[4][GGR_RADIX];
-    const int tid = threadIdx.x;
+#ifdef GGR_SORT_PROBE  // dev build (tools/sort_bench.hip): per-tile phase timestamps, 100 MHz constant clock
+__device__ unsigned long long ggr_probe[3][8][2048];
+#define PROBE(k) do { if (threadIdx.x == 0 && tile < 2048) ggr_probe[pass][k][tile] = wall_clock64(); } while (0)
+#else
+#define PROBE(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
-    for (int p = 0; p < 4; p++) h[p][tid] = 0;
-    __syncthreads();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    // four keys per thread per trip, all four loads issued before the first use (the kernel is latency-bound)
-    constexpr int U = 4;
-    for (size_t idx0 = (size_t)blockIdx.x * blockDim.x + tid; idx0 < ((n + 255) & ~(size_t)255); idx0 += stride * U) {
-        uint32_t ks[U];
-        bool vs[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const size_t idx = idx0 + (size_t)u * stride;
-            vs[u] = idx < n;
-            ks[u] = vs[u] ? keys[idx] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const bool valid = vs[u];
-            const uint32_t k = ks[u];
-            for (int p = 0; p < npasses; p++) {
-                const uint32_t d = (k >> (8 * p)) & 255u;
-                // wave-aggregate the (very common) case of a digit shared by the whole wave
-                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-                const uint64_t act = __ballot(valid);
-                if (__ballot(valid && d == d0) == act) {
-                    if (valid && (uint32_t)__builtin_ctzll(act) == (uint32_t)(tid & 63)) atomicAdd(&h[p][d0], (uint32_t)__popcll(act));
-                } else if (valid) {
-                    atomicAdd(&h[p][d], 1u);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int p = 0; p < npasses; p++) {
-        const uint32_t c = h[p][tid];
-        if (c) atomicAdd(&hist[GGR_HIST_TOTALS + p * GGR_RADIX + tid], c);
-    }
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    return v;
 }
 
-// exclusive scan of each pass's 256 totals → digit bases (one block, thread d = digit d)
-__global__ void __launch_bounds__(256)
-radix_global_scan_kernel(int npasses, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t sh[256];
+// one maximum per 256 keys (what preprocess_fwd leaves behind; only tools/sort_bench.hip launches this)
+__global__ void __launch_bounds__(GGR_PRE_THREADS)
+radix_block_max_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __restrict__ block_max) {
+    __shared__ uint32_t wm[GGR_PRE_THREADS / 64];
+    const size_t i = (size_t)blockIdx.x * GGR_PRE_THREADS + threadIdx.x;
+    const uint32_t m = wave_max_u32(i < n ? keys[i] : 0u);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) block_max[blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+}
+
+// digit totals of all three passes in one read of the keys.  Every block first reduces the producer blocks' key
+// maxima (n/256 words, one round trip, in flight together with its keys) to the digit width.
+#define GGR_HIST_THREADS 1024
+#define GGR_HIST_ITEMS 8
+__global__ void __launch_bounds__(GGR_HIST_THREADS)
+radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __restrict__ hist,
+                         const uint32_t* __restrict__ block_max, uint32_t nmax) {
+    __shared__ uint32_t h[GGR_SORT_PASSES][GGR_SORT_MAX_BINS];
+    __shared__ uint32_t wm[GGR_HIST_THREADS / 64];
     const int tid = threadIdx.x;
-    for (int p = 0; p < npasses; p++) {
-        const uint32_t v = hist[GGR_HIST_TOTALS + p * GGR_RADIX + tid];
-        sh[tid] = v;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const uint32_t t = tid >= off ? sh[tid - off] : 0u;
-            __syncthreads();
-            sh[tid] += t;
-            __syncthreads();
+    // this block's keys: all loads issued before anything waits (the kernel is latency-bound)
+    uint32_t ks[GGR_HIST_ITEMS];
+    const size_t base = (size_t)blockIdx.x * (GGR_HIST_THREADS * GGR_HIST_ITEMS);
+#pragma unroll
+    for (int u = 0; u < GGR_HIST_ITEMS; u++) {
+        const size_t idx = base + (size_t)u * GGR_HIST_THREADS + tid;
+        ks[u] = idx < n ? keys[idx] : 0xFFFFFFFFu;   // (0xFFFFFFFF marks "no key": real keys are < 2^31)
+    }
+    uint32_t m = 0;
+    for (uint32_t i0 = 0; i0 < nmax; i0 += 4 * GGR_HIST_THREADS) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = block_max[min(i0 + u * GGR_HIST_THREADS + tid, nmax - 1)];
+        m = max(max(m, v[0]), max(v[1], max(v[2], v[3])));
+    }
+    for (int x = tid; x < GGR_SORT_PASSES * GGR_SORT_MAX_BINS; x += GGR_HIST_THREADS) (&h[0][0])[x] = 0;
+    m = wave_max_u32(m);
+    if ((tid & 63) == 0) wm[tid >> 6] = m;
+    __syncthreads();
+    m = wave_max_u32(wm[tid & 15]);  // (lanes 0..15 hold the 16 wave maxima, the others repeat them)
+    const uint32_t bits = m ? 32u - (uint32_t)__builtin_clz(m) : 1u;
+    uint32_t w = (bits + 2u) / 3u;
+    if (w > GGR_SORT_MAX_BITS) {
+        w = GGR_SORT_MAX_BITS;
+        if (tid == 0 && blockIdx.x == 0) atomicOr(&hist[GGR_HIST_FAULT], GGR_FAULT_RANGE);
+    }
+    if (tid == 0 && blockIdx.x == 0) hist[GGR_HIST_PARAMS] = w;   // (read by the pass kernels: later launches)
+    const uint32_t mask = (1u << w) - 1u;
+#pragma unroll
+    for (int u = 0; u < GGR_HIST_ITEMS; u++) {
+        if (ks[u] != 0xFFFFFFFFu) {
+            atomicAdd(&h[0][ks[u] & mask], 1u);
+            atomicAdd(&h[1][(ks[u] >> w) & mask], 1u);
+            atomicAdd(&h[2][(ks[u] >> (2u * w)) & mask], 1u);
         }
-        hist[GGR_HIST_BASES + p * GGR_RADIX + tid] = sh[tid] - v;
-        __syncthreads();
+    }
+    __syncthreads();
+    const uint32_t bins = 1u << w;
+    for (uint32_t x = tid; x < GGR_SORT_PASSES * bins; x += GGR_HIST_THREADS) {
+        const uint32_t p = x >> w, d = x & mask;
+        const uint32_t c = h[p][d];
+        if (c) atomicAdd(&hist[GGR_HIST_TOTALS + p * GGR_SORT_MAX_BINS + d], c);
     }
 }
 
@@ -120,16 +132,32 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
                       uint32_t ntiles, uint32_t* __restrict__ hist, const uint2* __restrict__ gather_src,
                       uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
     constexpr int NW = GGR_SORT_THREADS / 64;
-    __shared__ uint32_t wcount[NW][GGR_RADIX];  // per-wave digit counters, later per-wave output bases
+    constexpr int DPT = GGR_SORT_MAX_BINS / GGR_SORT_THREADS;  // digits per thread at the widest digit
+    __shared__ uint16_t wcount[NW][GGR_SORT_MAX_BINS];  // per-wave digit counters (a wave holds 512 keys), later per-wave prefixes
+    __shared__ uint32_t dbase[GGR_SORT_MAX_BINS];       // global start of this tile's run of every digit
+    __shared__ uint32_t texcl[GGR_SORT_MAX_BINS];       // start of that run inside the tile's locally sorted order
+    __shared__ uint2 sorted[GGR_SORT_TILE];             // the tile's (key, val) pairs — then its payloads — in output order
+    __shared__ uint32_t wsum[NW];
     __shared__ uint32_t tile_sh;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int shift = pass * GGR_RADIX_BITS;
     if (tid == 0) tile_sh = atomicAdd(&hist[GGR_HIST_TICKETS + pass], 1u);
-    for (int x = tid; x < NW * GGR_RADIX; x += GGR_SORT_THREADS) (&wcount[0][0])[x] = 0;
+    const uint32_t w = hist[GGR_HIST_PARAMS];            // bits per digit (block-uniform)
+    const uint32_t bins = 1u << w, mask = bins - 1u;
+    const uint32_t shift = (uint32_t)pass * w;
+    // this pass's digit totals, requested now (they are final: the histogram kernel has ended)
+    uint32_t tot[DPT];
+#pragma unroll
+    for (int q = 0; q < DPT; q++) {
+        const uint32_t d = tid + q * GGR_SORT_THREADS;
+        tot[q] = d < bins ? hist[GGR_HIST_TOTALS + pass * GGR_SORT_MAX_BINS + d] : 0u;
+    }
+    for (uint32_t x = tid; x < NW * GGR_SORT_MAX_BINS / 2; x += GGR_SORT_THREADS)
+        reinterpret_cast<uint32_t*>(&wcount[0][0])[x] = 0u;
     __syncthreads();
     const uint32_t tile = tile_sh;
-    uint32_t* status = hist + GGR_HIST_STATUS + (size_t)pass * ntiles * GGR_RADIX;
+    PROBE(0);
+    uint32_t* status = hist + GGR_HIST_STATUS + ((size_t)pass * ntiles << GGR_SORT_MAX_BITS);
 
     const size_t base = (size_t)tile * GGR_SORT_TILE + (size_t)wave * (64 * GGR_SORT_ITEMS);
     uint32_t key[GGR_SORT_ITEMS], val[GGR_SORT_ITEMS], rank[GGR_SORT_ITEMS];
@@ -143,8 +171,8 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     }
     uint2 pay[GATHER ? GGR_SORT_ITEMS : 1];
     if (GATHER) {
-        for (uint32_t w = blockIdx.x * GGR_SORT_THREADS + tid; w < zero_words; w += gridDim.x * GGR_SORT_THREADS)
-            zero_area[w] = 0u;
+        for (uint32_t wz = blockIdx.x * GGR_SORT_THREADS + tid; wz < zero_words; wz += gridDim.x * GGR_SORT_THREADS)
+            zero_area[wz] = 0u;
         // issued now, consumed after the ranking and the look-back: the random 8-B reads hide behind them
 #pragma unroll
         for (int r = 0; r < GGR_SORT_ITEMS; r++) {
@@ -152,106 +180,224 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
             pay[r] = idx < n ? gather_src[val[r]] : make_uint2(0u, 0u);
         }
     }
+    // exclusive scan of the digit totals → global digit bases (was a separate one-block launch): thread d owns
+    // digits d and d + 512; wave scan + the 8 wave sums, the second half continues the first
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int q = 0; q < DPT; q++) {
+            if ((uint32_t)q * GGR_SORT_THREADS < bins) {  // (block-uniform)
+                uint32_t incl = tot[q];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+                    if (lane >= off) incl += t;
+                }
+                if (lane == 63) wsum[wave] = incl;
+                __syncthreads();
+                uint32_t before = run;
+#pragma unroll
+                for (int ww = 0; ww < NW; ww++) {
+                    const uint32_t sw = wsum[ww];
+                    if (ww < wave) before += sw;
+                    run += sw;
+                }
+                const uint32_t d = tid + q * GGR_SORT_THREADS;
+                if (d < bins) dbase[d] = before + incl - tot[q];
+                __syncthreads();
+            }
+        }
+    }
+    PROBE(1);
     // wave-private counters: plain LDS accesses, ordered by wavefront-scope fences (LDS executes a wave's
     // operations in order; a `volatile` pointer here compiles to flat_load/flat_store + s_waitcnt vmcnt(0))
-    uint32_t* wc = wcount[wave];
+    uint16_t* wc = wcount[wave];
+    // (a) the match masks of all eight rounds first — ballots only, the rounds are independent of each other —
+    // (b) then the chain through the wave's counters: two dependent LDS operations per round and nothing else
+    // (with the ballots inside the chain a round cost ≈ 0.4 µs: tools/sort_bench.hip -DGGR_SORT_PROBE)
+    uint32_t before[GGR_SORT_ITEMS], cnt[GGR_SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < GGR_SORT_ITEMS; r++) {
+        const size_t idx = base + r * 64 + lane;
+        const uint32_t d = (key[r] >> shift) & mask;
+        uint64_t m = __ballot(idx < n);
+#pragma unroll
+        for (int b = 0; b < GGR_SORT_MAX_BITS; b++) {
+            if ((uint32_t)b < w) {  // (uniform)
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+        }
+        // m = valid lanes of this round holding the same digit
+        before[r] = (uint32_t)__popcll(m & lt_mask);
+        cnt[r] = (uint32_t)__popcll(m);
+    }
 #pragma unroll
     for (int r = 0; r < GGR_SORT_ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
         const bool valid = idx < n;
-        const uint32_t d = (key[r] >> shift) & (GGR_RADIX - 1);
-        uint64_t m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < GGR_RADIX_BITS; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
-        }
-        // m = valid lanes of this round holding the same digit
-        const uint32_t before = (uint32_t)__popcll(m & lt_mask);
-        const uint32_t cnt = (uint32_t)__popcll(m);
+        const uint32_t d = (key[r] >> shift) & mask;
         uint32_t prev = 0;
         if (valid) prev = wc[d];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (valid && before == 0) wc[d] = prev + cnt;
+        if (valid && before[r] == 0) wc[d] = (uint16_t)(prev + cnt[r]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        rank[r] = prev + before;
+        rank[r] = prev + before[r];
     }
+    PROBE(2);
     __syncthreads();
-    // thread d < 256 owns digit d: publish the tile aggregate, look back, publish the inclusive prefix
-    uint32_t cw[NW], g = 0;
-    if (tid < GGR_RADIX) {
-        uint32_t total = 0;
+    PROBE(3);
+    // thread d owns digits d (and d + 512): publish the tile aggregate, look back, publish the inclusive prefix;
+    // then dbase[d] = global start of this tile's run of digit d, wcount[w][d] = wave w's offset inside that run
+    uint32_t dtot[DPT];
 #pragma unroll
-        for (int w = 0; w < NW; w++) { cw[w] = wcount[w][tid]; total += cw[w]; }
-        uint32_t* mine = status + (size_t)tile * GGR_RADIX + tid;
-        __hip_atomic_store(mine, ((tile == 0 ? GGR_FLAG_INCL : GGR_FLAG_AGG) << 30) | total, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        if (tile > 0) {
-            uint32_t t = tile - 1, spins = 0;
-            for (;;) {
-                const uint32_t v = __hip_atomic_load(status + (size_t)t * GGR_RADIX + tid, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t flag = v >> 30;
-                if (flag == 0) {
-                    if (++spins > GGR_SPIN_LIMIT) { hist[GGR_HIST_TICKETS + 8] = 1u; break; }  // never hang
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                excl += v & GGR_COUNT_MASK;
-                if (flag == GGR_FLAG_INCL || t == 0) break;
-                t--;
-            }
-            __hip_atomic_store(mine, (GGR_FLAG_INCL << 30) | ((excl + total) & GGR_COUNT_MASK), __ATOMIC_RELAXED,
+    for (int q = 0; q < DPT; q++) {
+        const uint32_t d = tid + q * GGR_SORT_THREADS;
+        dtot[q] = 0;
+        if (d < bins) {
+            uint32_t cw[NW], total = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) { cw[ww] = wcount[ww][d]; total += cw[ww]; }
+            uint32_t* mine = status + (size_t)tile * bins + d;
+            __hip_atomic_store(mine, ((tile == 0 ? GGR_FLAG_INCL : GGR_FLAG_AGG) << 30) | total, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        }
-        g = hist[GGR_HIST_BASES + pass * GGR_RADIX + tid] + excl;
-    }
-    __syncthreads();
-    if (tid < GGR_RADIX) {
-        uint32_t run = g;
+            uint32_t excl = 0;
+            if (tile > 0) {
+                int t = (int)tile - 1;
+                uint32_t spins = 0;
+                bool done = false;
+                while (!done) {
+                    uint32_t v[GGR_LOOKBACK];
 #pragma unroll
-        for (int w = 0; w < NW; w++) { wcount[w][tid] = run; run += cw[w]; }
+                    for (int j = 0; j < GGR_LOOKBACK; j++)
+                        v[j] = __hip_atomic_load(status + (size_t)max(t - j, 0) * bins + d, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                    int used = 0;
+#pragma unroll
+                    for (int j = 0; j < GGR_LOOKBACK; j++) {
+                        if (!done && used == j && t - j >= 0) {
+                            const uint32_t flag = v[j] >> 30;
+                            if (flag != 0) {
+                                excl += v[j] & GGR_COUNT_MASK;
+                                used = j + 1;
+                                if (flag == GGR_FLAG_INCL || t - j == 0) done = true;
+                            }
+                        }
+                    }
+                    t -= used;
+                    if (!done && used == 0) {
+                        if (++spins > GGR_SPIN_LIMIT) { atomicOr(&hist[GGR_HIST_FAULT], GGR_FAULT_SPIN); break; }  // never hang
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __hip_atomic_store(mine, (GGR_FLAG_INCL << 30) | ((excl + total) & GGR_COUNT_MASK), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // (only this thread touches digit d's column: no barrier between the reads above and these writes)
+            dbase[d] += excl;
+            dtot[q] = total;
+            uint32_t pre = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) { wcount[ww][d] = (uint16_t)pre; pre += cw[ww]; }
+        }
+    }
+    PROBE(4);
+    // exclusive scan of the tile's own digit counts → where each digit's run starts in the tile's sorted order
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int q = 0; q < DPT; q++) {
+            if ((uint32_t)q * GGR_SORT_THREADS < bins) {  // (block-uniform)
+                uint32_t incl = dtot[q];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+                    if (lane >= off) incl += t;
+                }
+                __syncthreads();  // (wsum: the previous round's readers are done)
+                if (lane == 63) wsum[wave] = incl;
+                __syncthreads();
+                uint32_t bef = run;
+#pragma unroll
+                for (int ww = 0; ww < NW; ww++) {
+                    const uint32_t sw = wsum[ww];
+                    if (ww < wave) bef += sw;
+                    run += sw;
+                }
+                const uint32_t d = tid + q * GGR_SORT_THREADS;
+                if (d < bins) texcl[d] = bef + incl - dtot[q];
+            }
+        }
     }
     __syncthreads();
+    PROBE(5);
+    // Local reorder: the tile's pairs go through LDS into (digit, wave, round, lane) order — the order of the output —
+    // and thread i then stores elements i, i + 512, …: consecutive lanes write consecutive addresses inside a digit's
+    // run instead of 64 unrelated 4-byte stores per instruction.
+    uint32_t lpos[GGR_SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < GGR_SORT_ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
-        if (idx < n) {
-            const uint32_t d = (key[r] >> shift) & (GGR_RADIX - 1);
-            const uint32_t pos = wcount[wave][d] + rank[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = val[r];
-            if (GATHER) gather_dst[pos] = pay[r];
+        const uint32_t d = (key[r] >> shift) & mask;
+        lpos[r] = texcl[d] + wcount[wave][d] + rank[r];
+        if (idx < n) sorted[lpos[r]] = make_uint2(key[r], val[r]);
+    }
+    __syncthreads();
+    const uint32_t tile_n = (uint32_t)min((size_t)GGR_SORT_TILE, n - (size_t)tile * GGR_SORT_TILE);
+    uint32_t gpos[GGR_SORT_ITEMS];
+#pragma unroll
+    for (int k = 0; k < GGR_SORT_ITEMS; k++) {
+        const uint32_t j = tid + k * GGR_SORT_THREADS;
+        gpos[k] = 0;
+        if (j < tile_n) {
+            const uint2 kv = sorted[j];
+            const uint32_t d = (kv.x >> shift) & mask;
+            gpos[k] = dbase[d] + (j - texcl[d]);
+            keys_out[gpos[k]] = kv.x;
+            vals_out[gpos[k]] = kv.y;
         }
     }
+    if (GATHER) {
+        __syncthreads();  // every pair has been read: the same LDS now carries the payloads
+#pragma unroll
+        for (int r = 0; r < GGR_SORT_ITEMS; r++) {
+            const size_t idx = base + r * 64 + lane;
+            if (idx < n) sorted[lpos[r]] = pay[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GGR_SORT_ITEMS; k++) {
+            const uint32_t j = tid + k * GGR_SORT_THREADS;
+            if (j < tile_n) gather_dst[gpos[k]] = sorted[j];
+        }
+    }
+    PROBE(6);
 }
 
-const uint32_t* radix_sort_fault_word(const uint32_t* hist) { return hist + GGR_HIST_TICKETS + 8; }
-
-size_t radix_hist_words(size_t n) { return GGR_HIST_STATUS + 4 * ggr_sort_blocks(n ? n : 1) * GGR_RADIX; }
+const uint32_t* radix_sort_fault_word(const uint32_t* hist) { return hist + GGR_HIST_FAULT; }
 
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                      uint32_t* hist, size_t n, int nbits, uint32_t** keys_out, uint32_t** vals_out,
-                      hipStream_t s, bool hist_zeroed, const uint2* gather_src, uint2* gather_dst,
+                      uint32_t* hist, size_t n, uint32_t** keys_out, uint32_t** vals_out,
+                      hipStream_t s, bool hist_zeroed, bool block_max_ready, const uint2* gather_src, uint2* gather_dst,
                       uint32_t* zero_area, uint32_t zero_words) {
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
-    const int npasses = (nbits + GGR_RADIX_BITS - 1) / GGR_RADIX_BITS;
-    if (n > 0 && npasses > 0) {
+    if (n > 0) {
         const uint32_t ntiles = (uint32_t)ggr_sort_blocks(n);
+        const uint32_t nmax = (uint32_t)((n + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS);
+        uint32_t* block_max = hist + ggr_sort_zero_words(n);
         if (!hist_zeroed)  // (ggr_forward: preprocess_fwd clears the area — one launch less)
-            (void)hipMemsetAsync(hist, 0, (GGR_HIST_STATUS + (size_t)npasses * ntiles * GGR_RADIX) * sizeof(uint32_t), s);
-        // one block per CU: the kernel ends with 256·npasses global atomics per block, and at 2048
-        // blocks those ≈2 M contended atomics cost more (≈45 µs) than reading the keys
-        // (64 blocks was tried for n ≈ 1 M: slower, 0.121 → 0.151 ms — each thread then walks 61 keys serially)
-        const unsigned hist_blocks = (unsigned)min((size_t)256, (n + 255) / 256);
-        hipLaunchKernelGGL(radix_global_hist_kernel, dim3(hist_blocks), dim3(256), 0, s, kin, n, npasses, hist);
-        hipLaunchKernelGGL(radix_global_scan_kernel, dim3(1), dim3(256), 0, s, npasses, hist);
-        for (int p = 0; p < npasses; p++) {
-            if (p == npasses - 1 && gather_src)
+            (void)hipMemsetAsync(hist, 0, ggr_sort_zero_words(n) * sizeof(uint32_t), s);
+        if (!block_max_ready)  // (ggr_forward: preprocess_fwd leaves them)
+            hipLaunchKernelGGL(radix_block_max_kernel, dim3(nmax), dim3(GGR_PRE_THREADS), 0, s, kin, n, block_max);
+        const unsigned hist_blocks =
+            (unsigned)((n + GGR_HIST_THREADS * GGR_HIST_ITEMS - 1) / (GGR_HIST_THREADS * GGR_HIST_ITEMS));
+        hipLaunchKernelGGL(radix_global_hist_kernel, dim3(hist_blocks), dim3(GGR_HIST_THREADS), 0, s, kin, n, hist,
+                           block_max, nmax);
+        for (int p = 0; p < GGR_SORT_PASSES; p++) {
+            if (p == GGR_SORT_PASSES - 1 && gather_src)
                 hipLaunchKernelGGL(radix_onesweep_kernel<true>, dim3(ntiles), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
                                    kout, vout, n, p, ntiles, hist, gather_src, gather_dst, zero_area, zero_words);
             else

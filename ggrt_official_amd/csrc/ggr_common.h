@@ -35,13 +35,21 @@
 #define GGR_ALPHA_MAX 0.99f
 #define GGR_T_MIN 0.0001f
 
-// radix sort geometry: 512 threads × 8 items = 4096 keys per tile (8 ranking rounds per wave instead of 16 with
-// 256 × 16: the rounds are a chain of dependent LDS round trips, and a tile per CU leaves room for 8 waves)
+// depth sort geometry (binning.hip): 512 threads × 8 items = 4096 keys per sort tile (8 ranking rounds per wave: the
+// rounds are a chain of dependent LDS round trips, and a tile per CU leaves room for 8 waves)
 #define GGR_SORT_THREADS 512
 #define GGR_SORT_ITEMS 8
 #define GGR_SORT_TILE (GGR_SORT_THREADS * GGR_SORT_ITEMS)
-#define GGR_RADIX_BITS 8
-#define GGR_RADIX 256
+// The sort key of a Gaussian is (float bits of its view depth) − GGR_KEY_BASE: every visible Gaussian has depth > 0.2
+// (the near cull), so its bits exceed those of 0.2f; culled Gaussians carry key 0 (they touch no tile — where they end
+// up in the order is irrelevant).  Subtracting the base removes the constant high part of the float bits: a scene
+// with depths in [0.2, 13 000) has 27-bit keys, and the sort takes THREE passes of ⌈bits/3⌉-bit digits (≤ 10 bits, i.e.
+// every depth below 6.8e37) instead of four 8-bit ones.
+#define GGR_KEY_BASE 0x3E4CCCCDu  // __float_as_uint(0.2f)
+#define GGR_SORT_PASSES 3
+#define GGR_SORT_MAX_BITS 10      // per digit
+#define GGR_SORT_MAX_BINS (1 << GGR_SORT_MAX_BITS)
+#define GGR_PRE_THREADS 256       // preprocess_fwd block size: one key maximum per block is left for the sort
 
 // tile-list builder: Gaussians (in depth order) per chunk
 #define GGR_BIN_CHUNK 1024
@@ -49,8 +57,20 @@
 static inline size_t ggr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) / GGR_SORT_TILE; }
-// words of sort work area: totals + bases + tickets (2112) + 4 passes of look-back status words
-static inline size_t ggr_sort_hist_words(size_t n) { return 2112 + 4 * ggr_sort_blocks(n ? n : 1) * GGR_RADIX; }
+// Sort work area (u32 words): digit totals of the 3 passes [0, 3072) | tickets, fault word, digit parameters
+// [3072, 3136) | look-back status words, 3 passes × tiles × 1024 | one key maximum per preprocess block.
+// Everything before the block maxima is zeroed by preprocess_fwd (ggr_sort_zero_words); the maxima are plain stores.
+#define GGR_HIST_TOTALS 0
+#define GGR_HIST_TICKETS (GGR_SORT_PASSES * GGR_SORT_MAX_BINS)
+#define GGR_HIST_FAULT (GGR_HIST_TICKETS + 8)
+#define GGR_HIST_PARAMS (GGR_HIST_TICKETS + 16)   // [0] = bits per digit
+#define GGR_HIST_STATUS (GGR_HIST_TICKETS + 64)
+static inline size_t ggr_sort_zero_words(size_t n) {
+    return GGR_HIST_STATUS + (size_t)GGR_SORT_PASSES * ggr_sort_blocks(n ? n : 1) * GGR_SORT_MAX_BINS;
+}
+static inline size_t ggr_sort_hist_words(size_t n) {
+    return ggr_sort_zero_words(n) + ((n ? n : 1) + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS;
+}
 
 struct GeomLayout {
     float4* splat;
@@ -196,11 +216,14 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* campos, int W, int H, float tanfovx, float tanfovy, int32_t* radii,
                            GeomLayout g, InputForm inf, hipStream_t s);
 
-// stable LSD radix sort of (u32 key, u32 val) pairs on bits [0, nbits); returns the buffers that
-// hold the result (either a or b)
+// stable LSD radix sort of (u32 key, u32 val) pairs, keys in the depth-sort form above (< 2^30, else the fault word
+// is raised); three passes; returns the buffers that hold the result (b after three passes).  The key maxima of the
+// n/256 producer blocks must be in the work area (preprocess_fwd; `block_max_ready` = false makes the sort compute
+// them itself: tools/sort_bench.hip)
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                      uint32_t* hist, size_t n, int nbits, uint32_t** keys_out, uint32_t** vals_out,
-                      hipStream_t s, bool hist_zeroed = false /*the caller already cleared ggr_sort_hist_words(n)*/,
+                      uint32_t* hist, size_t n, uint32_t** keys_out, uint32_t** vals_out,
+                      hipStream_t s, bool hist_zeroed = false /*the caller already cleared ggr_sort_zero_words(n)*/,
+                      bool block_max_ready = false,
                       const uint2* gather_src = nullptr /*last pass also writes gather_dst[pos] = gather_src[val]*/,
                       uint2* gather_dst = nullptr, uint32_t* zero_area = nullptr /*and clears these words*/,
                       uint32_t zero_words = 0);

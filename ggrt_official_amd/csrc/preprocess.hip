@@ -82,7 +82,7 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(GGR_PRE_THREADS)
 preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -95,7 +95,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       uint32_t* __restrict__ tiles_touched,
                       uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
                       float* __restrict__ cov3D_out, uint32_t* __restrict__ zero_area, uint32_t zero_words,
-                      InputForm inf) {
+                      uint32_t* __restrict__ block_max, InputForm inf) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_row_stride]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // zero the depth sort's histogram / ticket / look-back words here instead of with a separate fill launch
@@ -150,11 +150,11 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         else stage_sh_rows(sh_lds, shs, g0, nG, row, copy_row, sh_stride, sh_flat);
         __syncthreads();
     }
-    if (i >= P) return;
+    const bool in_range = i < P;  // (threads past P run on Gaussian P-1's inputs and store nothing)
 
     // defaults for a culled Gaussian
     int rad_out = 0;
-    uint32_t key_out = 0xFFFFFFFFu, tiles_out = 0, clamp_bits = 0;
+    uint32_t key_out = 0u, tiles_out = 0, clamp_bits = 0;  // sort key 0: culled (ggr_common.h GGR_KEY_BASE)
     uint2 rect_out = make_uint2(0, 0);
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
 
@@ -170,14 +170,16 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     } else {
         float sc[3] = {in_s * cin[0], in_s * cin[1], in_s * cin[2]};
         cov3d_from_scale_rot(sc, scale_modifier, rin, cov6);
+        if (in_range) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) cov3D_out[6 * (size_t)i + k] = cov6[k];
+            for (int k = 0; k < 6; k++) cov3D_out[6 * (size_t)i + k] = cov6[k];
+        }
     }
 
     float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
     float t1 = V[1] * p0 + V[5] * p1 + V[9] * p2 + V[13];
     const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
-    if (t2 > GGR_NEAR_CULL) {
+    if (t2 > GGR_NEAR_CULL && in_range) {
         const float ph0 = PM[0] * p0 + PM[4] * p1 + PM[8] * p2 + PM[12];
         const float ph1 = PM[1] * p0 + PM[5] * p1 + PM[9] * p2 + PM[13];
         const float ph3 = PM[3] * p0 + PM[7] * p1 + PM[11] * p2 + PM[15];
@@ -249,7 +251,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     rgb[0] = fmaxf(r0, 0.f); rgb[1] = fmaxf(r1, 0.f); rgb[2] = fmaxf(r2, 0.f);
                 }
                 rad_out = rad;
-                key_out = __float_as_uint(t2);
+                key_out = __float_as_uint(t2) - GGR_KEY_BASE;  // > 0: t2 > 0.2f
                 tiles_out = (uint32_t)area;
                 rect_out = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
                 s0 = make_float4(px, py, con0, con1);
@@ -263,15 +265,25 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             }
         }
     }
-    radii[i] = rad_out;
-    depth_key[i] = key_out;       // written straight into the depth sort's key / value input buffers
-    sort_vals[i] = (uint32_t)i;   // (saves a device memcpy and an iota launch)
-    tiles_touched[i] = tiles_out;
-    rect[i] = rect_out;
-    clamped_out[i] = clamp_bits;
-    splat[3 * (size_t)i] = s0;
-    splat[3 * (size_t)i + 1] = s1;
-    splat[3 * (size_t)i + 2] = s2;
+    if (in_range) {
+        radii[i] = rad_out;
+        depth_key[i] = key_out;       // written straight into the depth sort's key / value input buffers
+        sort_vals[i] = (uint32_t)i;   // (saves a device memcpy and an iota launch)
+        tiles_touched[i] = tiles_out;
+        rect[i] = rect_out;
+        clamped_out[i] = clamp_bits;
+        splat[3 * (size_t)i] = s0;
+        splat[3 * (size_t)i + 1] = s1;
+        splat[3 * (size_t)i + 2] = s2;
+    }
+    // the largest sort key of this block: the depth sort derives its digit width from these (binning.hip)
+    __shared__ uint32_t kmax[GGR_PRE_THREADS / 64];
+    uint32_t km = key_out;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, off));
+    if ((threadIdx.x & 63) == 0) kmax[threadIdx.x >> 6] = km;
+    __syncthreads();
+    if (threadIdx.x == 0) block_max[blockIdx.x] = max(max(kmax[0], kmax[1]), max(kmax[2], kmax[3]));
 }
 
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
@@ -281,8 +293,8 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* campos, int W, int H, float tanfovx, float tanfovy, int32_t* radii,
                            GeomLayout g, InputForm inf, hipStream_t s) {
     if (P <= 0) return;
-    const uint32_t zero_words = (uint32_t)ggr_sort_hist_words((size_t)P);  // the depth sort's work area (binning.hip)
-    const int threads = 256;
+    const uint32_t zero_words = (uint32_t)ggr_sort_zero_words((size_t)P);  // the depth sort's work area (binning.hip)
+    const int threads = GGR_PRE_THREADS;
     const int blocks = (P + threads - 1) / threads;
     const int deg = ggr_sh_degree(D, shs ? M : 25, inf.sh_cap);
     const bool flat = ((3 * M) & 1) && (reinterpret_cast<uintptr_t>(shs) & 15) == 0;  // same predicate as the kernel
@@ -294,7 +306,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                        aux_precomp, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.keys_a,
-                       g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D, g.hist, zero_words, inf);
+                       g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D, g.hist, zero_words, g.hist + zero_words, inf);
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D,

@@ -2,6 +2,9 @@
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ggrt_official_amd/csrc tools/sort_bench.hip \
 //        ggrt_official_amd/csrc/binning.hip -o /tmp/sort_bench
 #include "ggr_common.h"
+#ifdef GGR_SORT_PROBE
+namespace ggr { extern __device__ unsigned long long ggr_probe[3][8][2048]; }
+#endif
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -12,21 +15,24 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
 int main(int argc, char** argv) {
-    size_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 10763014;
-    int nbits = argc > 2 ? atoi(argv[2]) : 13;
-    int mode = argc > 3 ? atoi(argv[3]) : 0;  // 0: structured tile ids, 1: random, 2: float depth bits
+    size_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 1000000;
+    int nbits = argc > 2 ? atoi(argv[2]) : 27;   // mode 1: significant bits of the random keys (≤ 30)
+    int mode = argc > 3 ? atoi(argv[3]) : 2;  // 1: random, 2: depth keys (float bits of z in [1.5, 50) − bits of 0.2f), 3: with ties + culled
     std::vector<uint32_t> hk(n), hv(n);
     uint32_t seed = 12345;
     auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
     const uint32_t gx = 120, gy = 68;
     size_t i = 0;
     while (i < n) {
-        if (mode == 0) {  // a Gaussian's rect: w×h tiles row-major
-            uint32_t w = 1 + rnd() % 6, h = 1 + rnd() % 6, x0 = rnd() % (gx - w + 1), y0 = rnd() % (gy - h + 1);
-            for (uint32_t y = 0; y < h && i < n; y++)
-                for (uint32_t x = 0; x < w && i < n; x++) { hk[i] = (y0 + y) * gx + x0 + x; hv[i] = (uint32_t)i; i++; }
-        } else if (mode == 1) { hk[i] = rnd() & ((nbits >= 32 ? 0 : (1u << nbits)) - 1u); hv[i] = (uint32_t)i; i++; }
-        else { float z = 1.5f + (rnd() % 100000) * 0.000485f; uint32_t b; memcpy(&b, &z, 4); hk[i] = b; hv[i] = (uint32_t)i; i++; }
+        (void)gx; (void)gy;
+        if (mode == 1) { hk[i] = ((rnd() << 8) ^ rnd()) & ((1u << nbits) - 1u); hv[i] = (uint32_t)i; i++; }
+        else {
+            float z = expf(logf(1.5f) + (rnd() % 1000003) * (1.0f / 1000003.f) * (logf(50.f) - logf(1.5f)));
+            if (mode == 3) z = floorf(z * 64.f) / 64.f + 1.5f;   // many exact ties
+            uint32_t b; memcpy(&b, &z, 4);
+            hk[i] = (mode == 3 && rnd() % 7 == 0) ? 0u : b - GGR_KEY_BASE;  // 0 = culled
+            hv[i] = (uint32_t)i; i++;
+        }
     }
     uint32_t *ka, *kb, *va, *vb, *hist;
     CK(hipMalloc(&ka, n * 4)); CK(hipMalloc(&kb, n * 4)); CK(hipMalloc(&va, n * 4)); CK(hipMalloc(&vb, n * 4));
@@ -38,18 +44,37 @@ int main(int argc, char** argv) {
     for (int it = 0; it < 8; it++) {
         CK(hipMemcpy(ka, hk.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(va, hv.data(), n * 4, hipMemcpyHostToDevice));
         CK(hipEventRecord(e0, s));
-        ggr::radix_sort_pairs(ka, kb, va, vb, hist, n, nbits, &ko, &vo, s);
+        ggr::radix_sort_pairs(ka, kb, va, vb, hist, n, &ko, &vo, s);
         CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
     }
     std::vector<uint32_t> rk(n), rv(n);
     CK(hipMemcpy(rk.data(), ko, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(rv.data(), vo, n * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> idx(n); std::iota(idx.begin(), idx.end(), 0u);
-    const uint32_t mask = nbits >= 32 ? 0xFFFFFFFFu : ((1u << (8 * ((nbits + 7) / 8))) - 1u);
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return (hk[a] & mask) < (hk[b] & mask); });
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return hk[a] < hk[b]; });
     size_t bad = 0;
     for (size_t j = 0; j < n; j++) if (rk[j] != hk[idx[j]] || rv[j] != hv[idx[j]]) bad++;
-    printf("n=%zu nbits=%d mode=%d  best %.3f ms  (%.1f GB/s at 16 B/key/pass x %d passes)  mismatches=%zu\n", n, nbits, mode, best,
-           n * 16.0 * ((nbits + 7) / 8) / best / 1e6, (nbits + 7) / 8, bad);
+    uint32_t hw[80];
+    CK(hipMemcpy(hw, hist + GGR_HIST_TICKETS, sizeof hw, hipMemcpyDeviceToHost));
+    printf("n=%zu mode=%d  best %.3f ms (incl. the memset + block-max launches the product does not need)  digit bits %u  fault %u  mismatches=%zu\n",
+           n, mode, best, hw[16], hw[8], bad);
+#ifdef GGR_SORT_PROBE
+    {   // phase durations of the LAST run, per pass: mean over tiles (µs) of [ticket→loads issued+scan, rank, barrier wait,
+        // look-back, barrier wait, scatter issue] and the span first-start → last-end
+        static unsigned long long pr[3][8][2048];
+        CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ggr::ggr_probe), sizeof pr));
+        const size_t nt = std::min<size_t>(2048, (n + GGR_SORT_TILE - 1) / GGR_SORT_TILE);
+        for (int p = 0; p < 3; p++) {
+            double ph[6] = {0, 0, 0, 0, 0, 0};
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (size_t t = 0; t < nt; t++) {
+                for (int k = 0; k < 6; k++) ph[k] += (double)(pr[p][k + 1][t] - pr[p][k][t]) / 100.0;
+                t0 = std::min(t0, pr[p][0][t]); t1 = std::max(t1, pr[p][6][t]);
+            }
+            printf("  pass %d: scan+loads %.2f rank %.2f bar %.2f lookback %.2f bar %.2f scatter %.2f us (mean per tile); first start -> last end %.2f us\n",
+                   p, ph[0] / nt, ph[1] / nt, ph[2] / nt, ph[3] / nt, ph[4] / nt, ph[5] / nt, (double)(t1 - t0) / 100.0);
+        }
+    }
+#endif
     return bad != 0;
 }
