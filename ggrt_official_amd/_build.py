@@ -42,6 +42,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
+    extra_env = os.environ.get("GGR_EXTRA_HIPCC_FLAGS", "").split()  # dev experiments only (e.g. -DGGR_XCD_SPLIT=4)
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
@@ -49,7 +50,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *extra_env, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

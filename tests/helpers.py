@@ -46,11 +46,31 @@ def check_image(img, ref, name="color", tag="", psnr_min=None, flip_fraction=Non
     assert p >= (PSNR_MIN if psnr_min is None else psnr_min), f"{name}: PSNR {p:.1f} dB"
 
 
+GRAD_RTOL_ALL = 1e-3     # the north-star's bar, on the whole tensor, threshold flips included
+FLIP_ROWS = 1e-5         # fraction of the Gaussians (at least 8) whose gradient a threshold flip may have touched
+
+
 def check_grads(grads, ref, keys, tag="", rtol=None):
+    """Per tensor: rel-L2 over ALL rows ≤ 1e-3 (north-star), and rel-L2 ≤ GRAD_RTOL once the few rows with the
+    largest error are set aside.  Why rows are set aside: the same α/T threshold flips that move single pixels of the
+    image (check_image) add or drop one (pixel, Gaussian) term of a gradient sum — a discrete event, not rounding.
+    At C3 (1 M Gaussians, dL/dcolor ≈ 1.6e-7 per pixel) ONE such term in ONE Gaussian is 7.8e-5 of the whole means3D
+    gradient norm while every other row agrees to 9e-7 (scripts/grad_outliers.py)."""
     for k in keys:
-        r = rel_l2(grads[k], ref[k])
-        record_metric(f"{tag}:{k}", kind=1, rel_l2=r)
-        assert r <= (GRAD_RTOL if rtol is None else rtol), f"grad {k}: rel-L2 {r:.3e}"
+        a = np.asarray(grads[k], np.float64)
+        b = np.asarray(ref[k], np.float64)
+        rows = a.shape[0] if a.ndim > 1 else a.size
+        a2, b2 = a.reshape(rows, -1), b.reshape(rows, -1)
+        r_all = rel_l2(a2, b2)
+        err = np.linalg.norm(a2 - b2, axis=1)
+        drop = min(rows, max(8, int(FLIP_ROWS * rows)))
+        keep = np.ones(rows, bool)
+        if rows > drop:
+            keep[np.argpartition(-err, drop - 1)[:drop]] = False
+        r = float(np.linalg.norm((a2 - b2)[keep]) / max(np.linalg.norm(b2[keep]), 1e-30)) if keep.any() else 0.0
+        record_metric(f"{tag}:{k}", kind=1, rel_l2=r, rel_l2_all=r_all)
+        assert r_all <= GRAD_RTOL_ALL, f"grad {k}: rel-L2 over all rows {r_all:.3e}"
+        assert r <= (GRAD_RTOL if rtol is None else rtol), f"grad {k}: rel-L2 {r:.3e} ({drop} rows set aside; all rows {r_all:.3e})"
 
 
 def oracle_forward(sc: Scene, use_sh=True, use_cov=True, colors=None, sh_cap=4):
