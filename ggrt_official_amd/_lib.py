@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libggr_raster.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -32,6 +32,13 @@ class GgrForwardIn(C.Structure):
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("aux_precomp", C.c_void_p),
         ("input_scale", C.c_void_p), ("cov3D_full", C.c_int32), ("sh_channel_major", C.c_int32),
         ("aux_affine", C.c_int32), ("aux_a", C.c_float), ("aux_b", C.c_float),
+    ]
+
+
+class GgrViews(C.Structure):
+    _fields_ = [
+        ("num_views", C.c_int32), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+        ("bg", C.c_void_p), ("tanfov", C.c_void_p), ("input_scale", C.c_void_p),
     ]
 
 
@@ -79,6 +86,14 @@ SYMBOLS = [
                               ALLOC_FN, C.c_void_p, C.c_void_p]),
     ("ggr_backward", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrBackwardIn), C.POINTER(GgrBackwardOut),
                                C.c_void_p]),
+    ("ggr_geom_bytes_views", C.c_size_t, [C.c_int32, C.c_int32]),
+    ("ggr_image_bytes_views", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    ("ggr_work_bytes_views", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("ggr_backward_scratch_bytes_views", C.c_size_t, [C.c_int32, C.c_int32]),
+    ("ggr_forward_views", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrViews), C.POINTER(GgrForwardIn),
+                                    C.POINTER(GgrForwardOut), ALLOC_FN, C.c_void_p, C.c_void_p]),
+    ("ggr_backward_views", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrViews), C.POINTER(GgrBackwardIn),
+                                     C.POINTER(GgrBackwardOut), C.c_void_p]),
     ("ggr_camera_setup", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ggr_forward_status", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_void_p]),

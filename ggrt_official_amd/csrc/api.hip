@@ -102,8 +102,6 @@ ReadbackSlot* readback_slot() {
 
 InputForm input_form(const GgrSettings* st, const GgrForwardIn* in) {
     InputForm f;
-    f.tanfov_dev = st->tanfov_dev;
-    f.input_scale = in->input_scale;
     f.cov_stride = in->cov3D_full ? 9 : 6;
     f.sh_channel_major = in->sh_channel_major ? 1 : 0;
     f.aux_affine = (in->aux_affine && !in->aux_precomp) ? 1 : 0;
@@ -114,6 +112,32 @@ InputForm input_form(const GgrSettings* st, const GgrForwardIn* in) {
 }
 
 size_t tiles_of(int W, int H) { return (size_t)((W + GGR_TILE - 1) / GGR_TILE) * ((H + GGR_TILE - 1) / GGR_TILE); }
+
+// the reference's call: one camera, taken from the settings
+ViewSet single_view(const GgrSettings* st, const GgrForwardIn* in) {
+    ViewSet vs;
+    vs.V = 1;
+    vs.view = st->viewmatrix; vs.proj = st->projmatrix; vs.campos = st->campos; vs.bg = st->bg;
+    vs.tanfov = st->tanfov_dev; vs.input_scale = in->input_scale;
+    vs.tanfovx = st->tanfovx; vs.tanfovy = st->tanfovy;
+    return vs;
+}
+
+int view_set(const GgrSettings* st, const GgrViews* v, ViewSet* vs) {
+    if (!v || v->num_views < 1) return fail(GGR_E_INVALID, "GgrViews: num_views must be >= 1");
+    if (!v->viewmatrix || !v->projmatrix || !v->campos || !v->bg)
+        return fail(GGR_E_INVALID, "GgrViews: null camera array");
+    const int64_t V = v->num_views;
+    const int64_t gy = (st->image_height + GGR_TILE - 1) / GGR_TILE;
+    if (V * st->num_points >= 0x7FFFFFFFll) return fail(GGR_E_LIMIT, "num_views x num_points too large");
+    if (V * gy > 65535) return fail(GGR_E_LIMIT, "num_views x tile rows exceeds 65535");
+    if (V * (int64_t)tiles_of(st->image_width, st->image_height) > (1 << 24)) return fail(GGR_E_LIMIT, "more than 2^24 tiles over all views");
+    vs->V = (int)V;
+    vs->view = v->viewmatrix; vs->proj = v->projmatrix; vs->campos = v->campos; vs->bg = v->bg;
+    vs->tanfov = v->tanfov; vs->input_scale = v->input_scale;
+    vs->tanfovx = st->tanfovx; vs->tanfovy = st->tanfovy;
+    return GGR_OK;
+}
 
 }  // namespace
 
@@ -130,29 +154,33 @@ size_t ggr_work_bytes(int32_t P, int32_t W, int32_t H) {
 }
 size_t ggr_backward_scratch_bytes(int32_t P) { return ggr_carve_bwd(nullptr, (size_t)(P > 0 ? P : 0)).bytes; }
 
-int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* out, GgrAllocFn alloc,
-                void* alloc_ctx, void* stream) {
-    g_err[0] = 0;
-    int rc = validate(st, in);
-    if (rc) return rc;
+}  // extern "C"
+
+namespace {
+
+// forward of V views of the same P Gaussians (V = 1: ggr_forward).  All per-Gaussian state is per (view, Gaussian),
+// the tiles of the views are stacked (ggr_common.h ViewSet): one preprocess launch, ONE depth sort over the V·P keys,
+// one tile-list build over the V·T tiles, one blend launch.
+int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* in, GgrForwardOut* out, GgrAllocFn alloc,
+                 void* alloc_ctx, void* stream) {
     if (!out || !out->out_color || !out->geom_buffer || !out->image_buffer || !alloc)
         return fail(GGR_E_INVALID, "null output / buffer / allocator");
     if (st->num_points > 0 && !out->radii) return fail(GGR_E_INVALID, "null radii");
     hipStream_t s = (hipStream_t)stream;
-    const int P = st->num_points, W = st->image_width, H = st->image_height;
+    const int P1 = st->num_points, W = st->image_width, H = st->image_height, NV = vs.V;
+    const int P = P1 * NV;                      // (view, Gaussian) pairs
     const int gx = (W + GGR_TILE - 1) / GGR_TILE;
-    const size_t tiles = tiles_of(W, H);
+    const size_t tiles = tiles_of(W, H) * (size_t)NV;
     const bool dbg = st->debug != 0;
 
     GeomLayout g = ggr_carve_geom(out->geom_buffer, (size_t)P);
-    ImageLayout im = ggr_carve_image(out->image_buffer, W, H);
+    ImageLayout im = ggr_carve_image(out->image_buffer, W, H, NV);
     StageTimer tm(s, out->stage_ms, GGR_FWD_STAGES);
 
     // 1. per-Gaussian projection
-    ggr::launch_preprocess_fwd(P, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
+    ggr::launch_preprocess_fwd(P1, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
                                in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
-                               in->aux_precomp, st->viewmatrix, st->projmatrix, st->campos, W, H, st->tanfovx,
-                               st->tanfovy, out->radii, g, input_form(st, in), s);
+                               in->aux_precomp, vs, W, H, out->radii, g, input_form(st, in), s);
     KCHECK(dbg, s, "preprocess_fwd");
     tm.mark();
 
@@ -168,8 +196,9 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
         ggr::tile_list_gather_targets(plan, work, tiles, &rect_sorted, &zero_area, &zero_words);
         // (preprocess already wrote the keys into g.keys_a and the identity permutation into g.vals_a)
         ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, &dk, &order, s,
-                              /*hist_zeroed=*/true /*by preprocess_fwd*/, /*block_max_ready=*/true /*likewise*/, g.rect,
-                              rect_sorted, zero_area, zero_words);
+                              /*hist_zeroed=*/true /*by preprocess_fwd*/,
+                              /*block_max_ready=*/(uint32_t)((P1 + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS) /*likewise*/,
+                              g.rect, rect_sorted, zero_area, zero_words);
         KCHECK(dbg, s, "depth sort");
     }
     tm.mark();
@@ -234,25 +263,22 @@ int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* ou
     tm.mark();
 
     // 5. blend
-    ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, st->bg, out->out_color, im.final_T, im.n_contrib,
-                          out->out_depth, im.ckpt, im.ckpt_slots, im.tile_top, s);
+    ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, vs.bg, out->out_color, im.final_T, im.n_contrib,
+                          out->out_depth, im.ckpt, im.ckpt_slots, im.tile_top, NV, s);
     KCHECK(dbg, s, "blend_fwd");
     tm.mark();
     tm.finish();
     return GGR_OK;
 }
 
-int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut* out, void* stream) {
-    g_err[0] = 0;
-    if (!in) return fail(GGR_E_INVALID, "null inputs");
-    int rc = validate(st, &in->fwd);
-    if (rc) return rc;
+int backward_impl(const GgrSettings* st, const ViewSet& vs, const GgrBackwardIn* in, GgrBackwardOut* out, void* stream) {
     if (!out) return fail(GGR_E_INVALID, "null gradient output struct");
+    const int NV = vs.V;
     if (st->num_points == 0) {  // nothing to differentiate; camera gradients are zero
         hipStream_t s0 = (hipStream_t)stream;
-        if (out->dL_dviewmatrix) HIP_TRY(hipMemsetAsync(out->dL_dviewmatrix, 0, 64, s0));
-        if (out->dL_dprojmatrix) HIP_TRY(hipMemsetAsync(out->dL_dprojmatrix, 0, 64, s0));
-        if (out->dL_dcampos) HIP_TRY(hipMemsetAsync(out->dL_dcampos, 0, 12, s0));
+        if (out->dL_dviewmatrix) HIP_TRY(hipMemsetAsync(out->dL_dviewmatrix, 0, 64 * (size_t)NV, s0));
+        if (out->dL_dprojmatrix) HIP_TRY(hipMemsetAsync(out->dL_dprojmatrix, 0, 64 * (size_t)NV, s0));
+        if (out->dL_dcampos) HIP_TRY(hipMemsetAsync(out->dL_dcampos, 0, 12 * (size_t)NV, s0));
         return GGR_OK;
     }
     if (!out->dL_dmeans3D || !out->dL_dmeans2D || !out->dL_dopacities || !out->dL_dcov3D)
@@ -271,26 +297,25 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     const bool dbg = st->debug != 0;
     if (in->num_rendered != 0 && !in->binning_buffer) return fail(GGR_E_INVALID, "null binning buffer");
 
-    GeomLayout g = ggr_carve_geom((void*)in->geom_buffer, (size_t)P);
-    ImageLayout im = ggr_carve_image((void*)in->image_buffer, W, H);
+    GeomLayout g = ggr_carve_geom((void*)in->geom_buffer, (size_t)P * NV);
+    ImageLayout im = ggr_carve_image((void*)in->image_buffer, W, H, NV);
     const uint32_t* point_list = (const uint32_t*)in->binning_buffer;
-    BwdScratch sc = ggr_carve_bwd(in->scratch, (size_t)P);
+    BwdScratch sc = ggr_carve_bwd(in->scratch, (size_t)P, (size_t)NV);
 
     StageTimer tm(s, out->stage_ms, GGR_BWD_STAGES);
     HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));  // dL_dmeans2D / dL_dopacities are written by preprocess_bwd
     tm.mark();
 
     if (in->num_rendered != 0) {  // (-1: sync-free forward, count known on the device only)
-        ggr::launch_blend_bwd(W, H, im.ranges, point_list, g.splat, st->bg, im.final_T, im.n_contrib,
+        ggr::launch_blend_bwd(W, H, im.ranges, point_list, g.splat, vs.bg, im.final_T, im.n_contrib,
                               in->dL_dout_color, in->dL_dout_depth, sc.grad2d, im.tile_top, im.ckpt,
-                              im.ckpt_slots, im.bwd_segments, s);
+                              im.ckpt_slots, im.bwd_segments, NV, s);
         KCHECK(dbg, s, "blend_bwd");
     }
     tm.mark();
     const float* cov = in->fwd.cov3D_precomp ? in->fwd.cov3D_precomp : g.cov3D;
     ggr::launch_preprocess_bwd(P, st->sh_degree, st->sh_stride, in->fwd.means3D, in->fwd.shs, has_cp ? 1 : 0,
-                               in->fwd.scales, in->fwd.rotations, st->scale_modifier, cov, st->viewmatrix,
-                               st->projmatrix, st->campos, W, H, st->tanfovx, st->tanfovy, in->radii, g.clamped,
+                               in->fwd.scales, in->fwd.rotations, st->scale_modifier, cov, vs, W, H, in->radii, g.clamped,
                                sc.grad2d, in->dL_dout_depth ? 1 : 0, out->dL_dmeans3D, out->dL_dmeans2D,
                                out->dL_dopacities, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
                                out->dL_dscales, out->dL_drotations, in->fwd.aux_precomp ? out->dL_daux : nullptr,
@@ -299,6 +324,57 @@ int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut*
     KCHECK(dbg, s, "preprocess_bwd");
     tm.mark();
     return GGR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ggr_forward(const GgrSettings* st, const GgrForwardIn* in, GgrForwardOut* out, GgrAllocFn alloc,
+                void* alloc_ctx, void* stream) {
+    g_err[0] = 0;
+    int rc = validate(st, in);
+    if (rc) return rc;
+    return forward_impl(st, single_view(st, in), in, out, alloc, alloc_ctx, stream);
+}
+
+int ggr_backward(const GgrSettings* st, const GgrBackwardIn* in, GgrBackwardOut* out, void* stream) {
+    g_err[0] = 0;
+    if (!in) return fail(GGR_E_INVALID, "null inputs");
+    int rc = validate(st, &in->fwd);
+    if (rc) return rc;
+    return backward_impl(st, single_view(st, &in->fwd), in, out, stream);
+}
+
+int ggr_forward_views(const GgrSettings* st, const GgrViews* views, const GgrForwardIn* in, GgrForwardOut* out,
+                      GgrAllocFn alloc, void* alloc_ctx, void* stream) {
+    g_err[0] = 0;
+    int rc = validate(st, in);
+    if (rc) return rc;
+    ViewSet vs;
+    if ((rc = view_set(st, views, &vs)) != 0) return rc;
+    return forward_impl(st, vs, in, out, alloc, alloc_ctx, stream);
+}
+
+int ggr_backward_views(const GgrSettings* st, const GgrViews* views, const GgrBackwardIn* in, GgrBackwardOut* out,
+                       void* stream) {
+    g_err[0] = 0;
+    if (!in) return fail(GGR_E_INVALID, "null inputs");
+    int rc = validate(st, &in->fwd);
+    if (rc) return rc;
+    ViewSet vs;
+    if ((rc = view_set(st, views, &vs)) != 0) return rc;
+    return backward_impl(st, vs, in, out, stream);
+}
+
+size_t ggr_geom_bytes_views(int32_t P, int32_t V) { return ggr_carve_geom(nullptr, (size_t)(P > 0 ? P : 0) * (size_t)(V > 0 ? V : 1)).bytes; }
+size_t ggr_image_bytes_views(int32_t W, int32_t H, int32_t V) { return ggr_carve_image(nullptr, W, H, V > 0 ? V : 1).bytes; }
+size_t ggr_work_bytes_views(int32_t P, int32_t W, int32_t H, int32_t V) {
+    const size_t v = (size_t)(V > 0 ? V : 1);
+    return ggr::plan_tile_lists((size_t)(P > 0 ? P : 0) * v, tiles_of(W, H) * v).work_bytes;
+}
+size_t ggr_backward_scratch_bytes_views(int32_t P, int32_t V) {
+    return ggr_carve_bwd(nullptr, (size_t)(P > 0 ? P : 0), (size_t)(V > 0 ? V : 1)).bytes;
 }
 
 int ggr_camera_setup(int32_t n, const float* extrinsics, const float* intrinsics, const float* near, const float* far,

@@ -381,12 +381,12 @@ const uint32_t* radix_sort_fault_word(const uint32_t* hist) { return hist + GGR_
 
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                       uint32_t* hist, size_t n, uint32_t** keys_out, uint32_t** vals_out,
-                      hipStream_t s, bool hist_zeroed, bool block_max_ready, const uint2* gather_src, uint2* gather_dst,
+                      hipStream_t s, bool hist_zeroed, uint32_t block_max_ready, const uint2* gather_src, uint2* gather_dst,
                       uint32_t* zero_area, uint32_t zero_words) {
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     if (n > 0) {
         const uint32_t ntiles = (uint32_t)ggr_sort_blocks(n);
-        const uint32_t nmax = (uint32_t)((n + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS);
+        const uint32_t nmax = block_max_ready ? block_max_ready : (uint32_t)((n + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS);
         uint32_t* block_max = hist + ggr_sort_zero_words(n);
         if (!hist_zeroed)  // (ggr_forward: preprocess_fwd clears the area — one launch less)
             (void)hipMemsetAsync(hist, 0, ggr_sort_zero_words(n) * sizeof(uint32_t), s);

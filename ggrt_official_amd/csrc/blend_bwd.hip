@@ -79,7 +79,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                  const float* __restrict__ dL_ddepth, float* __restrict__ grad2d,
                  const uint32_t* __restrict__ tile_top, const float* __restrict__ ckpt, int ckpt_slots,
-                 int segments) {
+                 int segments, int views) {
     __shared__ StagedSplat stage[BATCH];
     __shared__ __attribute__((aligned(16))) uint16_t surv[4][BATCH];  // per wave: stage indices of the entries that survive its quadrant cull
 
@@ -87,10 +87,12 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     // workgroup = (depth segment, tile), segment-major: all tiles' segment 0 first.  (Tile-major order interleaves
     // the loaded and the empty segments with a fixed period, and the dispatcher's round robin then puts all loaded
     // workgroups on the same fraction of the CUs: C3 with 2 segments per tile ran 0.75 ms instead of 0.43.)
-    const int ntiles = grid_x * ((H + GGR_TILE - 1) / GGR_TILE);
+    // (`views` frames stacked vertically, as in blend_fwd: tile vt of the launch = tile (vt mod T) of view vt / T)
+    const int tiles1 = grid_x * ((H + GGR_TILE - 1) / GGR_TILE), ntiles = tiles1 * views;
     const int seg = segments > 1 ? (int)blockIdx.x / xcd_grid(ntiles) : 0;
-    const int tile = xcd_tile((int)blockIdx.x - seg * xcd_grid(ntiles), ntiles);
-    if (tile < 0) return;  // padding workgroup (before any barrier)
+    const int vtile = xcd_tile((int)blockIdx.x - seg * xcd_grid(ntiles), ntiles);
+    if (vtile < 0) return;  // padding workgroup (before any barrier)
+    const int view = vtile / tiles1, tile = vtile - view * tiles1;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int qx0 = tile_x * GGR_TILE + (wave & 1) * 8, qy0 = tile_y * GGR_TILE + (wave >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -102,9 +104,9 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const float pxc = (float)(lane & 7) - 3.5f, pyc = (float)(lane >> 3) - 3.5f;
     const float rx1 = (float)min(qx0 + 7, W - 1), ry1 = (float)min(qy0 + 7, H - 1);
 
-    const uint2 range = ranges[tile];
+    const uint2 range = ranges[vtile];
     // entries [0, top) are replayed: nothing behind the tile's last contributor (left by the forward) can matter
-    const int top = (int)min(tile_top[tile], range.y - range.x);
+    const int top = (int)min(tile_top[vtile], range.y - range.x);
     // ---- depth segment [seg_lo, seg_hi) of the replayed entries ---------------------------------------------------
     // One segment = the whole list unless the forward left checkpoints (ggr_common.h, ImageLayout).  Then segment
     // s is checkpoint interval s of this tile's list; the workgroups of intervals behind `top` leave here, having
@@ -118,6 +120,12 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     if (seg_lo >= seg_hi) return;  // (block-uniform, before any barrier)
     const size_t hw = (size_t)H * W;
     const size_t pid = inside ? (size_t)py * W + px : 0;
+    {   // this view's slices
+        const size_t vo = (size_t)view * hw;
+        final_T += vo; n_contrib += vo; dL_dpix += 3 * vo; bg += 3 * view;
+        if (HAS_DEPTH) dL_ddepth += vo;
+        if (ckpt) ckpt += (size_t)ckpt_slots * GGR_CKPT_FLOATS * vo;
+    }
 
     const float T_final = inside ? final_T[pid] : 0.f;
     const uint32_t last = inside ? n_contrib[pid] : 0u;
@@ -331,19 +339,20 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, const float* final_T, const uint32_t* n_contrib,
                       const float* dL_dpix, const float* dL_ddepth, float* grad2d, const uint32_t* tile_top,
-                      const float* ckpt, int ckpt_slots, int segments, hipStream_t s) {
+                      const float* ckpt, int ckpt_slots, int segments, int views, hipStream_t s) {
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
-    if (gx * gy == 0) return;
+    if (gx * gy * views == 0) return;
+    const int nt = gx * gy * views;
     // one workgroup per (checkpoint interval, tile): `segments` == the forward's slot count, or 1 without checkpoints
     segments = (ckpt && ckpt_slots >= 2) ? ckpt_slots : 1;
     if (dL_ddepth)
-        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(xcd_grid(gx * gy) * segments), dim3(256), 0, s, W, H, gx, ranges,
+        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(xcd_grid(nt) * segments), dim3(256), 0, s, W, H, gx, ranges,
                            point_list, splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d, tile_top, ckpt,
-                           ckpt_slots, segments);
+                           ckpt_slots, segments, views);
     else
-        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(xcd_grid(gx * gy) * segments), dim3(256), 0, s, W, H, gx, ranges,
+        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(xcd_grid(nt) * segments), dim3(256), 0, s, W, H, gx, ranges,
                            point_list, splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d, tile_top, ckpt,
-                           ckpt_slots, segments);
+                           ckpt_slots, segments, views);
 }
 
 }  // namespace ggr

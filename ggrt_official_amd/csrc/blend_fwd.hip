@@ -26,14 +26,18 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
                  const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ out_depth, float* __restrict__ ckpt,
-                 int ckpt_slots, uint32_t* __restrict__ tile_top) {
+                 int ckpt_slots, uint32_t* __restrict__ tile_top, int views) {
     __shared__ StagedSplat stage[BATCH];
     __shared__ int wave_done[4];
     __shared__ uint32_t wave_last[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = xcd_tile((int)blockIdx.x, grid_x * ((H + GGR_TILE - 1) / GGR_TILE));
-    if (tile < 0) return;  // padding workgroup (before any barrier)
+    // `views` frames stacked vertically (ggr_common.h ViewSet): tile vt of the launch = tile (vt mod T) of view vt / T;
+    // per-view outputs and per-pixel state follow each other in the caller's [V, …] arrays
+    const int tiles1 = grid_x * ((H + GGR_TILE - 1) / GGR_TILE), ntiles = tiles1 * views;
+    const int vtile = xcd_tile((int)blockIdx.x, ntiles);
+    if (vtile < 0) return;  // padding workgroup (before any barrier)
+    const int view = vtile / tiles1, tile = vtile - view * tiles1;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int qx0 = tile_x * GGR_TILE + (wave & 1) * 8, qy0 = tile_y * GGR_TILE + (wave >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -44,14 +48,20 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const float rx1 = (float)min(qx0 + 7, W - 1), ry1 = (float)min(qy0 + 7, H - 1);
     const bool quad_live = qx0 < W && qy0 < H;
 
-    const uint2 range = ranges[tile];
+    const uint2 range = ranges[vtile];
     const int total = (int)(range.y - range.x);
     // images with few tiles: per-pixel checkpoints every `ck_every` list positions let the backward replay the
     // list in independent depth segments (ggr_common.h, ImageLayout).  A pixel that is done keeps its final
     // state, which is all the backward can ask of it (it never looks behind a pixel's last contributor).
     const size_t hw = (size_t)H * W;
     const size_t pid = inside ? (size_t)py * W + px : 0;
-    const int ck_every = ckpt ? ckpt_stride(total, ckpt_slots, grid_x * ((H + GGR_TILE - 1) / GGR_TILE)) : 0;
+    const int ck_every = ckpt ? ckpt_stride(total, ckpt_slots, ntiles) : 0;
+    {   // this view's slices
+        const size_t vo = (size_t)view * hw;
+        out_color += 3 * vo; final_T += vo; n_contrib += vo; bg += 3 * view;
+        if (out_depth) out_depth += vo;
+        if (ckpt) ckpt += (size_t)ckpt_slots * GGR_CKPT_FLOATS * vo;
+    }
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
     uint32_t last = 0;
@@ -138,7 +148,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     for (int off = 32; off > 0; off >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, off));
     if (lane == 0) wave_last[wave] = wl;
     __syncthreads();
-    if (tid == 0) tile_top[tile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
+    if (tid == 0) tile_top[vtile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
     if (inside) {
         if (ckpt) {  // slot 0: the final sums (what lies behind a checkpoint = final − checkpoint)
             float* ck = ckpt + pid;
@@ -155,11 +165,11 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
-                      float* out_depth, float* ckpt, int ckpt_slots, uint32_t* tile_top, hipStream_t s) {
+                      float* out_depth, float* ckpt, int ckpt_slots, uint32_t* tile_top, int views, hipStream_t s) {
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
-    if (gx * gy == 0) return;
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(xcd_grid(gx * gy)), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg,
-                       out_color, final_T, n_contrib, out_depth, ckpt, ckpt_slots, tile_top);
+    if (gx * gy * views == 0) return;
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(xcd_grid(gx * gy * views)), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg,
+                       out_color, final_T, n_contrib, out_depth, ckpt, ckpt_slots, tile_top, views);
 }
 
 }  // namespace ggr

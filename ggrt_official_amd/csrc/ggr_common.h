@@ -137,12 +137,13 @@ struct ImageLayout {
     size_t bytes;
 };
 
-static inline ImageLayout ggr_carve_image(void* base, int W, int H) {
+// (V views of one launch set: V frames stacked — tiles and pixels of view v follow those of view v-1 in every array)
+static inline ImageLayout ggr_carve_image(void* base, int W, int H, int V = 1) {
     ImageLayout L;
     char* p = (char*)base;
     size_t o = 0;
-    size_t tiles = (size_t)((W + GGR_TILE - 1) / GGR_TILE) * ((H + GGR_TILE - 1) / GGR_TILE);
-    size_t pix = (size_t)W * H;
+    size_t tiles = (size_t)((W + GGR_TILE - 1) / GGR_TILE) * ((H + GGR_TILE - 1) / GGR_TILE) * (size_t)V;
+    size_t pix = (size_t)W * H * (size_t)V;
     auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes ? bytes : 4); return r; };
     L.ranges = (uint2*)take(tiles * 8);
     L.final_T = (float*)take(pix * 4);
@@ -167,18 +168,18 @@ static inline ImageLayout ggr_carve_image(void* base, int W, int H) {
 #define GGR_G2D_STRIDE 16
 struct BwdScratch {
     float* grad2d;    // [P][16]
-    float* pose_acc;  // [64]: dL/dviewmatrix [0:16], dL/dprojmatrix [16:32], dL/dcampos [32:35]
+    float* pose_acc;  // rows of 64: dL/dviewmatrix [0:16], dL/dprojmatrix [16:32], dL/dcampos [32:35] partials
     size_t bytes;
 };
 
-static inline BwdScratch ggr_carve_bwd(void* base, size_t P) {
+static inline BwdScratch ggr_carve_bwd(void* base, size_t P, size_t V = 1) {
     BwdScratch L;
     char* p = (char*)base;
     size_t o = 0;
     size_t Pp = P ? P : 1;
     auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes); return r; };
-    L.grad2d = (float*)take(Pp * GGR_G2D_STRIDE * 4);
-    L.pose_acc = (float*)take((64 + ((Pp + 255) / 256) * 64) * 4);  // result row + one row of partials per block
+    L.grad2d = (float*)take(Pp * V * GGR_G2D_STRIDE * 4);                 // one record per (view, Gaussian)
+    L.pose_acc = (float*)take((64 + V * ((Pp + 255) / 256) * 64) * 4);    // one row of partials per (view, block)
     L.bytes = o;
     return L;
 }
@@ -186,16 +187,29 @@ static inline BwdScratch ggr_carve_bwd(void* base, size_t P) {
 // Input forms (call-site fusion): what reference render_cuda does with torch ops on the P-sized
 // tensors before every rasterizer call is applied on load instead (and chained through in backward).
 struct InputForm {
-    const float* input_scale;  // device scalar s or NULL (= 1): means·s, cov·s², scales·s — the 1/near
-                               // renormalisation of cuda_splatting.py:66-73
     int cov_stride;            // 6: [P,6] upper triangle.  9: [P,3,3] row-major, entries (0,1,2,4,5,8) used —
                                // the triu gather of :116,124
     int sh_channel_major;      // 0: [P,M,3] (upstream).  1: [P,3,M] = GGRt's harmonics layout — saves the
                                // transpose copy of :77 and its backward
     int aux_affine;            // 1: blended feature = max(aux_a + aux_b·z/s, 0) instead of z — GGRt's depth pass
     float aux_a, aux_b;        //    (:240-269: depth as a degree-0 SH coefficient) without a per-Gaussian tensor
-    const float* tanfov_dev;   // device float[2] overriding tanfovx / tanfovy, or NULL (GgrSettings.tanfov_dev)
     int sh_cap;                // highest SH band evaluated: 4 (GGRt's fork as recollected, default) or 3 (graphdeco)
+};
+
+// The cameras of one launch set: V views of the SAME P Gaussians (V = 1: the reference's call).  Per-Gaussian state of
+// view v lives at index v·P + g; its tiles are tiles [v·T, (v+1)·T) of a virtual image of V frames stacked vertically
+// (tile row = v·grid_y + row), so the depth sort, the tile-list builder and the blend kernels run ONCE over all views
+// (replaces the per-view loop of reference cuda_splatting.py:93-127).
+struct ViewSet {
+    int V;
+    const float* view;         // device [V,16]
+    const float* proj;         // device [V,16]
+    const float* campos;       // device [V,3]
+    const float* bg;           // device [V,3]
+    const float* tanfov;       // device [V,2] or NULL → tanfovx / tanfovy below for every view
+    const float* input_scale;  // device [V] or NULL (= 1): means·s, cov·s², scales·s — the 1/near renormalisation of
+                               // cuda_splatting.py:66-73
+    float tanfovx, tanfovy;
 };
 
 // SH bands actually evaluated: min(D, cap), and never more than a row of M coefficients holds
@@ -209,11 +223,11 @@ __host__ __device__ static inline int ggr_sh_degree(int D, int M, int cap) {
 // ---- kernel launchers (defined in the .hip translation units) -------------------------------
 namespace ggr {
 
+// geom `g` is carved for V·P Gaussians; radii [V,P]; aux_precomp [V,P] or NULL
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
-                           const float* aux_precomp, const float* viewmatrix, const float* projmatrix,
-                           const float* campos, int W, int H, float tanfovx, float tanfovy, int32_t* radii,
+                           const float* aux_precomp, ViewSet vs, int W, int H, int32_t* radii,
                            GeomLayout g, InputForm inf, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 val) pairs, keys in the depth-sort form above (< 2^30, else the fault word
@@ -223,7 +237,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                       uint32_t* hist, size_t n, uint32_t** keys_out, uint32_t** vals_out,
                       hipStream_t s, bool hist_zeroed = false /*the caller already cleared ggr_sort_zero_words(n)*/,
-                      bool block_max_ready = false,
+                      uint32_t block_max_ready = 0 /*> 0: that many key maxima are already in the work area*/,
                       const uint2* gather_src = nullptr /*last pass also writes gather_dst[pos] = gather_src[val]*/,
                       uint2* gather_dst = nullptr, uint32_t* zero_area = nullptr /*and clears these words*/,
                       uint32_t zero_words = 0);
@@ -256,19 +270,21 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
-                      float* out_depth, float* ckpt /*or null*/, int ckpt_slots, uint32_t* tile_top, hipStream_t s);
+                      float* out_depth, float* ckpt /*or null*/, int ckpt_slots, uint32_t* tile_top, int views,
+                      hipStream_t s);
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, const float* final_T, const uint32_t* n_contrib,
                       const float* dL_dpix, const float* dL_ddepth /*or null*/, float* grad2d /*[P][16], zeroed*/,
-                      const uint32_t* tile_top, const float* ckpt /*or null*/, int ckpt_slots, int segments,
+                      const uint32_t* tile_top, const float* ckpt /*or null*/, int ckpt_slots, int segments, int views,
                       hipStream_t s);
 
+// radii / clamped / grad2d / dL_dmeans2D / dL_daux are per view ([V,P,…]); the other gradients are summed over the
+// views; pose_acc holds V·blocks rows of 64 floats; dL_dview/dL_dproj [V,16], dL_dcampos [V,3]
 void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs,
                            int has_colors_precomp, const float* scales, const float* rotations,
-                           float scale_modifier, const float* cov3D, const float* viewmatrix,
-                           const float* projmatrix, const float* campos, int W, int H, float tanfovx,
-                           float tanfovy, const int32_t* radii, const uint32_t* clamped,
+                           float scale_modifier, const float* cov3D, ViewSet vs, int W, int H, const int32_t* radii,
+                           const uint32_t* clamped,
                            const float* grad2d, int has_dz, float* dL_dmeans3D, float* dL_dmeans2D,
                            float* dL_dopacity, float* dL_dsh,
                            float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,

@@ -82,14 +82,14 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
+// MULTI = false: one view, the loop over views folds away at compile time; MULTI = true: run-time loop over the views
+template <bool MULTI>
 __global__ void __launch_bounds__(GGR_PRE_THREADS)
 preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       float scale_modifier, const float* __restrict__ cov3D_precomp,
-                      const float* __restrict__ aux_precomp,
-                      const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
-                      const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
+                      const float* __restrict__ aux_precomp, ViewSet vs, int W, int H,
                       int32_t* __restrict__ radii, float4* __restrict__ splat,
                       uint32_t* __restrict__ depth_key, uint32_t* __restrict__ sort_vals,
                       uint32_t* __restrict__ tiles_touched,
@@ -117,11 +117,6 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // this thread's own inputs are requested BEFORE the SH staging, so that their round trip overlaps it
     // (clamped index: threads past P load Gaussian P-1 and drop it)
     const size_t il = (size_t)min(i, P - 1);
-    float V[16], PM[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PM[k] = projmatrix[k]; }
-    if (inf.tanfov_dev) { tanfovx = inf.tanfov_dev[0]; tanfovy = inf.tanfov_dev[1]; }  // device-resident tan(fov/2)
-    const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
     const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];
     const float opac = opacities[il];
     float cin[6], rin[4] = {0.f, 0.f, 0.f, 0.f};
@@ -139,7 +134,6 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll
         for (int k = 0; k < 4; k++) rin[k] = rotations[4 * il + k];
     }
-    const float aux_in = aux_precomp ? aux_precomp[il] : 0.f;
     float cp_in[3] = {0.f, 0.f, 0.f};
     if (colors_precomp) { cp_in[0] = colors_precomp[3 * il]; cp_in[1] = colors_precomp[3 * il + 1]; cp_in[2] = colors_precomp[3 * il + 2]; }
     if (shs) {
@@ -151,134 +145,153 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         __syncthreads();
     }
     const bool in_range = i < P;  // (threads past P run on Gaussian P-1's inputs and store nothing)
+    const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
+    uint32_t km = 0u;  // largest sort key of this thread over all views
 
-    // defaults for a culled Gaussian
-    int rad_out = 0;
-    uint32_t key_out = 0u, tiles_out = 0, clamp_bits = 0;  // sort key 0: culled (ggr_common.h GGR_KEY_BASE)
-    uint2 rect_out = make_uint2(0, 0);
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+    // ---- one pass per view: the Gaussian's inputs (and its SH row in LDS) are read ONCE for all of them ----------
+    const int NV = MULTI ? vs.V : 1;
+#pragma clang loop unroll(disable)
+    for (int v = 0; v < NV; v++) {
+        float V[16], PM[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { V[k] = vs.view[16 * v + k]; PM[k] = vs.proj[16 * v + k]; }
+        const float* campos = vs.campos + 3 * v;
+        const float tanfovx = vs.tanfov ? vs.tanfov[2 * v] : vs.tanfovx;      // device-resident tan(fov/2)
+        const float tanfovy = vs.tanfov ? vs.tanfov[2 * v + 1] : vs.tanfovy;
+        const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
+        const size_t o = (size_t)v * P + (size_t)il;  // per-view index of this Gaussian's state
+        const float aux_in = aux_precomp ? aux_precomp[o] : 0.f;
 
-    // call-site fusion: the reference's 1/near renormalisation (means·s, cov·s², scales·s — cuda_splatting.py:
-    // 66-73) and its upper-triangle gather out of [P,3,3] covariances (:116,124) happen on load.  One fp32
-    // multiply per value, exactly what the torch ops of the unfused call site do.
-    const float p0 = in_s * m0, p1 = in_s * m1, p2 = in_s * m2;
-    float cov6[6];
-    if (cov3D_precomp) {
-        const float s2 = in_s * in_s;
-#pragma unroll
-        for (int k = 0; k < 6; k++) cov6[k] = cin[k] * s2;
-    } else {
-        float sc[3] = {in_s * cin[0], in_s * cin[1], in_s * cin[2]};
-        cov3d_from_scale_rot(sc, scale_modifier, rin, cov6);
-        if (in_range) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) cov3D_out[6 * (size_t)i + k] = cov6[k];
-        }
-    }
+        // defaults for a culled Gaussian
+        int rad_out = 0;
+        uint32_t key_out = 0u, tiles_out = 0, clamp_bits = 0;  // sort key 0: culled (ggr_common.h GGR_KEY_BASE)
+        uint2 rect_out = make_uint2(0, 0);
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
 
-    float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
-    float t1 = V[1] * p0 + V[5] * p1 + V[9] * p2 + V[13];
-    const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
-    if (t2 > GGR_NEAR_CULL && in_range) {
-        const float ph0 = PM[0] * p0 + PM[4] * p1 + PM[8] * p2 + PM[12];
-        const float ph1 = PM[1] * p0 + PM[5] * p1 + PM[9] * p2 + PM[13];
-        const float ph3 = PM[3] * p0 + PM[7] * p1 + PM[11] * p2 + PM[15];
-        const float pw = 1.0f / (ph3 + 0.0000001f);
-        const float ppx = ph0 * pw, ppy = ph1 * pw;
-
-        const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
-        const float limx = GGR_FRUSTUM_CLAMP * tanfovx, limy = GGR_FRUSTUM_CLAMP * tanfovy;
-        const float txtz = t0 / t2, tytz = t1 / t2;
-        t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
-        t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
-        const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2);
-        const float J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
-        // A = J·R with R[i][j] = V[4*j+i]
-        float A0[3], A1[3];
+        // call-site fusion: the reference's 1/near renormalisation (means·s, cov·s², scales·s — cuda_splatting.py:
+        // 66-73) and its upper-triangle gather out of [P,3,3] covariances (:116,124) happen on load.  One fp32
+        // multiply per value, exactly what the torch ops of the unfused call site do.
+        const float p0 = in_s * m0, p1 = in_s * m1, p2 = in_s * m2;
+        float cov6[6];
+        if (cov3D_precomp) {
+            const float s2 = in_s * in_s;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            A0[j] = J00 * V[4 * j + 0] + J02 * V[4 * j + 2];
-            A1[j] = J11 * V[4 * j + 1] + J12 * V[4 * j + 2];
-        }
-        const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
-        float AS0[3], AS1[3];
+            for (int k = 0; k < 6; k++) cov6[k] = cin[k] * s2;
+        } else {
+            float sc[3] = {in_s * cin[0], in_s * cin[1], in_s * cin[2]};
+            cov3d_from_scale_rot(sc, scale_modifier, rin, cov6);
+            if (in_range) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; k++) { a0 += A0[k] * S[3 * k + j]; a1 += A1[k] * S[3 * k + j]; }
-            AS0[j] = a0; AS1[j] = a1;
-        }
-        float c00 = 0.f, c01 = 0.f, c11 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { c00 += AS0[k] * A0[k]; c01 += AS0[k] * A1[k]; c11 += AS1[k] * A1[k]; }
-        const float a = c00 + GGR_DILATION, b = c01, c = c11 + GGR_DILATION;
-        const float det = a * c - b * b;
-        if (det != 0.0f) {
-            const float det_inv = 1.f / det;
-            const float con0 = c * det_inv, con1 = -b * det_inv, con2 = a * det_inv;
-            const float mid = 0.5f * (a + c);
-            const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
-            const float l1 = mid + sq, l2 = mid - sq;
-            const int rad = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
-            const float px = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
-            const float py = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
-            const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
-            const int rminx = min(gx, max(0, (int)((px - (float)rad) / (float)GGR_TILE)));
-            const int rminy = min(gy, max(0, (int)((py - (float)rad) / (float)GGR_TILE)));
-            const int rmaxx = min(gx, max(0, (int)((px + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
-            const int rmaxy = min(gy, max(0, (int)((py + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
-            const int area = (rmaxx - rminx) * (rmaxy - rminy);
-            if (area != 0) {
-                float rgb[3];
-                if (colors_precomp) {
-                    rgb[0] = cp_in[0]; rgb[1] = cp_in[1]; rgb[2] = cp_in[2];
-                } else {
-                    const int deg = sh_deg;
-                    float d0 = p0 - campos[0], d1 = p1 - campos[1], d2 = p2 - campos[2];
-                    const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-                    d0 /= len; d1 /= len; d2 /= len;
-                    float B[25];
-                    sh_basis(deg, d0, d1, d2, B);
-                    const int K = (deg + 1) * (deg + 1);
-                    const float* sh = sh_lds + threadIdx.x * sh_stride;
-                    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-                    for (int k = 0; k < K; k++) {
-                        r0 += B[k] * sh[k * sh_ks]; r1 += B[k] * sh[k * sh_ks + sh_cs]; r2 += B[k] * sh[k * sh_ks + 2 * sh_cs];
-                    }
-                    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
-                    clamp_bits = (r0 < 0.f ? 1u : 0u) | (r1 < 0.f ? 2u : 0u) | (r2 < 0.f ? 4u : 0u);
-                    rgb[0] = fmaxf(r0, 0.f); rgb[1] = fmaxf(r1, 0.f); rgb[2] = fmaxf(r2, 0.f);
-                }
-                rad_out = rad;
-                key_out = __float_as_uint(t2) - GGR_KEY_BASE;  // > 0: t2 > 0.2f
-                tiles_out = (uint32_t)area;
-                rect_out = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
-                s0 = make_float4(px, py, con0, con1);
-                s1 = make_float4(con2, opac, rgb[0], rgb[1]);
-                // 4th blended feature: the caller's aux value, or view z, or (fused GGRt depth pass, :240-269)
-                // max(a + b·z_unscaled, 0) with z_unscaled = z / s
-                float feat = t2;
-                if (aux_precomp) feat = aux_in;
-                else if (inf.aux_affine) feat = fmaxf(inf.aux_a + inf.aux_b * (t2 / in_s), 0.f);
-                s2 = make_float4(rgb[2], feat, 2.f * logf(255.f * opac), 0.f);  // .z = qmax for the box cull
+                for (int k = 0; k < 6; k++) cov3D_out[6 * o + k] = cov6[k];
             }
         }
-    }
-    if (in_range) {
-        radii[i] = rad_out;
-        depth_key[i] = key_out;       // written straight into the depth sort's key / value input buffers
-        sort_vals[i] = (uint32_t)i;   // (saves a device memcpy and an iota launch)
-        tiles_touched[i] = tiles_out;
-        rect[i] = rect_out;
-        clamped_out[i] = clamp_bits;
-        splat[3 * (size_t)i] = s0;
-        splat[3 * (size_t)i + 1] = s1;
-        splat[3 * (size_t)i + 2] = s2;
+
+        float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
+        float t1 = V[1] * p0 + V[5] * p1 + V[9] * p2 + V[13];
+        const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
+        if (t2 > GGR_NEAR_CULL && in_range) {
+            const float ph0 = PM[0] * p0 + PM[4] * p1 + PM[8] * p2 + PM[12];
+            const float ph1 = PM[1] * p0 + PM[5] * p1 + PM[9] * p2 + PM[13];
+            const float ph3 = PM[3] * p0 + PM[7] * p1 + PM[11] * p2 + PM[15];
+            const float pw = 1.0f / (ph3 + 0.0000001f);
+            const float ppx = ph0 * pw, ppy = ph1 * pw;
+
+            const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+            const float limx = GGR_FRUSTUM_CLAMP * tanfovx, limy = GGR_FRUSTUM_CLAMP * tanfovy;
+            const float txtz = t0 / t2, tytz = t1 / t2;
+            t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+            t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+            const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2);
+            const float J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
+            // A = J·R with R[i][j] = V[4*j+i]
+            float A0[3], A1[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                A0[j] = J00 * V[4 * j + 0] + J02 * V[4 * j + 2];
+                A1[j] = J11 * V[4 * j + 1] + J12 * V[4 * j + 2];
+            }
+            const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
+            float AS0[3], AS1[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { a0 += A0[k] * S[3 * k + j]; a1 += A1[k] * S[3 * k + j]; }
+                AS0[j] = a0; AS1[j] = a1;
+            }
+            float c00 = 0.f, c01 = 0.f, c11 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { c00 += AS0[k] * A0[k]; c01 += AS0[k] * A1[k]; c11 += AS1[k] * A1[k]; }
+            const float a = c00 + GGR_DILATION, b = c01, c = c11 + GGR_DILATION;
+            const float det = a * c - b * b;
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float con0 = c * det_inv, con1 = -b * det_inv, con2 = a * det_inv;
+                const float mid = 0.5f * (a + c);
+                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float l1 = mid + sq, l2 = mid - sq;
+                const int rad = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+                const float px = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
+                const float py = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
+                const int rminx = min(gx, max(0, (int)((px - (float)rad) / (float)GGR_TILE)));
+                const int rminy = min(gy, max(0, (int)((py - (float)rad) / (float)GGR_TILE)));
+                const int rmaxx = min(gx, max(0, (int)((px + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
+                const int rmaxy = min(gy, max(0, (int)((py + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
+                const int area = (rmaxx - rminx) * (rmaxy - rminy);
+                if (area != 0) {
+                    float rgb[3];
+                    if (colors_precomp) {
+                        rgb[0] = cp_in[0]; rgb[1] = cp_in[1]; rgb[2] = cp_in[2];
+                    } else {
+                        const int deg = sh_deg;
+                        float d0 = p0 - campos[0], d1 = p1 - campos[1], d2 = p2 - campos[2];
+                        const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+                        d0 /= len; d1 /= len; d2 /= len;
+                        float B[25];
+                        sh_basis(deg, d0, d1, d2, B);
+                        const int K = (deg + 1) * (deg + 1);
+                        const float* sh = sh_lds + threadIdx.x * sh_stride;
+                        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+                        for (int k = 0; k < K; k++) {
+                            r0 += B[k] * sh[k * sh_ks]; r1 += B[k] * sh[k * sh_ks + sh_cs]; r2 += B[k] * sh[k * sh_ks + 2 * sh_cs];
+                        }
+                        r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+                        clamp_bits = (r0 < 0.f ? 1u : 0u) | (r1 < 0.f ? 2u : 0u) | (r2 < 0.f ? 4u : 0u);
+                        rgb[0] = fmaxf(r0, 0.f); rgb[1] = fmaxf(r1, 0.f); rgb[2] = fmaxf(r2, 0.f);
+                    }
+                    rad_out = rad;
+                    key_out = __float_as_uint(t2) - GGR_KEY_BASE;  // > 0: t2 > 0.2f
+                    tiles_out = (uint32_t)area;
+                    // tile rows of view v sit below those of views 0 … v-1 in the virtual stacked image
+                    const uint32_t yo = (uint32_t)(v * gy);
+                    rect_out = make_uint2((uint32_t)rminx | (((uint32_t)rminy + yo) << 16),
+                                          (uint32_t)rmaxx | (((uint32_t)rmaxy + yo) << 16));
+                    s0 = make_float4(px, py, con0, con1);
+                    s1 = make_float4(con2, opac, rgb[0], rgb[1]);
+                    // 4th blended feature: the caller's aux value, or view z, or (fused GGRt depth pass, :240-269)
+                    // max(a + b·z_unscaled, 0) with z_unscaled = z / s
+                    float feat = t2;
+                    if (aux_precomp) feat = aux_in;
+                    else if (inf.aux_affine) feat = fmaxf(inf.aux_a + inf.aux_b * (t2 / in_s), 0.f);
+                    s2 = make_float4(rgb[2], feat, 2.f * logf(255.f * opac), 0.f);  // .z = qmax for the box cull
+                }
+            }
+        }
+        if (in_range) {
+            radii[o] = rad_out;
+            depth_key[o] = key_out;       // written straight into the depth sort's key / value input buffers
+            sort_vals[o] = (uint32_t)o;   // (saves a device memcpy and an iota launch)
+            tiles_touched[o] = tiles_out;
+            rect[o] = rect_out;
+            clamped_out[o] = clamp_bits;
+            splat[3 * o] = s0;
+            splat[3 * o + 1] = s1;
+            splat[3 * o + 2] = s2;
+        }
+        km = max(km, key_out);
     }
     // the largest sort key of this block: the depth sort derives its digit width from these (binning.hip)
     __shared__ uint32_t kmax[GGR_PRE_THREADS / 64];
-    uint32_t km = key_out;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, off));
     if ((threadIdx.x & 63) == 0) kmax[threadIdx.x >> 6] = km;
@@ -289,11 +302,11 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
-                           const float* aux_precomp, const float* viewmatrix, const float* projmatrix,
-                           const float* campos, int W, int H, float tanfovx, float tanfovy, int32_t* radii,
+                           const float* aux_precomp, ViewSet vs, int W, int H, int32_t* radii,
                            GeomLayout g, InputForm inf, hipStream_t s) {
     if (P <= 0) return;
-    const uint32_t zero_words = (uint32_t)ggr_sort_zero_words((size_t)P);  // the depth sort's work area (binning.hip)
+    // the depth sort's work area (binning.hip), sized for the V·P keys of all views
+    const uint32_t zero_words = (uint32_t)ggr_sort_zero_words((size_t)P * vs.V);
     const int threads = GGR_PRE_THREADS;
     const int blocks = (P + threads - 1) / threads;
     const int deg = ggr_sh_degree(D, shs ? M : 25, inf.sh_cap);
@@ -303,10 +316,16 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
     const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
     const size_t lds = shs ? (size_t)threads * row_stride * sizeof(float) : 0;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
-                       colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
-                       aux_precomp, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, radii, g.splat, g.keys_a,
-                       g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D, g.hist, zero_words, g.hist + zero_words, inf);
+    if (vs.V > 1)
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+                           aux_precomp, vs, W, H, radii, g.splat, g.keys_a, g.vals_a, g.tiles_touched, g.rect,
+                           g.clamped, g.cov3D, g.hist, zero_words, g.hist + zero_words, inf);
+    else
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+                           aux_precomp, vs, W, H, radii, g.splat, g.keys_a, g.vals_a, g.tiles_touched, g.rect,
+                           g.clamped, g.cov3D, g.hist, zero_words, g.hist + zero_words, inf);
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D,

@@ -38,14 +38,50 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     return v;
 }
 
-template <bool POSE>
+#define GGR_SH_MAXK 25
+
+// SH basis in the rasterizer's sign convention (same values as preprocess_fwd's); B must hold 25 floats
+__device__ __forceinline__ void sh_basis25(int deg, float x, float y, float z, float* B) {
+    B[0] = SH_C0;
+    if (deg > 0) {
+        B[1] = -SH_C1 * y; B[2] = SH_C1 * z; B[3] = -SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            B[4] = bSH_C2[0] * xy; B[5] = bSH_C2[1] * yz; B[6] = bSH_C2[2] * (2.f * zz - xx - yy);
+            B[7] = bSH_C2[3] * xz; B[8] = bSH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                B[9] = bSH_C3[0] * y * (3.f * xx - yy);
+                B[10] = bSH_C3[1] * xy * z;
+                B[11] = bSH_C3[2] * y * (4.f * zz - xx - yy);
+                B[12] = bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                B[13] = bSH_C3[4] * x * (4.f * zz - xx - yy);
+                B[14] = bSH_C3[5] * z * (xx - yy);
+                B[15] = bSH_C3[6] * x * (xx - 3.f * yy);
+                if (deg > 3) {
+                    B[16] = bSH_C4[0] * xy * (xx - yy);
+                    B[17] = bSH_C4[1] * yz * (3.f * xx - yy);
+                    B[18] = bSH_C4[2] * xy * (7.f * zz - 1.f);
+                    B[19] = bSH_C4[3] * yz * (7.f * zz - 3.f);
+                    B[20] = bSH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f);
+                    B[21] = bSH_C4[5] * xz * (7.f * zz - 3.f);
+                    B[22] = bSH_C4[6] * (xx - yy) * (7.f * zz - 1.f);
+                    B[23] = bSH_C4[7] * xz * (xx - 3.f * yy);
+                    B[24] = bSH_C4[8] * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
+                }
+            }
+        }
+    }
+}
+
+// MULTI = false: one view, the loop over views folds away at compile time (the reference's backward, and its register
+// budget); MULTI = true: the launch set's views in a run-time loop
+template <bool POSE, bool MULTI>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                       int has_colors_precomp, const float* __restrict__ scales,
                       const float* __restrict__ rotations, float scale_modifier,
-                      const float* __restrict__ cov3D, const float* __restrict__ viewmatrix,
-                      const float* __restrict__ projmatrix, const float* __restrict__ campos, int W, int H,
-                      float tanfovx, float tanfovy, const int32_t* __restrict__ radii,
+                      const float* __restrict__ cov3D, ViewSet vs, int W, int H,
+                      const int32_t* __restrict__ radii,
                       const uint32_t* __restrict__ clamped, const float* __restrict__ grad2d, int has_dz,
                       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
@@ -55,20 +91,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_stride]: SH in, dL/dSH out
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
-    const bool live = in_range && radii[i] > 0;
-    // the blend backward's per-Gaussian record (ggr_common.h GGR_G2D_*): its mean2D and opacity entries are
-    // final results and are copied out here; a Gaussian no tile list holds still has its zeroed record
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-    float g_z = 0.f;
-    if (in_range) {
-        const float4* rec = reinterpret_cast<const float4*>(grad2d) + (GGR_G2D_STRIDE / 4) * (size_t)i;
-        r0 = rec[0];  // r, g, b, mean.x
-        r1 = rec[1];  // mean.y, conic xx, xy, yy
-        const float2 r2 = *reinterpret_cast<const float2*>(rec + 2);  // opacity, z
-        g_z = r2.y;
-        dL_dmeans2D[3 * i] = r0.w; dL_dmeans2D[3 * i + 1] = r1.x; dL_dmeans2D[3 * i + 2] = 0.f;
-        dL_dopacity[i] = r2.x;
-    }
+    const int NV = MULTI ? vs.V : 1;
     // coalesced staging of the block's SH rows (same reason as in preprocess_fwd)
     const bool use_sh = !has_colors_precomp && shs != nullptr;
     const int deg = ggr_sh_degree(D, use_sh ? M : 25, inf.sh_cap);
@@ -81,298 +104,380 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const bool sh_flat = (sh_row & 1) != 0 && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
     // (input forms as in preprocess_fwd: channel-major rows are staged — and their gradient written — whole)
     const int copy_row = inf.sh_channel_major ? (int)sh_row : sh_rowf;
-    // rows longer than what is used (GGRt: 25 coefficients, 16 used): only the used 3K floats live in LDS
+    // rows longer than what is used (GGRt with sh_max_degree 3: 25 coefficients, 16 used): only the used 3K floats live in LDS
     const bool sh_compact = (int)sh_row > sh_rowf && sh_row <= 128 && (sh_flat || inf.sh_channel_major);
     const int sh_stride = sh_compact ? (sh_rowf | 1) : sh_flat ? (int)sh_row : (copy_row | 1);
     const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? (sh_compact ? sh_rowf / 3 : M) : 1;
-    if (inf.tanfov_dev) { tanfovx = inf.tanfov_dev[0]; tanfovy = inf.tanfov_dev[1]; }  // device-resident tan(fov/2)
-    const float in_s = inf.input_scale ? inf.input_scale[0] : 1.0f;
     // this thread's own inputs are requested BEFORE the SH staging, so that their round trip overlaps it
-    float V[16], PM[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PM[k] = projmatrix[k]; }
     const size_t il = (size_t)min(i, P - 1);
     const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];
-    float cin[6];
-    if (cov_is_input && inf.cov_stride == 9) {
-        const float* c9 = cov3D + 9 * il;
-        cin[0] = c9[0]; cin[1] = c9[1]; cin[2] = c9[2]; cin[3] = c9[4]; cin[4] = c9[5]; cin[5] = c9[8];
-    } else {
+    float cin_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cov_is_input) {   // the caller's covariances, in the caller's form; the scale / rotation path reads the
+        if (inf.cov_stride == 9) {  // per-view ones preprocess_fwd stored (already scaled) inside the view loop
+            const float* c9 = cov3D + 9 * il;
+            cin_in[0] = c9[0]; cin_in[1] = c9[1]; cin_in[2] = c9[2]; cin_in[3] = c9[4]; cin_in[4] = c9[5]; cin_in[5] = c9[8];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 6; k++) cin[k] = cov3D[6 * il + k];
+            for (int k = 0; k < 6; k++) cin_in[k] = cov3D[6 * il + k];
+        }
     }
-    const uint32_t clamp_in = clamped[il];
     if (use_sh) {
         if (sh_compact) stage_sh_rows_compact(sh_lds, shs, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
         else stage_sh_rows(sh_lds, shs, g0, nG, sh_row, copy_row, sh_stride, sh_flat);
         __syncthreads();
     }
 
-    float dmean[3] = {0.f, 0.f, 0.f};
-    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float dV[16], dPM[16], dcam[3] = {0.f, 0.f, 0.f};
-    if (POSE) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) { dV[k] = 0.f; dPM[k] = 0.f; }
-    }
+    // sums over the views of this launch set (one view: the reference's backward)
+    float dmean[3] = {0.f, 0.f, 0.f};      // w.r.t. the caller's (unscaled) means
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // w.r.t. the caller's covariances (cov_is_input) — else unused
+    float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+    float dop = 0.f, dcp[3] = {0.f, 0.f, 0.f};
     const int K = (deg + 1) * (deg + 1);
+    bool any_live = false;
 
-    if (live) {
-        const float p0 = in_s * m0, p1 = in_s * m1, p2 = in_s * m2;
-        float cov6[6];
-        // the caller's covariances come in the caller's form (preprocess_fwd applies the same); on the scale /
-        // rotation path they are what preprocess_fwd stored (already scaled)
-        const float s2 = cov_is_input ? in_s * in_s : 1.0f;
-#pragma unroll
-        for (int k = 0; k < 6; k++) cov6[k] = cin[k] * s2;
-        const float dcon0 = r1.y, dcon1 = r1.z, dcon2 = r1.w;
-
-        const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
-        float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
-        float t1 = V[1] * p0 + V[5] * p1 + V[9] * p2 + V[13];
-        const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
-        const float limx = GGR_FRUSTUM_CLAMP * tanfovx, limy = GGR_FRUSTUM_CLAMP * tanfovy;
-        const float txtz = t0 / t2, tytz = t1 / t2;
-        const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-        const float ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-        t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
-        t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
-        const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2);
-        const float J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
-        float A0[3], A1[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            A0[j] = J00 * V[4 * j + 0] + J02 * V[4 * j + 2];
-            A1[j] = J11 * V[4 * j + 1] + J12 * V[4 * j + 2];
+#pragma clang loop unroll(disable)
+    for (int v = 0; v < NV; v++) {
+        // (compiler barrier: without it the 3K SH coefficient reads from LDS below — invariant across views — are
+        // hoisted out of the loop into 75 registers, and the kernel needs 256 VGPRs = one block per CU)
+        __asm__ volatile("" ::: "memory");
+        const size_t o = (size_t)v * P + il;   // this Gaussian's state for view v
+        const bool live = in_range && radii[o] > 0;
+        any_live = any_live || live;
+        // the blend backward's per-Gaussian record (ggr_common.h GGR_G2D_*): its mean2D and opacity entries are
+        // final results; a Gaussian no tile list holds still has its zeroed record
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        float g_z = 0.f;
+        if (in_range) {
+            const float4* rec = reinterpret_cast<const float4*>(grad2d) + (GGR_G2D_STRIDE / 4) * o;
+            r0 = rec[0];  // r, g, b, mean.x
+            r1 = rec[1];  // mean.y, conic xx, xy, yy
+            const float2 r2 = *reinterpret_cast<const float2*>(rec + 2);  // opacity, z
+            g_z = r2.y;
+            dL_dmeans2D[3 * o] = r0.w; dL_dmeans2D[3 * o + 1] = r1.x; dL_dmeans2D[3 * o + 2] = 0.f;
+            dop += r2.x;
         }
-        const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
-        float SA0[3], SA1[3];
+        float V[16], PM[16];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            SA0[j] = A0[0] * S[j] + A0[1] * S[3 + j] + A0[2] * S[6 + j];
-            SA1[j] = A1[0] * S[j] + A1[1] * S[3 + j] + A1[2] * S[6 + j];
-        }
-        const float a = SA0[0] * A0[0] + SA0[1] * A0[1] + SA0[2] * A0[2] + GGR_DILATION;
-        const float b = SA0[0] * A1[0] + SA0[1] * A1[1] + SA0[2] * A1[2];
-        const float c = SA1[0] * A1[0] + SA1[1] * A1[1] + SA1[2] * A1[2] + GGR_DILATION;
-        const float denom = a * c - b * b;
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
-        if (denom2inv != 0.f) {
-            dL_da = denom2inv * (-c * c * dcon0 + 2.f * b * c * dcon1 + (denom - a * c) * dcon2);
-            dL_dc = denom2inv * (-a * a * dcon2 + 2.f * a * b * dcon1 + (denom - a * c) * dcon0);
-            dL_db = denom2inv * 2.f * (b * c * dcon0 - (denom + 2.f * b * b) * dcon1 + a * b * dcon2);
-            dcov[0] = A0[0] * A0[0] * dL_da + A0[0] * A1[0] * dL_db + A1[0] * A1[0] * dL_dc;
-            dcov[3] = A0[1] * A0[1] * dL_da + A0[1] * A1[1] * dL_db + A1[1] * A1[1] * dL_dc;
-            dcov[5] = A0[2] * A0[2] * dL_da + A0[2] * A1[2] * dL_db + A1[2] * A1[2] * dL_dc;
-            dcov[1] = 2.f * A0[0] * A0[1] * dL_da + (A0[0] * A1[1] + A0[1] * A1[0]) * dL_db + 2.f * A1[0] * A1[1] * dL_dc;
-            dcov[2] = 2.f * A0[0] * A0[2] * dL_da + (A0[0] * A1[2] + A0[2] * A1[0]) * dL_db + 2.f * A1[0] * A1[2] * dL_dc;
-            dcov[4] = 2.f * A0[2] * A0[1] * dL_da + (A0[1] * A1[2] + A0[2] * A1[1]) * dL_db + 2.f * A1[1] * A1[2] * dL_dc;
-        }
-        float dA0[3], dA1[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            dA0[j] = 2.f * SA0[j] * dL_da + SA1[j] * dL_db;
-            dA1[j] = 2.f * SA1[j] * dL_dc + SA0[j] * dL_db;
-        }
-        // A = J·R, R[k][j] = V[4*j+k]
-        const float dJ00 = dA0[0] * V[0] + dA0[1] * V[4] + dA0[2] * V[8];
-        const float dJ02 = dA0[0] * V[2] + dA0[1] * V[6] + dA0[2] * V[10];
-        const float dJ11 = dA1[0] * V[1] + dA1[1] * V[5] + dA1[2] * V[9];
-        const float dJ12 = dA1[0] * V[2] + dA1[1] * V[6] + dA1[2] * V[10];
-        const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
-        const float dtx = xmul * -fx * tz2 * dJ02;
-        const float dty = ymul * -fy * tz2 * dJ12;
-        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * t0) * tz3 * dJ02 + (2.f * fy * t1) * tz3 * dJ12;
-        // t = [p 1]·V → dL/dp = R^T dt  (R row k = V[4*j+k] over j)
-        dmean[0] = V[0] * dtx + V[1] * dty + V[2] * dtz;
-        dmean[1] = V[4] * dtx + V[5] * dty + V[6] * dtz;
-        dmean[2] = V[8] * dtx + V[9] * dty + V[10] * dtz;
+        for (int k = 0; k < 16; k++) { V[k] = vs.view[16 * v + k]; PM[k] = vs.proj[16 * v + k]; }
+        const float* campos = vs.campos + 3 * v;
+        const float tanfovx = vs.tanfov ? vs.tanfov[2 * v] : vs.tanfovx;      // device-resident tan(fov/2)
+        const float tanfovy = vs.tanfov ? vs.tanfov[2 * v + 1] : vs.tanfovy;
+        const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
+        float dV[16], dPM[16], dcam[3] = {0.f, 0.f, 0.f};
         if (POSE) {
-            // through t: dL/dV[4*j+k] += p_j * dt_k (j<3), dL/dV[12+k] += dt_k
-            const float dt[3] = {dtx, dty, dtz};
-            const float pp[3] = {p0, p1, p2};
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < 16; k++) { dV[k] = 0.f; dPM[k] = 0.f; }
+        }
+        if (in_range && dL_daux) dL_daux[o] = (live && has_dz) ? g_z : 0.f;  // aux feature: gradient is the blend's
+
+        if (live) {
+            const float p0 = in_s * m0, p1 = in_s * m1, p2 = in_s * m2;
+            float cov6[6];
+            // the caller's covariances come in the caller's form (preprocess_fwd applies the same); on the scale /
+            // rotation path they are what preprocess_fwd stored for this view (already scaled)
+            const float s2 = cov_is_input ? in_s * in_s : 1.0f;
+            if (cov_is_input) {
 #pragma unroll
-                for (int j = 0; j < 3; j++) dV[4 * j + k] += pp[j] * dt[k];
-                dV[12 + k] += dt[k];
+                for (int k = 0; k < 6; k++) cov6[k] = cin_in[k] * s2;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov6[k] = cov3D[6 * o + k];
             }
-            // through R in A = J·R: dL/dR[k][j] = Σ_i J[i][k] dA[i][j];  R[k][j] = V[4*j+k]
+            const float dcon0 = r1.y, dcon1 = r1.z, dcon2 = r1.w;
+
+            const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+            float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
+            float t1 = V[1] * p0 + V[5] * p1 + V[9] * p2 + V[13];
+            const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
+            const float limx = GGR_FRUSTUM_CLAMP * tanfovx, limy = GGR_FRUSTUM_CLAMP * tanfovy;
+            const float txtz = t0 / t2, tytz = t1 / t2;
+            const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+            const float ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+            t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+            t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+            const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2);
+            const float J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
+            float A0[3], A1[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                dV[4 * j + 0] += J00 * dA0[j];
-                dV[4 * j + 1] += J11 * dA1[j];
-                dV[4 * j + 2] += J02 * dA0[j] + J12 * dA1[j];
+                A0[j] = J00 * V[4 * j + 0] + J02 * V[4 * j + 2];
+                A1[j] = J11 * V[4 * j + 1] + J12 * V[4 * j + 2];
             }
-        }
-
-        // mean2D (NDC units) → mean3D through the perspective divide
-        const float d2x = r0.w, d2y = r1.x;
-        const float mh0 = PM[0] * p0 + PM[4] * p1 + PM[8] * p2 + PM[12];
-        const float mh1 = PM[1] * p0 + PM[5] * p1 + PM[9] * p2 + PM[13];
-        const float mh3 = PM[3] * p0 + PM[7] * p1 + PM[11] * p2 + PM[15];
-        const float mw = 1.0f / (mh3 + 0.0000001f);
-        const float mul1 = mh0 * mw * mw, mul2 = mh1 * mw * mw;
-        dmean[0] += (PM[0] * mw - PM[3] * mul1) * d2x + (PM[1] * mw - PM[3] * mul2) * d2y;
-        dmean[1] += (PM[4] * mw - PM[7] * mul1) * d2x + (PM[5] * mw - PM[7] * mul2) * d2y;
-        dmean[2] += (PM[8] * mw - PM[11] * mul1) * d2x + (PM[9] * mw - PM[11] * mul2) * d2y;
-        if (POSE) {
-            // ndc_x = mh0*mw, ndc_y = mh1*mw:  d/dmh0 = mw·d2x, d/dmh1 = mw·d2y, d/dmh3 = -(mul1·d2x + mul2·d2y)
-            const float g0 = mw * d2x, g1 = mw * d2y, g3 = -(mul1 * d2x + mul2 * d2y);
-            const float pp[4] = {p0, p1, p2, 1.f};
+            const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
+            float SA0[3], SA1[3];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                dPM[4 * j + 0] += pp[j] * g0;
-                dPM[4 * j + 1] += pp[j] * g1;
-                dPM[4 * j + 3] += pp[j] * g3;
+            for (int j = 0; j < 3; j++) {
+                SA0[j] = A0[0] * S[j] + A0[1] * S[3 + j] + A0[2] * S[6 + j];
+                SA1[j] = A1[0] * S[j] + A1[1] * S[3 + j] + A1[2] * S[6 + j];
             }
-        }
+            const float a = SA0[0] * A0[0] + SA0[1] * A0[1] + SA0[2] * A0[2] + GGR_DILATION;
+            const float b = SA0[0] * A1[0] + SA0[1] * A1[1] + SA0[2] * A1[2];
+            const float c = SA1[0] * A1[0] + SA1[1] * A1[1] + SA1[2] * A1[2] + GGR_DILATION;
+            const float denom = a * c - b * b;
+            const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+            float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+            float dcv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this view's dL/d(scaled covariance)
+            if (denom2inv != 0.f) {
+                dL_da = denom2inv * (-c * c * dcon0 + 2.f * b * c * dcon1 + (denom - a * c) * dcon2);
+                dL_dc = denom2inv * (-a * a * dcon2 + 2.f * a * b * dcon1 + (denom - a * c) * dcon0);
+                dL_db = denom2inv * 2.f * (b * c * dcon0 - (denom + 2.f * b * b) * dcon1 + a * b * dcon2);
+                dcv[0] = A0[0] * A0[0] * dL_da + A0[0] * A1[0] * dL_db + A1[0] * A1[0] * dL_dc;
+                dcv[3] = A0[1] * A0[1] * dL_da + A0[1] * A1[1] * dL_db + A1[1] * A1[1] * dL_dc;
+                dcv[5] = A0[2] * A0[2] * dL_da + A0[2] * A1[2] * dL_db + A1[2] * A1[2] * dL_dc;
+                dcv[1] = 2.f * A0[0] * A0[1] * dL_da + (A0[0] * A1[1] + A0[1] * A1[0]) * dL_db + 2.f * A1[0] * A1[1] * dL_dc;
+                dcv[2] = 2.f * A0[0] * A0[2] * dL_da + (A0[0] * A1[2] + A0[2] * A1[0]) * dL_db + 2.f * A1[0] * A1[2] * dL_dc;
+                dcv[4] = 2.f * A0[2] * A0[1] * dL_da + (A0[1] * A1[2] + A0[2] * A1[1]) * dL_db + 2.f * A1[1] * A1[2] * dL_dc;
+            }
+            float dA0[3], dA1[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                dA0[j] = 2.f * SA0[j] * dL_da + SA1[j] * dL_db;
+                dA1[j] = 2.f * SA1[j] * dL_dc + SA0[j] * dL_db;
+            }
+            // A = J·R, R[k][j] = V[4*j+k]
+            const float dJ00 = dA0[0] * V[0] + dA0[1] * V[4] + dA0[2] * V[8];
+            const float dJ02 = dA0[0] * V[2] + dA0[1] * V[6] + dA0[2] * V[10];
+            const float dJ11 = dA1[0] * V[1] + dA1[1] * V[5] + dA1[2] * V[9];
+            const float dJ12 = dA1[0] * V[2] + dA1[1] * V[6] + dA1[2] * V[10];
+            const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
+            const float dtx = xmul * -fx * tz2 * dJ02;
+            const float dty = ymul * -fy * tz2 * dJ12;
+            const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * t0) * tz3 * dJ02 + (2.f * fy * t1) * tz3 * dJ12;
+            // t = [p 1]·V → dL/dp = R^T dt  (R row k = V[4*j+k] over j)
+            float dmv[3];  // this view's dL/d(scaled mean)
+            dmv[0] = V[0] * dtx + V[1] * dty + V[2] * dtz;
+            dmv[1] = V[4] * dtx + V[5] * dty + V[6] * dtz;
+            dmv[2] = V[8] * dtx + V[9] * dty + V[10] * dtz;
+            if (POSE) {
+                // through t: dL/dV[4*j+k] += p_j * dt_k (j<3), dL/dV[12+k] += dt_k
+                const float dt[3] = {dtx, dty, dtz};
+                const float pp[3] = {p0, p1, p2};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+#pragma unroll
+                    for (int j = 0; j < 3; j++) dV[4 * j + k] += pp[j] * dt[k];
+                    dV[12 + k] += dt[k];
+                }
+                // through R in A = J·R: dL/dR[k][j] = Σ_i J[i][k] dA[i][j];  R[k][j] = V[4*j+k]
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    dV[4 * j + 0] += J00 * dA0[j];
+                    dV[4 * j + 1] += J11 * dA1[j];
+                    dV[4 * j + 2] += J02 * dA0[j] + J12 * dA1[j];
+                }
+            }
 
-        // depth-as-feature gradient: z = t2 = [p 1]·V[:,2]
-        if (has_dz && !dL_daux) {
-            float gz = g_z;
-            if (inf.aux_affine)  // feature = max(a + b·z/s, 0)
-                gz = (inf.aux_a + inf.aux_b * (t2 / in_s) > 0.f) ? gz * (inf.aux_b / in_s) : 0.f;
-            dmean[0] += V[2] * gz; dmean[1] += V[6] * gz; dmean[2] += V[10] * gz;
-            if (POSE) { dV[2] += p0 * gz; dV[6] += p1 * gz; dV[10] += p2 * gz; dV[14] += gz; }
-        }
+            // mean2D (NDC units) → mean3D through the perspective divide
+            const float d2x = r0.w, d2y = r1.x;
+            const float mh0 = PM[0] * p0 + PM[4] * p1 + PM[8] * p2 + PM[12];
+            const float mh1 = PM[1] * p0 + PM[5] * p1 + PM[9] * p2 + PM[13];
+            const float mh3 = PM[3] * p0 + PM[7] * p1 + PM[11] * p2 + PM[15];
+            const float mw = 1.0f / (mh3 + 0.0000001f);
+            const float mul1 = mh0 * mw * mw, mul2 = mh1 * mw * mw;
+            dmv[0] += (PM[0] * mw - PM[3] * mul1) * d2x + (PM[1] * mw - PM[3] * mul2) * d2y;
+            dmv[1] += (PM[4] * mw - PM[7] * mul1) * d2x + (PM[5] * mw - PM[7] * mul2) * d2y;
+            dmv[2] += (PM[8] * mw - PM[11] * mul1) * d2x + (PM[9] * mw - PM[11] * mul2) * d2y;
+            if (POSE) {
+                // ndc_x = mh0*mw, ndc_y = mh1*mw:  d/dmh0 = mw·d2x, d/dmh1 = mw·d2y, d/dmh3 = -(mul1·d2x + mul2·d2y)
+                const float g0_ = mw * d2x, g1_ = mw * d2y, g3_ = -(mul1 * d2x + mul2 * d2y);
+                const float pp[4] = {p0, p1, p2, 1.f};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    dPM[4 * j + 0] += pp[j] * g0_;
+                    dPM[4 * j + 1] += pp[j] * g1_;
+                    dPM[4 * j + 3] += pp[j] * g3_;
+                }
+            }
 
-        // colour
-        float dc0 = r0.x, dc1 = r0.y, dc2 = r0.z;
-        if (has_colors_precomp) {
-            dL_dcolors_precomp[3 * i] = dc0; dL_dcolors_precomp[3 * i + 1] = dc1; dL_dcolors_precomp[3 * i + 2] = dc2;
-        } else {
-            const uint32_t cl = clamp_in;
-            if (cl & 1u) dc0 = 0.f;
-            if (cl & 2u) dc1 = 0.f;
-            if (cl & 4u) dc2 = 0.f;
-            const float vx = p0 - campos[0], vy = p1 - campos[1], vz = p2 - campos[2];
-            const float len = sqrtf(vx * vx + vy * vy + vz * vz);
-            const float x = vx / len, y = vy / len, z = vz / len;
-            float* sh = sh_lds + threadIdx.x * sh_stride;  // read the coefficient, then overwrite it
-            float* dsh = sh;                                // with its gradient (written out below)
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-            // helper: coefficient k with basis value Bk and basis gradient (bx,by,bz)
+            // depth-as-feature gradient: z = t2 = [p 1]·V[:,2]
+            if (has_dz && !dL_daux) {
+                float gz = g_z;
+                if (inf.aux_affine)  // feature = max(a + b·z/s, 0)
+                    gz = (inf.aux_a + inf.aux_b * (t2 / in_s) > 0.f) ? gz * (inf.aux_b / in_s) : 0.f;
+                dmv[0] += V[2] * gz; dmv[1] += V[6] * gz; dmv[2] += V[10] * gz;
+                if (POSE) { dV[2] += p0 * gz; dV[6] += p1 * gz; dV[10] += p2 * gz; dV[14] += gz; }
+            }
+
+            // colour
+            float dc0 = r0.x, dc1 = r0.y, dc2 = r0.z;
+            if (has_colors_precomp) {
+                dcp[0] += dc0; dcp[1] += dc1; dcp[2] += dc2;
+            } else {
+                const uint32_t cl = clamped[o];
+                if (cl & 1u) dc0 = 0.f;
+                if (cl & 2u) dc1 = 0.f;
+                if (cl & 4u) dc2 = 0.f;
+                const float vx = p0 - campos[0], vy = p1 - campos[1], vz = p2 - campos[2];
+                const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+                const float x = vx / len, y = vy / len, z = vz / len;
+                const float* sh = sh_lds + threadIdx.x * sh_stride;
+                float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+                // helper: coefficient k with basis gradient (bx,by,bz) — the direction term only; dL/dSH itself
+                // (Σ over views of basis × colour gradient) is formed after the view loop, channel by channel
 #define SH_TERM(k, Bk, bx, by, bz)                                                                     \
     {                                                                                                  \
         const int o0 = (k) * sh_ks, o1 = o0 + sh_cs, o2 = o1 + sh_cs;                                  \
         const float s0 = sh[o0], s1 = sh[o1], s2 = sh[o2];                                             \
-        dsh[o0] = (Bk) * dc0; dsh[o1] = (Bk) * dc1; dsh[o2] = (Bk) * dc2;                              \
         const float sd = s0 * dc0 + s1 * dc1 + s2 * dc2;                                               \
         ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                          \
     }
-            SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)
-            if (deg > 0) {
-                SH_TERM(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)
-                SH_TERM(2, SH_C1 * z, 0.f, 0.f, SH_C1)
-                SH_TERM(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)
-                if (deg > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    SH_TERM(4, bSH_C2[0] * xy, bSH_C2[0] * y, bSH_C2[0] * x, 0.f)
-                    SH_TERM(5, bSH_C2[1] * yz, 0.f, bSH_C2[1] * z, bSH_C2[1] * y)
-                    SH_TERM(6, bSH_C2[2] * (2.f * zz - xx - yy), bSH_C2[2] * -2.f * x, bSH_C2[2] * -2.f * y, bSH_C2[2] * 4.f * z)
-                    SH_TERM(7, bSH_C2[3] * xz, bSH_C2[3] * z, 0.f, bSH_C2[3] * x)
-                    SH_TERM(8, bSH_C2[4] * (xx - yy), bSH_C2[4] * 2.f * x, bSH_C2[4] * -2.f * y, 0.f)
-                    if (deg > 2) {
-                        SH_TERM(9, bSH_C3[0] * y * (3.f * xx - yy), bSH_C3[0] * 6.f * xy, bSH_C3[0] * 3.f * (xx - yy), 0.f)
-                        SH_TERM(10, bSH_C3[1] * xy * z, bSH_C3[1] * yz, bSH_C3[1] * xz, bSH_C3[1] * xy)
-                        SH_TERM(11, bSH_C3[2] * y * (4.f * zz - xx - yy), bSH_C3[2] * -2.f * xy,
-                                bSH_C3[2] * (-3.f * yy + 4.f * zz - xx), bSH_C3[2] * 8.f * yz)
-                        SH_TERM(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), bSH_C3[3] * -6.f * xz,
-                                bSH_C3[3] * -6.f * yz, bSH_C3[3] * 3.f * (2.f * zz - xx - yy))
-                        SH_TERM(13, bSH_C3[4] * x * (4.f * zz - xx - yy), bSH_C3[4] * (-3.f * xx + 4.f * zz - yy),
-                                bSH_C3[4] * -2.f * xy, bSH_C3[4] * 8.f * xz)
-                        SH_TERM(14, bSH_C3[5] * z * (xx - yy), bSH_C3[5] * 2.f * xz, bSH_C3[5] * -2.f * yz,
-                                bSH_C3[5] * (xx - yy))
-                        SH_TERM(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)
-                        if (deg > 3) {  // band 4 (oracle/ggr_oracle.c header): plain polynomial derivatives
-                            const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f, c21 = 21.f * zz - 3.f;
-                            const float xmy = xx - yy, x3y = xx - 3.f * yy, y3x = 3.f * xx - yy;
-                            SH_TERM(16, bSH_C4[0] * xy * xmy, bSH_C4[0] * y * y3x, bSH_C4[0] * x * x3y, 0.f)
-                            SH_TERM(17, bSH_C4[1] * yz * y3x, bSH_C4[1] * 6.f * xy * z, bSH_C4[1] * 3.f * z * xmy, bSH_C4[1] * y * y3x)
-                            SH_TERM(18, bSH_C4[2] * xy * a7, bSH_C4[2] * y * a7, bSH_C4[2] * x * a7, bSH_C4[2] * 14.f * xy * z)
-                            SH_TERM(19, bSH_C4[3] * yz * b7, 0.f, bSH_C4[3] * z * b7, bSH_C4[3] * y * c21)
-                            SH_TERM(20, bSH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f), 0.f, 0.f, bSH_C4[4] * z * (140.f * zz - 60.f))
-                            SH_TERM(21, bSH_C4[5] * xz * b7, bSH_C4[5] * z * b7, 0.f, bSH_C4[5] * x * c21)
-                            SH_TERM(22, bSH_C4[6] * xmy * a7, bSH_C4[6] * 2.f * x * a7, bSH_C4[6] * -2.f * y * a7, bSH_C4[6] * 14.f * z * xmy)
-                            SH_TERM(23, bSH_C4[7] * xz * x3y, bSH_C4[7] * 3.f * z * xmy, bSH_C4[7] * -6.f * xy * z, bSH_C4[7] * x * x3y)
-                            SH_TERM(24, bSH_C4[8] * (xx * x3y - yy * y3x), bSH_C4[8] * 4.f * x * x3y, bSH_C4[8] * -4.f * y * y3x, 0.f)
+                SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)
+                if (deg > 0) {
+                    SH_TERM(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)
+                    SH_TERM(2, SH_C1 * z, 0.f, 0.f, SH_C1)
+                    SH_TERM(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)
+                    if (deg > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        SH_TERM(4, bSH_C2[0] * xy, bSH_C2[0] * y, bSH_C2[0] * x, 0.f)
+                        SH_TERM(5, bSH_C2[1] * yz, 0.f, bSH_C2[1] * z, bSH_C2[1] * y)
+                        SH_TERM(6, bSH_C2[2] * (2.f * zz - xx - yy), bSH_C2[2] * -2.f * x, bSH_C2[2] * -2.f * y, bSH_C2[2] * 4.f * z)
+                        SH_TERM(7, bSH_C2[3] * xz, bSH_C2[3] * z, 0.f, bSH_C2[3] * x)
+                        SH_TERM(8, bSH_C2[4] * (xx - yy), bSH_C2[4] * 2.f * x, bSH_C2[4] * -2.f * y, 0.f)
+                        if (deg > 2) {
+                            SH_TERM(9, bSH_C3[0] * y * (3.f * xx - yy), bSH_C3[0] * 6.f * xy, bSH_C3[0] * 3.f * (xx - yy), 0.f)
+                            SH_TERM(10, bSH_C3[1] * xy * z, bSH_C3[1] * yz, bSH_C3[1] * xz, bSH_C3[1] * xy)
+                            SH_TERM(11, bSH_C3[2] * y * (4.f * zz - xx - yy), bSH_C3[2] * -2.f * xy,
+                                    bSH_C3[2] * (-3.f * yy + 4.f * zz - xx), bSH_C3[2] * 8.f * yz)
+                            SH_TERM(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), bSH_C3[3] * -6.f * xz,
+                                    bSH_C3[3] * -6.f * yz, bSH_C3[3] * 3.f * (2.f * zz - xx - yy))
+                            SH_TERM(13, bSH_C3[4] * x * (4.f * zz - xx - yy), bSH_C3[4] * (-3.f * xx + 4.f * zz - yy),
+                                    bSH_C3[4] * -2.f * xy, bSH_C3[4] * 8.f * xz)
+                            SH_TERM(14, bSH_C3[5] * z * (xx - yy), bSH_C3[5] * 2.f * xz, bSH_C3[5] * -2.f * yz,
+                                    bSH_C3[5] * (xx - yy))
+                            SH_TERM(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)
+                            if (deg > 3) {  // band 4 (oracle/ggr_oracle.c header): plain polynomial derivatives
+                                const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f, c21 = 21.f * zz - 3.f;
+                                const float xmy = xx - yy, x3y = xx - 3.f * yy, y3x = 3.f * xx - yy;
+                                SH_TERM(16, bSH_C4[0] * xy * xmy, bSH_C4[0] * y * y3x, bSH_C4[0] * x * x3y, 0.f)
+                                SH_TERM(17, bSH_C4[1] * yz * y3x, bSH_C4[1] * 6.f * xy * z, bSH_C4[1] * 3.f * z * xmy, bSH_C4[1] * y * y3x)
+                                SH_TERM(18, bSH_C4[2] * xy * a7, bSH_C4[2] * y * a7, bSH_C4[2] * x * a7, bSH_C4[2] * 14.f * xy * z)
+                                SH_TERM(19, bSH_C4[3] * yz * b7, 0.f, bSH_C4[3] * z * b7, bSH_C4[3] * y * c21)
+                                SH_TERM(20, bSH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f), 0.f, 0.f, bSH_C4[4] * z * (140.f * zz - 60.f))
+                                SH_TERM(21, bSH_C4[5] * xz * b7, bSH_C4[5] * z * b7, 0.f, bSH_C4[5] * x * c21)
+                                SH_TERM(22, bSH_C4[6] * xmy * a7, bSH_C4[6] * 2.f * x * a7, bSH_C4[6] * -2.f * y * a7, bSH_C4[6] * 14.f * z * xmy)
+                                SH_TERM(23, bSH_C4[7] * xz * x3y, bSH_C4[7] * 3.f * z * xmy, bSH_C4[7] * -6.f * xy * z, bSH_C4[7] * x * x3y)
+                                SH_TERM(24, bSH_C4[8] * (xx * x3y - yy * y3x), bSH_C4[8] * 4.f * x * x3y, bSH_C4[8] * -4.f * y * y3x, 0.f)
+                            }
                         }
                     }
                 }
-            }
 #undef SH_TERM
-            const float sum2 = vx * vx + vy * vy + vz * vz;
-            const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-            const float gx_ = ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
-            const float gy_ = (-vx * vy * ddx + (sum2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
-            const float gz_ = (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * inv32;
-            dmean[0] += gx_; dmean[1] += gy_; dmean[2] += gz_;
-            if (POSE) { dcam[0] -= gx_; dcam[1] -= gy_; dcam[2] -= gz_; }
-        }
-
-        if (scales && dL_dscales) {
-            const float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
-            const float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
-                                2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
-                                2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)};
-            const float sm = scale_modifier * in_s;  // d(sc)/d(scale input)
-            const float sc[3] = {scale_modifier * (in_s * scales[3 * i]), scale_modifier * (in_s * scales[3 * i + 1]),
-                                 scale_modifier * (in_s * scales[3 * i + 2])};
-            float Mx[9];
-#pragma unroll
-            for (int ii = 0; ii < 3; ii++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) Mx[3 * ii + j] = R[3 * ii + j] * sc[j];
-            const float dS[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
-                                 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
-            float dR[9], ds[3];
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                float acc = 0.f;
-#pragma unroll
-                for (int ii = 0; ii < 3; ii++) {
-                    float dMij = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) dMij += dS[3 * ii + k] * Mx[3 * k + j];
-                    dMij *= 2.f;
-                    acc += dMij * R[3 * ii + j];
-                    dR[3 * ii + j] = dMij * sc[j];
-                }
-                ds[j] = acc * sm;
+                const float sum2 = vx * vx + vy * vy + vz * vz;
+                const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+                const float gx_ = ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
+                const float gy_ = (-vx * vy * ddx + (sum2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
+                const float gz_ = (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * inv32;
+                dmv[0] += gx_; dmv[1] += gy_; dmv[2] += gz_;
+                if (POSE) { dcam[0] -= gx_; dcam[1] -= gy_; dcam[2] -= gz_; }
             }
-            dL_dscales[3 * i] = ds[0]; dL_dscales[3 * i + 1] = ds[1]; dL_dscales[3 * i + 2] = ds[2];
-            dL_drotations[4 * i] = 2.f * (z * (dR[3] - dR[1]) + y * (dR[2] - dR[6]) + x * (dR[7] - dR[5]));
-            dL_drotations[4 * i + 1] = 2.f * (y * (dR[1] + dR[3]) + z * (dR[2] + dR[6]) + r * (dR[7] - dR[5])) - 4.f * x * (dR[4] + dR[8]);
-            dL_drotations[4 * i + 2] = 2.f * (x * (dR[1] + dR[3]) + r * (dR[2] - dR[6]) + z * (dR[5] + dR[7])) - 4.f * y * (dR[0] + dR[8]);
-            dL_drotations[4 * i + 3] = 2.f * (r * (dR[3] - dR[1]) + x * (dR[2] + dR[6]) + y * (dR[5] + dR[7])) - 4.f * z * (dR[0] + dR[4]);
+            // chain through the on-load input forms: means·s, cov·s²
+            dmean[0] += in_s * dmv[0]; dmean[1] += in_s * dmv[1]; dmean[2] += in_s * dmv[2];
+            if (cov_is_input) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) dcov[k] += dcv[k] * s2;
+            }
+
+            if (scales && dL_dscales) {
+                const float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
+                const float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                                    2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                                    2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)};
+                const float sm = scale_modifier * in_s;  // d(sc)/d(scale input)
+                const float sc[3] = {scale_modifier * (in_s * scales[3 * i]), scale_modifier * (in_s * scales[3 * i + 1]),
+                                     scale_modifier * (in_s * scales[3 * i + 2])};
+                float Mx[9];
+#pragma unroll
+                for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) Mx[3 * ii + j] = R[3 * ii + j] * sc[j];
+                const float dS[9] = {dcv[0], 0.5f * dcv[1], 0.5f * dcv[2], 0.5f * dcv[1], dcv[3], 0.5f * dcv[4],
+                                     0.5f * dcv[2], 0.5f * dcv[4], dcv[5]};
+                float dR[9];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int ii = 0; ii < 3; ii++) {
+                        float dMij = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) dMij += dS[3 * ii + k] * Mx[3 * k + j];
+                        dMij *= 2.f;
+                        acc += dMij * R[3 * ii + j];
+                        dR[3 * ii + j] = dMij * sc[j];
+                    }
+                    dsc[j] += acc * sm;
+                }
+                drot[0] += 2.f * (z * (dR[3] - dR[1]) + y * (dR[2] - dR[6]) + x * (dR[7] - dR[5]));
+                drot[1] += 2.f * (y * (dR[1] + dR[3]) + z * (dR[2] + dR[6]) + r * (dR[7] - dR[5])) - 4.f * x * (dR[4] + dR[8]);
+                drot[2] += 2.f * (x * (dR[1] + dR[3]) + r * (dR[2] - dR[6]) + z * (dR[5] + dR[7])) - 4.f * y * (dR[0] + dR[8]);
+                drot[3] += 2.f * (r * (dR[3] - dR[1]) + x * (dR[2] + dR[6]) + y * (dR[5] + dR[7])) - 4.f * z * (dR[0] + dR[4]);
+            }
         }
-    } else if (in_range) {
-        // culled Gaussian: all gradients are zero
-        if (use_sh) {
-            float* dsh = sh_lds + threadIdx.x * sh_stride;
-            for (int k = 0; k < (sh_compact ? sh_rowf : sh_flat ? (int)sh_row : copy_row); k++) dsh[k] = 0.f;
-        }
-        if (has_colors_precomp) { dL_dcolors_precomp[3 * i] = 0.f; dL_dcolors_precomp[3 * i + 1] = 0.f; dL_dcolors_precomp[3 * i + 2] = 0.f; }
-        if (scales && dL_dscales) {
-            dL_dscales[3 * i] = dL_dscales[3 * i + 1] = dL_dscales[3 * i + 2] = 0.f;
-            dL_drotations[4 * i] = dL_drotations[4 * i + 1] = dL_drotations[4 * i + 2] = dL_drotations[4 * i + 3] = 0.f;
+        if (POSE) {
+            // Camera gradient of view v: 35 components summed over ALL Gaussians.  Atomics would put ≈ P/64 × 35 adds on
+            // 35 addresses (measured: 2.5 ms at P = 1 M); instead wave (DPP) → block (LDS) reduction, one row of
+            // 35 partials per (view, block) written with plain stores, and pose_finish_kernel sums the rows.
+            __shared__ float wred[4][40];  // 640 B: keeps the dynamic LDS base 16-B aligned (guide G17)
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float sv = wave_sum_lane63(dV[k]);
+                const float sp = wave_sum_lane63(dPM[k]);
+                if (lane == 63) { wred[wave][k] = sv; wred[wave][16 + k] = sp; }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float scm = wave_sum_lane63(dcam[k]);
+                if (lane == 63) wred[wave][32 + k] = scm;
+            }
+            __syncthreads();
+            if (threadIdx.x < 35)
+                pose_acc[((size_t)v * gridDim.x + blockIdx.x) * 64 + threadIdx.x] =
+                    wred[0][threadIdx.x] + wred[1][threadIdx.x] + wred[2][threadIdx.x] + wred[3][threadIdx.x];
+            __syncthreads();  // (wred is reused by the next view)
         }
     }
+
+    // ---- outputs: sums over the views -------------------------------------------------------------------------
     if (use_sh) {
-        // coalesced write-out of dL/dSH: the first 3K floats of every row from LDS, the rest zero
-        if (sh_compact) {
-            // nothing to clear: the compact row holds used coefficients only
-        } else if (live && inf.sh_channel_major) {  // unused coefficients (k ≥ K) of every channel get zero gradient
-            float* dsh = sh_lds + threadIdx.x * sh_stride;
-            for (int c = 0; c < 3; c++)
-                for (int k = K; k < M; k++) dsh[c * M + k] = 0.f;
-        } else if (sh_flat && live) {  // unused coefficients (k ≥ 16) of a live row get zero gradient
-            float* dsh = sh_lds + threadIdx.x * sh_stride;
-            for (int k = sh_rowf; k < (int)sh_row; k++) dsh[k] = 0.f;
+        // dL/dSH[k][c] = Σ_views B_k(direction of the view) · dL/dcolour_c(view), one colour channel at a time: 25
+        // accumulators instead of 75 (the basis is recomputed per (channel, view) — the kernel is HBM-bound, not
+        // VALU-bound — where 75 accumulators carried through the view loop cost 256 VGPRs + spills).  The Gaussian's
+        // LDS row then takes the gradient: the coefficients are no longer needed.
+        float* dsh = sh_lds + threadIdx.x * sh_stride;
+        if (in_range && !sh_compact) {
+            const int rowlen = sh_flat ? (int)sh_row : copy_row;
+            for (int k = 0; k < rowlen; k++) dsh[k] = 0.f;  // unused coefficients of a staged row: zero gradient
+        }
+#pragma clang loop unroll(disable)
+        for (int c = 0; c < 3; c++) {
+            float acc[GGR_SH_MAXK];
+#pragma unroll
+            for (int k = 0; k < GGR_SH_MAXK; k++) acc[k] = 0.f;
+#pragma clang loop unroll(disable)
+            for (int v = 0; v < NV; v++) {
+                const size_t o = (size_t)v * P + il;
+                if (in_range && radii[o] > 0 && !((clamped[o] >> c) & 1u)) {
+                    const float dc = grad2d[GGR_G2D_STRIDE * o + GGR_G2D_RGB + c];
+                    const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
+                    const float vx = in_s * m0 - vs.campos[3 * v], vy = in_s * m1 - vs.campos[3 * v + 1],
+                                vz = in_s * m2 - vs.campos[3 * v + 2];
+                    const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+                    float B[GGR_SH_MAXK];
+                    sh_basis25(deg, vx / len, vy / len, vz / len, B);
+#pragma unroll
+                    for (int k = 0; k < GGR_SH_MAXK; k++)
+                        if (k < K) acc[k] += B[k] * dc;
+                }
+            }
+            if (in_range) {
+#pragma unroll
+                for (int k = 0; k < GGR_SH_MAXK; k++)
+                    if (k < K) dsh[k * sh_ks + c * sh_cs] = acc[k];
+            }
         }
         __syncthreads();
+        // coalesced write-out of dL/dSH: the first 3K floats of every row from LDS, the rest zero
         if (sh_compact) {
             write_sh_rows_compact(dL_dsh, sh_lds, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
         } else if (sh_flat) {
@@ -386,12 +491,12 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             const int q_row = (int)(sh_row >> 2), q_used = copy_row >> 2;
             for (int j = threadIdx.x; j < nG * q_row; j += blockDim.x) {
                 const int g = j / q_row, q = j - g * q_row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (q < q_used) {
                     const float* d = sh_lds + g * sh_stride + 4 * q;
-                    v = make_float4(d[0], d[1], d[2], d[3]);
+                    v4 = make_float4(d[0], d[1], d[2], d[3]);
                 }
-                *reinterpret_cast<float4*>(dL_dsh + (g0 + g) * sh_row + 4 * q) = v;
+                *reinterpret_cast<float4*>(dL_dsh + (g0 + g) * sh_row + 4 * q) = v4;
             }
         } else {
             const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -401,60 +506,46 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     dL_dsh[(g0 + g) * sh_row + k] = k < copy_row ? sh_lds[g * sh_stride + k] : 0.f;
         }
     }
-    if (in_range && dL_daux) dL_daux[i] = (live && has_dz) ? g_z : 0.f;  // aux feature: gradient is the blend's
     if (in_range) {
-        // chain through the on-load input forms: means·s, cov·s² (the upper-triangle gather leaves the lower
-        // triangle of a [P,3,3] gradient at zero, as autograd does for the reference's fancy index)
-        dL_dmeans3D[3 * i] = in_s * dmean[0]; dL_dmeans3D[3 * i + 1] = in_s * dmean[1]; dL_dmeans3D[3 * i + 2] = in_s * dmean[2];
-        const float s2o = cov_is_input ? in_s * in_s : 1.0f;
+        dL_dopacity[i] = dop;
+        dL_dmeans3D[3 * i] = dmean[0]; dL_dmeans3D[3 * i + 1] = dmean[1]; dL_dmeans3D[3 * i + 2] = dmean[2];
+        if (has_colors_precomp) { dL_dcolors_precomp[3 * i] = dcp[0]; dL_dcolors_precomp[3 * i + 1] = dcp[1]; dL_dcolors_precomp[3 * i + 2] = dcp[2]; }
+        if (scales && dL_dscales) {
+            dL_dscales[3 * i] = dsc[0]; dL_dscales[3 * i + 1] = dsc[1]; dL_dscales[3 * i + 2] = dsc[2];
+            dL_drotations[4 * i] = drot[0]; dL_drotations[4 * i + 1] = drot[1]; dL_drotations[4 * i + 2] = drot[2];
+            dL_drotations[4 * i + 3] = drot[3];
+        }
+        // (the upper-triangle gather leaves the lower triangle of a [P,3,3] gradient at zero, as autograd does for
+        // the reference's fancy index)
         if (cov_is_input && inf.cov_stride == 9) {
             float* d9 = dL_dcov3D + 9 * (size_t)i;
-            d9[0] = dcov[0] * s2o; d9[1] = dcov[1] * s2o; d9[2] = dcov[2] * s2o;
-            d9[3] = 0.f;           d9[4] = dcov[3] * s2o; d9[5] = dcov[4] * s2o;
-            d9[6] = 0.f;           d9[7] = 0.f;           d9[8] = dcov[5] * s2o;
+            d9[0] = dcov[0]; d9[1] = dcov[1]; d9[2] = dcov[2];
+            d9[3] = 0.f;     d9[4] = dcov[3]; d9[5] = dcov[4];
+            d9[6] = 0.f;     d9[7] = 0.f;     d9[8] = dcov[5];
         } else {
 #pragma unroll
-            for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k] * s2o;
+            for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
         }
     }
-    if (POSE) {
-        // Camera gradient: 35 components summed over ALL Gaussians.  Atomics would put ≈ P/64 × 35 adds on
-        // 35 addresses (measured: 2.5 ms at P = 1 M); instead wave (DPP) → block (LDS) reduction, one row of
-        // 35 partials per block written with plain stores, and pose_finish_kernel sums the rows.
-        __shared__ float wred[4][40];  // 640 B: keeps the dynamic LDS base 16-B aligned (guide G17)
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float sv = wave_sum_lane63(dV[k]);
-            const float sp = wave_sum_lane63(dPM[k]);
-            if (lane == 63) { wred[wave][k] = sv; wred[wave][16 + k] = sp; }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float sc = wave_sum_lane63(dcam[k]);
-            if (lane == 63) wred[wave][32 + k] = sc;
-        }
-        __syncthreads();
-        if (threadIdx.x < 35)
-            pose_acc[64 + (size_t)blockIdx.x * 64 + threadIdx.x] =
-                wred[0][threadIdx.x] + wred[1][threadIdx.x] + wred[2][threadIdx.x] + wred[3][threadIdx.x];
-    }
+    (void)any_live;
 }
 
-// pose_acc[k] = Σ_blocks pose_acc[64 + b·64 + k]  (one workgroup per component, fixed order → deterministic)
+// dL/d(camera of view v)[k] = Σ_blocks pose_acc[(v·nblocks + b)·64 + k]  (one workgroup per (component, view), fixed
+// order → deterministic)
 __global__ void __launch_bounds__(256)
 pose_finish_kernel(const float* __restrict__ pose_acc, int nblocks, float* __restrict__ dL_dview,
                    float* __restrict__ dL_dproj, float* __restrict__ dL_dcampos) {
     __shared__ float sh[256];
-    const int k = blockIdx.x, tid = threadIdx.x;
+    const int k = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    pose_acc += (size_t)v * nblocks * 64;
     float acc = 0.f;
     // sixteen rows per trip, all loads issued before the first add (clamped index, masked add)
     for (int b0 = 0; b0 < nblocks; b0 += 16 * 256) {
-        float v[16];
+        float vv[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = pose_acc[64 + (size_t)min(b0 + u * 256 + tid, nblocks - 1) * 64 + k];
+        for (int u = 0; u < 16; u++) vv[u] = pose_acc[(size_t)min(b0 + u * 256 + tid, nblocks - 1) * 64 + k];
 #pragma unroll
-        for (int u = 0; u < 16; u++) acc += b0 + u * 256 + tid < nblocks ? v[u] : 0.f;
+        for (int u = 0; u < 16; u++) acc += b0 + u * 256 + tid < nblocks ? vv[u] : 0.f;
     }
     sh[tid] = acc;
     __syncthreads();
@@ -463,17 +554,16 @@ pose_finish_kernel(const float* __restrict__ pose_acc, int nblocks, float* __res
         __syncthreads();
     }
     if (tid == 0) {  // straight into the caller's tensors (was: 3 tiny device-to-device copies = 3 more launches)
-        if (k < 16) dL_dview[k] = sh[0];
-        else if (k < 32) dL_dproj[k - 16] = sh[0];
-        else dL_dcampos[k - 32] = sh[0];
+        if (k < 16) dL_dview[16 * v + k] = sh[0];
+        else if (k < 32) dL_dproj[16 * v + k - 16] = sh[0];
+        else dL_dcampos[3 * v + k - 32] = sh[0];
     }
 }
 
 void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs,
                            int has_colors_precomp, const float* scales, const float* rotations,
-                           float scale_modifier, const float* cov3D, const float* viewmatrix,
-                           const float* projmatrix, const float* campos, int W, int H, float tanfovx,
-                           float tanfovy, const int32_t* radii, const uint32_t* clamped,
+                           float scale_modifier, const float* cov3D, ViewSet vs, int W, int H, const int32_t* radii,
+                           const uint32_t* clamped,
                            const float* grad2d, int has_dz, float* dL_dmeans3D, float* dL_dmeans2D,
                            float* dL_dopacity, float* dL_dsh,
                            float* dL_dcolors_precomp, float* dL_dcov3D, float* dL_dscales,
@@ -488,17 +578,20 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
     const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
     const size_t lds = (!has_colors_precomp && shs) ? (size_t)256 * row_stride * sizeof(float) : 0;
+#define GGR_LAUNCH_PBWD(POSE_, MULTI_)                                                                                   \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<POSE_, MULTI_>), dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,     \
+                       has_colors_precomp, scales, rotations, scale_modifier, cov3D, vs, W, H, radii, clamped, grad2d,     \
+                       has_dz, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales,   \
+                       dL_drotations, dL_daux, pose_acc, inf, cov_is_input)
+    const bool multi = vs.V > 1;
     if (pose_acc) {
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
-                           has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
-                           campos, W, H, tanfovx, tanfovy, radii, clamped, grad2d, has_dz, dL_dmeans3D,
-                           dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc, inf, cov_is_input);
-        hipLaunchKernelGGL(pose_finish_kernel, dim3(35), dim3(256), 0, s, pose_acc, blocks, dL_dview, dL_dproj, dL_dcampos);
-    } else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,
-                           has_colors_precomp, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix,
-                           campos, W, H, tanfovx, tanfovy, radii, clamped, grad2d, has_dz, dL_dmeans3D,
-                           dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales, dL_drotations, dL_daux, pose_acc, inf, cov_is_input);
+        if (multi) GGR_LAUNCH_PBWD(true, true); else GGR_LAUNCH_PBWD(true, false);
+        hipLaunchKernelGGL(pose_finish_kernel, dim3(35, vs.V), dim3(256), 0, s, pose_acc, blocks, dL_dview, dL_dproj,
+                           dL_dcampos);
+    } else {
+        if (multi) GGR_LAUNCH_PBWD(false, true); else GGR_LAUNCH_PBWD(false, false);
+    }
+#undef GGR_LAUNCH_PBWD
 }
 
 }  // namespace ggr

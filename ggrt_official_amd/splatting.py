@@ -276,7 +276,7 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
 def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape,
                        background_color: Tensor, gaussians: Gaussians, view_to_batch,
                        depth_mode: Optional[DepthRenderingMode] = None, scale_invariant: bool = True,
-                       device_camera: bool = True, list_capacity: int = 0):
+                       device_camera: bool = True, list_capacity: int = 0, batched: bool = True):
     """The call site with NO torch operation on a Gaussian-sized tensor (SURVEY.md §8 a2 "where time goes"):
 
     * ``device_camera``: view / projection matrices, camera position, tan(fov/2) and 1/near of all views come
@@ -290,6 +290,11 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
       backward; ``covariances`` stay ``[g,3,3]`` — the upper-triangle gather (:116,124) happens on load;
     * ``depth_mode="depth"``: the depth-as-colour feature ``max(0.5 + C0·z, 0)`` (:240-269) is formed inside the
       kernel from the view depth (``aux_affine``); the other modes still build it with torch.
+
+    * ``batched``: the views that share a batch element go through ONE launch set (``rasterize_views``, SURVEY.md
+      §8f-2): the Gaussians are read once for all of them, one depth sort, one tile-list build, one blend launch,
+      gradients summed over the views inside the backward kernel — instead of one rasterizer call per view and
+      autograd adding the per-view gradient tensors.  A batch element with a single view takes the per-view call.
 
     Same images and gradients as ``render_color_and_depth`` / ``render_cuda`` up to fp32 rounding
     (``tests/test_callsite_fused.py``).  extrinsics/intrinsics/near/far/background: one row per view.
@@ -333,8 +338,41 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     g_means, g_cov, g_sh, g_op = (per_batch(gaussians.means), per_batch(gaussians.covariances),
                                   per_batch(gaussians.harmonics), per_batch(gaussians.opacities))
     g_scales, g_rot = per_batch(gaussians.scales), per_batch(gaussians.rotations)
-    colors, depths = [], []
+    colors, depths = [None] * n, [None] * n
+    groups = {}
     for i in range(n):
+        groups.setdefault(int(view_to_batch[i]), []).append(i)
+    single = []
+    for b, idx in groups.items():
+        if not (batched and len(idx) > 1 and extrinsics.is_cuda):
+            single += idx
+            continue
+        # ---- all views of batch element b in one launch set ----
+        from .rasterizer import rasterize_views
+        ii = torch.as_tensor(idx, device=view.device)
+        contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
+        take = (lambda t: t[idx[0]:idx[0] + len(idx)]) if contiguous else (lambda t: t.index_select(0, ii))
+        aux, aux_affine = None, None
+        if depth_mode == "depth":
+            aux_affine = (0.5, SH_C0)
+        elif depth_mode is not None:  # per-Gaussian feature per view, built with torch: [V,P]
+            feat = depth_feature(take(ext_orig), g_means[b][None].expand(len(idx), -1, -1), take(near), take(far), depth_mode)
+            aux = (0.5 + SH_C0 * feat).clamp(min=0.0)
+        tf = take(tanfov) if tanfov is not None else torch.tensor([tan_host[i] for i in idx], dtype=torch.float32,
+                                                                  device=view.device)
+        settings = GaussianRasterizationSettings(
+            image_height=h, image_width=w, tanfovx=0.0, tanfovy=0.0, bg=background_color[idx[0]], scale_modifier=1.0,
+            viewmatrix=view[idx[0]], projmatrix=full[idx[0]], sh_degree=degree, campos=campos[idx[0]],
+            prefiltered=False, list_capacity=list_capacity * len(idx), sh_channel_major=True, aux_affine=aux_affine)
+        kw = dict(cov3D_precomp=g_cov[b]) if fused_cov else dict(scales=g_scales[b], rotations=g_rot[b])
+        col, _, dep = rasterize_views(g_means[b], g_op[b][..., None], take(view), take(full), take(campos),
+                                      take(background_color), tf, settings, shs=g_sh[b], aux_precomp=aux,
+                                      input_scale=None if scale is None else take(scale), **kw)
+        if len(idx) == n and contiguous:  # every view in this one launch set: hand its outputs on as they are
+            return col, (dep if depth_mode is not None else None)
+        for k, i in enumerate(idx):
+            colors[i], depths[i] = col[k], dep[k]
+    for i in single:
         b = int(view_to_batch[i])
         aux, aux_affine = None, None
         if depth_mode == "depth":
@@ -355,8 +393,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
         sink = torch.empty_like(means).requires_grad_()
         out = GaussianRasterizer(settings)(means3D=means, means2D=sink, opacities=g_op[b][..., None], shs=g_sh[b],
                                            aux_precomp=aux, **kw)
-        colors.append(out[0])
-        depths.append(out[2])
+        colors[i], depths[i] = out[0], out[2]
     # one view (GGRt's usual call): a view of the rasterizer's output instead of a stack — no copy kernel forward,
     # none backward
     stack = lambda ts: ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 3
+#define GGR_ABI_VERSION 4
 
 enum {
     GGR_OK = 0,
@@ -185,6 +185,41 @@ int ggr_forward(const GgrSettings* settings, const GgrForwardIn* in, GgrForwardO
 /* replaces diff_gaussian_rasterization._C.rasterize_gaussians_backward */
 int ggr_backward(const GgrSettings* settings, const GgrBackwardIn* in, GgrBackwardOut* out,
                  void* stream);
+
+/* ---- V views of the SAME Gaussians in one launch set ------------------------------------------
+ * The reference renders the views of a sample in a Python loop — one rasterizer call per view over a v× repeated copy
+ * of the Gaussian tensors (decoder_splatting_cuda.py:40-60, cuda_splatting.py:93-127), each call with its own
+ * preprocess, sort and blend launches, and autograd then adds the V per-view gradient tensors.  Here the P Gaussians
+ * are read ONCE for all views (their SH rows stay in LDS while the cameras change), the V·P depth keys go through ONE
+ * sort, the tiles of the views are stacked into one tile-list build and one blend launch (a 480×352 frame has 660
+ * tiles — four views fill the chip where one cannot), and the backward returns the gradients already summed over
+ * the views.  Results per view equal ggr_forward / ggr_backward's: same lists, bit-identical images. */
+typedef struct GgrViews {
+    int32_t num_views;           /* V >= 1;  V·P < 2^31, V·ceil(H/16) <= 65535, V·tiles <= 2^24 */
+    const float* viewmatrix;     /* device [V,4,4] */
+    const float* projmatrix;     /* device [V,4,4] */
+    const float* campos;         /* device [V,3] */
+    const float* bg;             /* device [V,3] */
+    const float* tanfov;         /* device [V,2] (tanfovx, tanfovy) or NULL: settings->tanfovx/y for every view */
+    const float* input_scale;    /* device [V] or NULL (see GgrForwardIn.input_scale, which is ignored here) */
+} GgrViews;
+
+size_t ggr_geom_bytes_views(int32_t num_points, int32_t num_views);
+size_t ggr_image_bytes_views(int32_t width, int32_t height, int32_t num_views);
+size_t ggr_work_bytes_views(int32_t num_points, int32_t width, int32_t height, int32_t num_views);
+size_t ggr_backward_scratch_bytes_views(int32_t num_points, int32_t num_views);
+
+/* As ggr_forward with the camera fields of `settings` (bg, viewmatrix, projmatrix, campos, tanfov_dev) ignored in
+ * favour of `views`.  Shapes: out_color [V,3,H,W], radii [V,P], out_depth [V,H,W]; aux_precomp, when given, [V,P];
+ * buffers sized with the *_views queries; num_rendered counts the entries of all views. */
+int ggr_forward_views(const GgrSettings* settings, const GgrViews* views, const GgrForwardIn* in, GgrForwardOut* out,
+                      GgrAllocFn alloc, void* alloc_ctx, void* stream);
+
+/* As ggr_backward.  dL_dout_color [V,3,H,W], dL_dout_depth [V,H,W] or NULL, radii [V,P].  Gradients w.r.t. the
+ * Gaussians come out SUMMED over the views ([P,…]); dL_dmeans2D and dL_daux are per view ([V,P,3], [V,P]); the camera
+ * gradients are per view ([V,4,4], [V,4,4], [V,3]). */
+int ggr_backward_views(const GgrSettings* settings, const GgrViews* views, const GgrBackwardIn* in, GgrBackwardOut* out,
+                       void* stream);
 
 /* The per-view camera quantities of the call site in one launch (cuda_splatting.py:18-46,66-73,82-89 and
  * ggrt/geometry/projection.py:233-247): for each of n views  scale = scale_invariant ? 1/near : 1,

@@ -19,7 +19,7 @@ def test_library_builds_and_loads():
     path = _build.build_library()
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.ggr_abi_version() == 3
+    assert lib.ggr_abi_version() == 4
 
 
 def test_every_declared_symbol_is_exported_and_bound():
