@@ -30,8 +30,10 @@ namespace ggr {
 // agent-scope atomic loads (bypass the reader's L1), so no fence is needed and no ordering between
 // different words is assumed.  Tiles take their index from an atomic ticket, so a tile only ever
 // waits for tiles whose workgroups are already running: no dispatch-order assumption.
-// A sort tile looks back GGR_LOOKBACK predecessors per trip (all loads in flight together): the ≈ 250 tiles of a
-// 1 M-key sort run in lockstep, a one-predecessor-per-trip chain is then ≈ √(2·tiles) dependent ≈ 1 µs polls long.
+// A sort tile looks back GGR_LOOKBACK predecessors per trip (all loads in flight together) while all tiles of the
+// sort are resident at once (≤ 384 tiles: they run in lockstep and every tile starts far from the inclusive frontier),
+// one per trip beyond that (measured, tools/sort_bench.hip: 1 M keys 0.098 ms with 8 per trip / 0.101 with 1;
+// 4 M keys 0.335 / 0.313 ms — in the pipelined regime the extra polls only add traffic).
 
 #define GGR_FLAG_AGG 1u
 #define GGR_FLAG_INCL 2u
@@ -269,16 +271,17 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
                 int t = (int)tile - 1;
                 uint32_t spins = 0;
                 bool done = false;
+                const int depth = ntiles > 384u ? 1 : GGR_LOOKBACK;  // (uniform)
                 while (!done) {
                     uint32_t v[GGR_LOOKBACK];
 #pragma unroll
                     for (int j = 0; j < GGR_LOOKBACK; j++)
-                        v[j] = __hip_atomic_load(status + (size_t)max(t - j, 0) * bins + d, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                        v[j] = j < depth ? __hip_atomic_load(status + (size_t)max(t - j, 0) * bins + d, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT) : 0u;
                     int used = 0;
 #pragma unroll
                     for (int j = 0; j < GGR_LOOKBACK; j++) {
-                        if (!done && used == j && t - j >= 0) {
+                        if (!done && used == j && j < depth && t - j >= 0) {
                             const uint32_t flag = v[j] >> 30;
                             if (flag != 0) {
                                 excl += v[j] & GGR_COUNT_MASK;

@@ -135,24 +135,35 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int K = (deg + 1) * (deg + 1);
     bool any_live = false;
 
+    // the per-view loads (gradient record, radius, clamp bits) are requested ONE VIEW AHEAD: with them inside the
+    // iteration that uses them every view is a dependent ≈ 2 µs round trip per block
+    const float4* recs = reinterpret_cast<const float4*>(grad2d);
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
+    float2 n2 = make_float2(0.f, 0.f);
+    int nrad = 0;
+    {
+        const float4* rec = recs + (GGR_G2D_STRIDE / 4) * il;
+        n0 = rec[0]; n1 = rec[1]; n2 = *reinterpret_cast<const float2*>(rec + 2); nrad = radii[il];
+    }
 #pragma clang loop unroll(disable)
     for (int v = 0; v < NV; v++) {
         // (compiler barrier: without it the 3K SH coefficient reads from LDS below — invariant across views — are
         // hoisted out of the loop into 75 registers, and the kernel needs 256 VGPRs = one block per CU)
         __asm__ volatile("" ::: "memory");
         const size_t o = (size_t)v * P + il;   // this Gaussian's state for view v
-        const bool live = in_range && radii[o] > 0;
-        any_live = any_live || live;
         // the blend backward's per-Gaussian record (ggr_common.h GGR_G2D_*): its mean2D and opacity entries are
         // final results; a Gaussian no tile list holds still has its zeroed record
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-        float g_z = 0.f;
+        const float4 r0 = n0;  // r, g, b, mean.x
+        const float4 r1 = n1;  // mean.y, conic xx, xy, yy
+        const float2 r2 = n2;  // opacity, z
+        const bool live = in_range && nrad > 0;
+        any_live = any_live || live;
+        if (MULTI && v + 1 < NV) {
+            const float4* rec = recs + (GGR_G2D_STRIDE / 4) * (o + P);
+            n0 = rec[0]; n1 = rec[1]; n2 = *reinterpret_cast<const float2*>(rec + 2); nrad = radii[o + P];
+        }
+        const float g_z = r2.y;
         if (in_range) {
-            const float4* rec = reinterpret_cast<const float4*>(grad2d) + (GGR_G2D_STRIDE / 4) * o;
-            r0 = rec[0];  // r, g, b, mean.x
-            r1 = rec[1];  // mean.y, conic xx, xy, yy
-            const float2 r2 = *reinterpret_cast<const float2*>(rec + 2);  // opacity, z
-            g_z = r2.y;
             dL_dmeans2D[3 * o] = r0.w; dL_dmeans2D[3 * o + 1] = r1.x; dL_dmeans2D[3 * o + 2] = 0.f;
             dop += r2.x;
         }
@@ -163,7 +174,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float tanfovx = vs.tanfov ? vs.tanfov[2 * v] : vs.tanfovx;      // device-resident tan(fov/2)
         const float tanfovy = vs.tanfov ? vs.tanfov[2 * v + 1] : vs.tanfovy;
         const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
-        float dV[16], dPM[16], dcam[3] = {0.f, 0.f, 0.f};
+        float dV[16], dPM[16];
         if (POSE) {
 #pragma unroll
             for (int k = 0; k < 16; k++) { dV[k] = 0.f; dPM[k] = 0.f; }
@@ -298,78 +309,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 if (POSE) { dV[2] += p0 * gz; dV[6] += p1 * gz; dV[10] += p2 * gz; dV[14] += gz; }
             }
 
-            // colour
-            float dc0 = r0.x, dc1 = r0.y, dc2 = r0.z;
-            if (has_colors_precomp) {
-                dcp[0] += dc0; dcp[1] += dc1; dcp[2] += dc2;
-            } else {
-                const uint32_t cl = clamped[o];
-                if (cl & 1u) dc0 = 0.f;
-                if (cl & 2u) dc1 = 0.f;
-                if (cl & 4u) dc2 = 0.f;
-                const float vx = p0 - campos[0], vy = p1 - campos[1], vz = p2 - campos[2];
-                const float len = sqrtf(vx * vx + vy * vy + vz * vz);
-                const float x = vx / len, y = vy / len, z = vz / len;
-                const float* sh = sh_lds + threadIdx.x * sh_stride;
-                float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-                // helper: coefficient k with basis gradient (bx,by,bz) — the direction term only; dL/dSH itself
-                // (Σ over views of basis × colour gradient) is formed after the view loop, channel by channel
-#define SH_TERM(k, Bk, bx, by, bz)                                                                     \
-    {                                                                                                  \
-        const int o0 = (k) * sh_ks, o1 = o0 + sh_cs, o2 = o1 + sh_cs;                                  \
-        const float s0 = sh[o0], s1 = sh[o1], s2 = sh[o2];                                             \
-        const float sd = s0 * dc0 + s1 * dc1 + s2 * dc2;                                               \
-        ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                          \
-    }
-                SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)
-                if (deg > 0) {
-                    SH_TERM(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)
-                    SH_TERM(2, SH_C1 * z, 0.f, 0.f, SH_C1)
-                    SH_TERM(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)
-                    if (deg > 1) {
-                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                        SH_TERM(4, bSH_C2[0] * xy, bSH_C2[0] * y, bSH_C2[0] * x, 0.f)
-                        SH_TERM(5, bSH_C2[1] * yz, 0.f, bSH_C2[1] * z, bSH_C2[1] * y)
-                        SH_TERM(6, bSH_C2[2] * (2.f * zz - xx - yy), bSH_C2[2] * -2.f * x, bSH_C2[2] * -2.f * y, bSH_C2[2] * 4.f * z)
-                        SH_TERM(7, bSH_C2[3] * xz, bSH_C2[3] * z, 0.f, bSH_C2[3] * x)
-                        SH_TERM(8, bSH_C2[4] * (xx - yy), bSH_C2[4] * 2.f * x, bSH_C2[4] * -2.f * y, 0.f)
-                        if (deg > 2) {
-                            SH_TERM(9, bSH_C3[0] * y * (3.f * xx - yy), bSH_C3[0] * 6.f * xy, bSH_C3[0] * 3.f * (xx - yy), 0.f)
-                            SH_TERM(10, bSH_C3[1] * xy * z, bSH_C3[1] * yz, bSH_C3[1] * xz, bSH_C3[1] * xy)
-                            SH_TERM(11, bSH_C3[2] * y * (4.f * zz - xx - yy), bSH_C3[2] * -2.f * xy,
-                                    bSH_C3[2] * (-3.f * yy + 4.f * zz - xx), bSH_C3[2] * 8.f * yz)
-                            SH_TERM(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), bSH_C3[3] * -6.f * xz,
-                                    bSH_C3[3] * -6.f * yz, bSH_C3[3] * 3.f * (2.f * zz - xx - yy))
-                            SH_TERM(13, bSH_C3[4] * x * (4.f * zz - xx - yy), bSH_C3[4] * (-3.f * xx + 4.f * zz - yy),
-                                    bSH_C3[4] * -2.f * xy, bSH_C3[4] * 8.f * xz)
-                            SH_TERM(14, bSH_C3[5] * z * (xx - yy), bSH_C3[5] * 2.f * xz, bSH_C3[5] * -2.f * yz,
-                                    bSH_C3[5] * (xx - yy))
-                            SH_TERM(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)
-                            if (deg > 3) {  // band 4 (oracle/ggr_oracle.c header): plain polynomial derivatives
-                                const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f, c21 = 21.f * zz - 3.f;
-                                const float xmy = xx - yy, x3y = xx - 3.f * yy, y3x = 3.f * xx - yy;
-                                SH_TERM(16, bSH_C4[0] * xy * xmy, bSH_C4[0] * y * y3x, bSH_C4[0] * x * x3y, 0.f)
-                                SH_TERM(17, bSH_C4[1] * yz * y3x, bSH_C4[1] * 6.f * xy * z, bSH_C4[1] * 3.f * z * xmy, bSH_C4[1] * y * y3x)
-                                SH_TERM(18, bSH_C4[2] * xy * a7, bSH_C4[2] * y * a7, bSH_C4[2] * x * a7, bSH_C4[2] * 14.f * xy * z)
-                                SH_TERM(19, bSH_C4[3] * yz * b7, 0.f, bSH_C4[3] * z * b7, bSH_C4[3] * y * c21)
-                                SH_TERM(20, bSH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f), 0.f, 0.f, bSH_C4[4] * z * (140.f * zz - 60.f))
-                                SH_TERM(21, bSH_C4[5] * xz * b7, bSH_C4[5] * z * b7, 0.f, bSH_C4[5] * x * c21)
-                                SH_TERM(22, bSH_C4[6] * xmy * a7, bSH_C4[6] * 2.f * x * a7, bSH_C4[6] * -2.f * y * a7, bSH_C4[6] * 14.f * z * xmy)
-                                SH_TERM(23, bSH_C4[7] * xz * x3y, bSH_C4[7] * 3.f * z * xmy, bSH_C4[7] * -6.f * xy * z, bSH_C4[7] * x * x3y)
-                                SH_TERM(24, bSH_C4[8] * (xx * x3y - yy * y3x), bSH_C4[8] * 4.f * x * x3y, bSH_C4[8] * -4.f * y * y3x, 0.f)
-                            }
-                        }
-                    }
-                }
-#undef SH_TERM
-                const float sum2 = vx * vx + vy * vy + vz * vz;
-                const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-                const float gx_ = ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
-                const float gy_ = (-vx * vy * ddx + (sum2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
-                const float gz_ = (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * inv32;
-                dmv[0] += gx_; dmv[1] += gy_; dmv[2] += gz_;
-                if (POSE) { dcam[0] -= gx_; dcam[1] -= gy_; dcam[2] -= gz_; }
-            }
+            // colour: precomputed colours take the blend's gradient as it is; the SH path follows in its own loops
+            // over the views below (keeping it inside this loop costs ≈ 100 more live registers)
+            if (has_colors_precomp) { dcp[0] += r0.x; dcp[1] += r0.y; dcp[2] += r0.z; }
             // chain through the on-load input forms: means·s, cov·s²
             dmean[0] += in_s * dmv[0]; dmean[1] += in_s * dmv[1]; dmean[2] += in_s * dmv[2];
             if (cov_is_input) {
@@ -425,11 +367,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 const float sp = wave_sum_lane63(dPM[k]);
                 if (lane == 63) { wred[wave][k] = sv; wred[wave][16 + k] = sp; }
             }
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float scm = wave_sum_lane63(dcam[k]);
-                if (lane == 63) wred[wave][32 + k] = scm;
-            }
+            if (lane == 63) { wred[wave][32] = 0.f; wred[wave][33] = 0.f; wred[wave][34] = 0.f; }  // (campos: SH loop below)
             __syncthreads();
             if (threadIdx.x < 35)
                 pose_acc[((size_t)v * gridDim.x + blockIdx.x) * 64 + threadIdx.x] =
@@ -444,6 +382,112 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         // accumulators instead of 75 (the basis is recomputed per (channel, view) — the kernel is HBM-bound, not
         // VALU-bound — where 75 accumulators carried through the view loop cost 256 VGPRs + spills).  The Gaussian's
         // LDS row then takes the gradient: the coefficients are no longer needed.
+        // (1) the view-direction term of every view: dL/dmean += (∂dir/∂mean)ᵀ Σ_k ∇B_k(dir)·(sh_k · dL/dcolour)
+        // (loads one view ahead, as above)
+        float4 q0 = recs[(GGR_G2D_STRIDE / 4) * il];
+        int qrad = radii[il];
+        uint32_t qcl = clamped[il];
+#pragma clang loop unroll(disable)
+        for (int v = 0; v < NV; v++) {
+            __asm__ volatile("" ::: "memory");
+            const size_t o = (size_t)v * P + il;
+            const float4 r0 = q0;  // r, g, b, –
+            const bool live = in_range && qrad > 0;
+            const uint32_t cl = qcl;
+            if (MULTI && v + 1 < NV) { q0 = recs[(GGR_G2D_STRIDE / 4) * (o + P)]; qrad = radii[o + P]; qcl = clamped[o + P]; }
+            float dcam[3] = {0.f, 0.f, 0.f};
+            if (live) {
+            float dc0 = r0.x, dc1 = r0.y, dc2 = r0.z;
+            const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
+            const float p0 = in_s * m0, p1 = in_s * m1, p2 = in_s * m2;
+            const float* campos = vs.campos + 3 * v;
+            float dmv[3] = {0.f, 0.f, 0.f};
+            {
+            if (cl & 1u) dc0 = 0.f;
+            if (cl & 2u) dc1 = 0.f;
+            if (cl & 4u) dc2 = 0.f;
+            const float vx = p0 - campos[0], vy = p1 - campos[1], vz = p2 - campos[2];
+            const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+            const float x = vx / len, y = vy / len, z = vz / len;
+            const float* sh = sh_lds + threadIdx.x * sh_stride;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            // helper: coefficient k with basis gradient (bx,by,bz) — the direction term only; dL/dSH itself
+            // (Σ over views of basis × colour gradient) is formed after the view loop, channel by channel
+#define SH_TERM(k, Bk, bx, by, bz)                                                                     \
+{                                                                                                  \
+    const int o0 = (k) * sh_ks, o1 = o0 + sh_cs, o2 = o1 + sh_cs;                                  \
+    const float s0 = sh[o0], s1 = sh[o1], s2 = sh[o2];                                             \
+    const float sd = s0 * dc0 + s1 * dc1 + s2 * dc2;                                               \
+    ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                          \
+}
+            SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)
+            if (deg > 0) {
+                SH_TERM(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)
+                SH_TERM(2, SH_C1 * z, 0.f, 0.f, SH_C1)
+                SH_TERM(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)
+                if (deg > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    SH_TERM(4, bSH_C2[0] * xy, bSH_C2[0] * y, bSH_C2[0] * x, 0.f)
+                    SH_TERM(5, bSH_C2[1] * yz, 0.f, bSH_C2[1] * z, bSH_C2[1] * y)
+                    SH_TERM(6, bSH_C2[2] * (2.f * zz - xx - yy), bSH_C2[2] * -2.f * x, bSH_C2[2] * -2.f * y, bSH_C2[2] * 4.f * z)
+                    SH_TERM(7, bSH_C2[3] * xz, bSH_C2[3] * z, 0.f, bSH_C2[3] * x)
+                    SH_TERM(8, bSH_C2[4] * (xx - yy), bSH_C2[4] * 2.f * x, bSH_C2[4] * -2.f * y, 0.f)
+                    if (deg > 2) {
+                        SH_TERM(9, bSH_C3[0] * y * (3.f * xx - yy), bSH_C3[0] * 6.f * xy, bSH_C3[0] * 3.f * (xx - yy), 0.f)
+                        SH_TERM(10, bSH_C3[1] * xy * z, bSH_C3[1] * yz, bSH_C3[1] * xz, bSH_C3[1] * xy)
+                        SH_TERM(11, bSH_C3[2] * y * (4.f * zz - xx - yy), bSH_C3[2] * -2.f * xy,
+                                bSH_C3[2] * (-3.f * yy + 4.f * zz - xx), bSH_C3[2] * 8.f * yz)
+                        SH_TERM(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), bSH_C3[3] * -6.f * xz,
+                                bSH_C3[3] * -6.f * yz, bSH_C3[3] * 3.f * (2.f * zz - xx - yy))
+                        SH_TERM(13, bSH_C3[4] * x * (4.f * zz - xx - yy), bSH_C3[4] * (-3.f * xx + 4.f * zz - yy),
+                                bSH_C3[4] * -2.f * xy, bSH_C3[4] * 8.f * xz)
+                        SH_TERM(14, bSH_C3[5] * z * (xx - yy), bSH_C3[5] * 2.f * xz, bSH_C3[5] * -2.f * yz,
+                                bSH_C3[5] * (xx - yy))
+                        SH_TERM(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)
+                        if (deg > 3) {  // band 4 (oracle/ggr_oracle.c header): plain polynomial derivatives
+                            const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f, c21 = 21.f * zz - 3.f;
+                            const float xmy = xx - yy, x3y = xx - 3.f * yy, y3x = 3.f * xx - yy;
+                            SH_TERM(16, bSH_C4[0] * xy * xmy, bSH_C4[0] * y * y3x, bSH_C4[0] * x * x3y, 0.f)
+                            SH_TERM(17, bSH_C4[1] * yz * y3x, bSH_C4[1] * 6.f * xy * z, bSH_C4[1] * 3.f * z * xmy, bSH_C4[1] * y * y3x)
+                            SH_TERM(18, bSH_C4[2] * xy * a7, bSH_C4[2] * y * a7, bSH_C4[2] * x * a7, bSH_C4[2] * 14.f * xy * z)
+                            SH_TERM(19, bSH_C4[3] * yz * b7, 0.f, bSH_C4[3] * z * b7, bSH_C4[3] * y * c21)
+                            SH_TERM(20, bSH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f), 0.f, 0.f, bSH_C4[4] * z * (140.f * zz - 60.f))
+                            SH_TERM(21, bSH_C4[5] * xz * b7, bSH_C4[5] * z * b7, 0.f, bSH_C4[5] * x * c21)
+                            SH_TERM(22, bSH_C4[6] * xmy * a7, bSH_C4[6] * 2.f * x * a7, bSH_C4[6] * -2.f * y * a7, bSH_C4[6] * 14.f * z * xmy)
+                            SH_TERM(23, bSH_C4[7] * xz * x3y, bSH_C4[7] * 3.f * z * xmy, bSH_C4[7] * -6.f * xy * z, bSH_C4[7] * x * x3y)
+                            SH_TERM(24, bSH_C4[8] * (xx * x3y - yy * y3x), bSH_C4[8] * 4.f * x * x3y, bSH_C4[8] * -4.f * y * y3x, 0.f)
+                        }
+                    }
+                }
+            }
+#undef SH_TERM
+            const float sum2 = vx * vx + vy * vy + vz * vz;
+            const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            const float gx_ = ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
+            const float gy_ = (-vx * vy * ddx + (sum2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
+            const float gz_ = (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * inv32;
+            dmv[0] += gx_; dmv[1] += gy_; dmv[2] += gz_;
+            if (POSE) { dcam[0] -= gx_; dcam[1] -= gy_; dcam[2] -= gz_; }
+
+            }
+            dmean[0] += in_s * dmv[0]; dmean[1] += in_s * dmv[1]; dmean[2] += in_s * dmv[2];
+            }
+            if (POSE) {  // this view's dL/dcampos partial joins the row the main loop wrote (same threads: 32..34)
+                __shared__ float cred[4][4];
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float scm = wave_sum_lane63(dcam[k]);
+                    if (lane == 63) cred[wave][k] = scm;
+                }
+                __syncthreads();
+                if (threadIdx.x >= 32 && threadIdx.x < 35) {
+                    const int k = threadIdx.x - 32;
+                    pose_acc[((size_t)v * gridDim.x + blockIdx.x) * 64 + threadIdx.x] += cred[0][k] + cred[1][k] + cred[2][k] + cred[3][k];
+                }
+                __syncthreads();
+            }
+        }
         float* dsh = sh_lds + threadIdx.x * sh_stride;
         if (in_range && !sh_compact) {
             const int rowlen = sh_flat ? (int)sh_row : copy_row;
@@ -454,11 +498,18 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             float acc[GGR_SH_MAXK];
 #pragma unroll
             for (int k = 0; k < GGR_SH_MAXK; k++) acc[k] = 0.f;
+            float ndc = grad2d[GGR_G2D_STRIDE * il + GGR_G2D_RGB + c];
+            int prad = radii[il];
+            uint32_t pcl = clamped[il];
 #pragma clang loop unroll(disable)
             for (int v = 0; v < NV; v++) {
                 const size_t o = (size_t)v * P + il;
-                if (in_range && radii[o] > 0 && !((clamped[o] >> c) & 1u)) {
-                    const float dc = grad2d[GGR_G2D_STRIDE * o + GGR_G2D_RGB + c];
+                const float dc = ndc;
+                const bool use = in_range && prad > 0 && !((pcl >> c) & 1u);
+                if (MULTI && v + 1 < NV) {
+                    ndc = grad2d[GGR_G2D_STRIDE * (o + P) + GGR_G2D_RGB + c]; prad = radii[o + P]; pcl = clamped[o + P];
+                }
+                if (use) {
                     const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
                     const float vx = in_s * m0 - vs.campos[3 * v], vy = in_s * m1 - vs.campos[3 * v + 1],
                                 vz = in_s * m2 - vs.campos[3 * v + 2];
