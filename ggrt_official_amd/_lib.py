@@ -46,7 +46,7 @@ class GgrForwardOut(C.Structure):
     _fields_ = [
         ("out_color", C.c_void_p), ("radii", C.c_void_p), ("out_depth", C.c_void_p), ("geom_buffer", C.c_void_p),
         ("image_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("num_rendered", C.c_int64),
-        ("stage_ms", C.c_void_p), ("binning_capacity", C.c_int64),
+        ("stage_ms", C.c_void_p), ("binning_capacity", C.c_int64), ("no_backward", C.c_int32),
     ]
 
 
@@ -86,6 +86,7 @@ SYMBOLS = [
                               ALLOC_FN, C.c_void_p, C.c_void_p]),
     ("ggr_backward", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrBackwardIn), C.POINTER(GgrBackwardOut),
                                C.c_void_p]),
+    ("ggr_image_bytes_inference", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("ggr_geom_bytes_views", C.c_size_t, [C.c_int32, C.c_int32]),
     ("ggr_image_bytes_views", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("ggr_work_bytes_views", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -264,7 +264,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
 
     // 5. blend
     ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, vs.bg, out->out_color, im.final_T, im.n_contrib,
-                          out->out_depth, im.ckpt, im.ckpt_slots, im.tile_top, NV, s);
+                          out->out_depth, out->no_backward ? nullptr : im.ckpt, im.ckpt_slots, im.tile_top, NV, s);
     KCHECK(dbg, s, "blend_fwd");
     tm.mark();
     tm.finish();
@@ -367,6 +367,7 @@ int ggr_backward_views(const GgrSettings* st, const GgrViews* views, const GgrBa
     return backward_impl(st, vs, in, out, stream);
 }
 
+size_t ggr_image_bytes_inference(int32_t W, int32_t H, int32_t V) { return ggr_carve_image(nullptr, W, H, V > 0 ? V : 1).bytes_no_ckpt; }
 size_t ggr_geom_bytes_views(int32_t P, int32_t V) { return ggr_carve_geom(nullptr, (size_t)(P > 0 ? P : 0) * (size_t)(V > 0 ? V : 1)).bytes; }
 size_t ggr_image_bytes_views(int32_t W, int32_t H, int32_t V) { return ggr_carve_image(nullptr, W, H, V > 0 ? V : 1).bytes; }
 size_t ggr_work_bytes_views(int32_t P, int32_t W, int32_t H, int32_t V) {

@@ -134,7 +134,7 @@ struct ImageLayout {
     uint32_t* tile_top;  // [tiles]: max n_contrib of the tile = list entries the backward replays
     float* ckpt;         // [slots][5][H·W] or null
     int ckpt_slots, bwd_segments;
-    size_t bytes;
+    size_t bytes, bytes_no_ckpt;
 };
 
 // (V views of one launch set: V frames stacked — tiles and pixels of view v follow those of view v-1 in every array)
@@ -151,6 +151,7 @@ static inline ImageLayout ggr_carve_image(void* base, int W, int H, int V = 1) {
     L.tile_top = (uint32_t*)take(tiles * 4);
     L.ckpt_slots = ggr_ckpt_slots(tiles);
     L.bwd_segments = ggr_bwd_segments(tiles);
+    L.bytes_no_ckpt = o;  // (the checkpoint area comes last: an inference-only forward does without it)
     L.ckpt = L.ckpt_slots ? (float*)take((size_t)L.ckpt_slots * GGR_CKPT_FLOATS * pix * 4) : nullptr;
     L.bytes = o;
     return L;

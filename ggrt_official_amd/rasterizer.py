@@ -181,7 +181,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             depth = torch.empty((H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             geom = torch.empty((lib.ggr_geom_bytes(P),), dtype=torch.uint8, device=dev)
-            img = torch.empty((lib.ggr_image_bytes(W, H),), dtype=torch.uint8, device=dev)
+            # nothing requires grad (torch.no_grad() / inference): no backward will replay this forward, so the
+            # per-pixel checkpoints of the segmented backward are neither written nor allocated
+            infer = not any(ctx.needs_input_grad) if hasattr(ctx, "needs_input_grad") else not torch.is_grad_enabled()
+            img = torch.empty((lib.ggr_image_bytes_inference(W, H, 1) if infer else lib.ggr_image_bytes(W, H),),
+                              dtype=torch.uint8, device=dev)
             holder = {}
 
             def _alloc(_ctx, nbytes):
@@ -200,7 +204,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                     cov3D_precomp=_ptr(cov_c), aux_precomp=_ptr(aux_c), **form)
             fout = _lib.GgrForwardOut(out_color=color.data_ptr(), radii=_ptr(radii), out_depth=depth.data_ptr(),
                                       geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
-                                      binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0)
+                                      binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0,
+                                      no_backward=int(infer))
             capacity = int(getattr(rs, "list_capacity", 0) or 0)
             if capacity > 0:  # sync-free mode: bring the list buffer, no read-back inside ggr_forward
                 holder["bin"] = torch.empty((lib.ggr_binning_bytes(capacity, W, H),), dtype=torch.uint8, device=dev)
@@ -337,7 +342,9 @@ class _RasterizeViews(torch.autograd.Function):
             depth = torch.empty((V, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((V, P), dtype=torch.int32, device=dev)
             geom = torch.empty((lib.ggr_geom_bytes_views(P, V),), dtype=torch.uint8, device=dev)
-            img = torch.empty((lib.ggr_image_bytes_views(W, H, V),), dtype=torch.uint8, device=dev)
+            infer = not any(ctx.needs_input_grad)
+            img = torch.empty((lib.ggr_image_bytes_inference(W, H, V) if infer else lib.ggr_image_bytes_views(W, H, V),),
+                              dtype=torch.uint8, device=dev)
             holder = {}
 
             def _alloc(_ctx, nbytes):
@@ -357,7 +364,8 @@ class _RasterizeViews(torch.autograd.Function):
                                     cov3D_precomp=_ptr(cov_c), aux_precomp=_ptr(aux_c), **form)
             fout = _lib.GgrForwardOut(out_color=color.data_ptr(), radii=_ptr(radii), out_depth=depth.data_ptr(),
                                       geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
-                                      binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0)
+                                      binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0,
+                                      no_backward=int(infer))
             capacity = int(getattr(rs, "list_capacity", 0) or 0)
             if capacity > 0:  # sync-free mode: the capacity covers the lists of ALL views
                 holder["bin"] = torch.empty((lib.ggr_binning_bytes(capacity, W, H),), dtype=torch.uint8, device=dev)

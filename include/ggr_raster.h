@@ -119,6 +119,10 @@ typedef struct GgrForwardOut {
                               allocator call, so forward + backward can be captured in a hipGraph.  Lists that do
                               not fit are cut at the buffer's end and an overflow flag is raised on the device;
                               ggr_forward_status() reads count and flag whenever the caller chooses to sync. */
+    int32_t no_backward;   /* IN.  1: this forward will never be followed by ggr_backward (inference / torch.no_grad()):
+                              the per-pixel checkpoints of the segmented backward (images below 4096 tiles: 320 B per
+                              pixel) are neither written nor needed, and image_buffer may be the smaller
+                              ggr_image_bytes_inference() bytes.  0: as before. */
 } GgrForwardOut;
 
 /* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */
@@ -203,6 +207,9 @@ typedef struct GgrViews {
     const float* tanfov;         /* device [V,2] (tanfovx, tanfovy) or NULL: settings->tanfovx/y for every view */
     const float* input_scale;    /* device [V] or NULL (see GgrForwardIn.input_scale, which is ignored here) */
 } GgrViews;
+
+/* image_buffer size of a forward with GgrForwardOut.no_backward = 1 (no checkpoint area); num_views = 1 for ggr_forward */
+size_t ggr_image_bytes_inference(int32_t width, int32_t height, int32_t num_views);
 
 size_t ggr_geom_bytes_views(int32_t num_points, int32_t num_views);
 size_t ggr_image_bytes_views(int32_t width, int32_t height, int32_t num_views);

@@ -63,3 +63,21 @@ def test_long_lists_depth_gradient():
     assert np.abs(hd - depth.detach().numpy()).max() < 1e-3 * max(1.0, float(depth.detach().abs().max()))
     for k, v in ref.items():
         assert rel_l2(grads[k], v.numpy()) < 1e-3, (k, rel_l2(grads[k], v.numpy()))
+
+
+def test_inference_forward_skips_the_checkpoints():
+    """torch.no_grad() forward (GGRt's eval loop, eval/eval_ggrt.py:317): no checkpoint area is allocated or written
+    (GgrForwardOut.no_backward), the image is the same bit for bit."""
+    from ggrt_official_amd import GaussianRasterizer, _lib
+    sc = make_scene(30000, 160, 112, sh_degree=2, profile="B", seed=5).to("cuda:0")
+    lib = _lib.load()
+    assert lib.ggr_image_bytes_inference(160, 112, 1) < lib.ggr_image_bytes(160, 112) // 10
+    args = dict(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs,
+                cov3D_precomp=sc.cov3D)
+    with torch.no_grad():
+        a = GaussianRasterizer(sc.settings())(**args)
+    m = sc.means3D.clone().requires_grad_(True)
+    b = GaussianRasterizer(sc.settings())(**{**args, "means3D": m})
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    b[0].sum().backward()
+    assert torch.isfinite(m.grad).all()
