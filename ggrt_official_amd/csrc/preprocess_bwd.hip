@@ -410,13 +410,15 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             const float len = sqrtf(vx * vx + vy * vy + vz * vz);
             const float x = vx / len, y = vy / len, z = vz / len;
             const float* sh = sh_lds + threadIdx.x * sh_stride;
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-            // helper: coefficient k with basis gradient (bx,by,bz) — the direction term only; dL/dSH itself
-            // (Σ over views of basis × colour gradient) is formed after the view loop, channel by channel
+            float* dsh1 = sh_lds + threadIdx.x * sh_stride;  // one view: read the coefficient, then overwrite it with
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;           // its gradient (written out below)
+            // helper: coefficient k with basis value Bk and basis gradient (bx,by,bz).  Several views: the direction
+            // term only; dL/dSH (Σ over views of basis × colour gradient) is formed afterwards, channel by channel
 #define SH_TERM(k, Bk, bx, by, bz)                                                                     \
 {                                                                                                  \
     const int o0 = (k) * sh_ks, o1 = o0 + sh_cs, o2 = o1 + sh_cs;                                  \
     const float s0 = sh[o0], s1 = sh[o1], s2 = sh[o2];                                             \
+    if (!MULTI) { dsh1[o0] = (Bk) * dc0; dsh1[o1] = (Bk) * dc1; dsh1[o2] = (Bk) * dc2; }           \
     const float sd = s0 * dc0 + s1 * dc1 + s2 * dc2;                                               \
     ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                          \
 }
@@ -489,42 +491,57 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             }
         }
         float* dsh = sh_lds + threadIdx.x * sh_stride;
-        if (in_range && !sh_compact) {
-            const int rowlen = sh_flat ? (int)sh_row : copy_row;
-            for (int k = 0; k < rowlen; k++) dsh[k] = 0.f;  // unused coefficients of a staged row: zero gradient
-        }
-#pragma clang loop unroll(disable)
-        for (int c = 0; c < 3; c++) {
-            float acc[GGR_SH_MAXK];
-#pragma unroll
-            for (int k = 0; k < GGR_SH_MAXK; k++) acc[k] = 0.f;
-            float ndc = grad2d[GGR_G2D_STRIDE * il + GGR_G2D_RGB + c];
-            int prad = radii[il];
-            uint32_t pcl = clamped[il];
-#pragma clang loop unroll(disable)
-            for (int v = 0; v < NV; v++) {
-                const size_t o = (size_t)v * P + il;
-                const float dc = ndc;
-                const bool use = in_range && prad > 0 && !((pcl >> c) & 1u);
-                if (MULTI && v + 1 < NV) {
-                    ndc = grad2d[GGR_G2D_STRIDE * (o + P) + GGR_G2D_RGB + c]; prad = radii[o + P]; pcl = clamped[o + P];
-                }
-                if (use) {
-                    const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
-                    const float vx = in_s * m0 - vs.campos[3 * v], vy = in_s * m1 - vs.campos[3 * v + 1],
-                                vz = in_s * m2 - vs.campos[3 * v + 2];
-                    const float len = sqrtf(vx * vx + vy * vy + vz * vz);
-                    float B[GGR_SH_MAXK];
-                    sh_basis25(deg, vx / len, vy / len, vz / len, B);
-#pragma unroll
-                    for (int k = 0; k < GGR_SH_MAXK; k++)
-                        if (k < K) acc[k] += B[k] * dc;
+        if (!MULTI) {
+            // one view: the live rows already hold their gradient; culled Gaussians get zero rows, coefficients of
+            // bands that were not evaluated zero gradient
+            if (in_range && !(radii[il] > 0)) {
+                for (int k = 0; k < (sh_compact ? sh_rowf : sh_flat ? (int)sh_row : copy_row); k++) dsh[k] = 0.f;
+            } else if (in_range && !sh_compact) {
+                if (inf.sh_channel_major) {
+                    for (int c = 0; c < 3; c++)
+                        for (int k = K; k < M; k++) dsh[c * M + k] = 0.f;
+                } else if (sh_flat) {
+                    for (int k = sh_rowf; k < (int)sh_row; k++) dsh[k] = 0.f;
                 }
             }
-            if (in_range) {
+        } else {
+            if (in_range && !sh_compact) {
+                const int rowlen = sh_flat ? (int)sh_row : copy_row;
+                for (int k = 0; k < rowlen; k++) dsh[k] = 0.f;  // unused coefficients of a staged row: zero gradient
+            }
+#pragma clang loop unroll(disable)
+            for (int c = 0; c < 3; c++) {
+                float acc[GGR_SH_MAXK];
 #pragma unroll
-                for (int k = 0; k < GGR_SH_MAXK; k++)
-                    if (k < K) dsh[k * sh_ks + c * sh_cs] = acc[k];
+                for (int k = 0; k < GGR_SH_MAXK; k++) acc[k] = 0.f;
+                float ndc = grad2d[GGR_G2D_STRIDE * il + GGR_G2D_RGB + c];
+                int prad = radii[il];
+                uint32_t pcl = clamped[il];
+#pragma clang loop unroll(disable)
+                for (int v = 0; v < NV; v++) {
+                    const size_t o = (size_t)v * P + il;
+                    const float dc = ndc;
+                    const bool use = in_range && prad > 0 && !((pcl >> c) & 1u);
+                    if (MULTI && v + 1 < NV) {
+                        ndc = grad2d[GGR_G2D_STRIDE * (o + P) + GGR_G2D_RGB + c]; prad = radii[o + P]; pcl = clamped[o + P];
+                    }
+                    if (use) {
+                        const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
+                        const float vx = in_s * m0 - vs.campos[3 * v], vy = in_s * m1 - vs.campos[3 * v + 1],
+                                    vz = in_s * m2 - vs.campos[3 * v + 2];
+                        const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+                        float B[GGR_SH_MAXK];
+                        sh_basis25(deg, vx / len, vy / len, vz / len, B);
+#pragma unroll
+                        for (int k = 0; k < GGR_SH_MAXK; k++)
+                            if (k < K) acc[k] += B[k] * dc;
+                    }
+                }
+                if (in_range) {
+#pragma unroll
+                    for (int k = 0; k < GGR_SH_MAXK; k++)
+                        if (k < K) dsh[k * sh_ks + c * sh_cs] = acc[k];
+                }
             }
         }
         __syncthreads();
