@@ -173,7 +173,8 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     const size_t tiles = tiles_of(W, H) * (size_t)NV;
     const bool dbg = st->debug != 0;
 
-    GeomLayout g = ggr_carve_geom(out->geom_buffer, (size_t)P);
+    const size_t segs = ggr_sort_segments((size_t)NV);  // the depth sort runs one segment per view
+    GeomLayout g = ggr_carve_geom(out->geom_buffer, (size_t)P, segs);
     ImageLayout im = ggr_carve_image(out->image_buffer, W, H, NV);
     StageTimer tm(s, out->stage_ms, GGR_FWD_STAGES);
 
@@ -195,7 +196,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         uint32_t *zero_area = nullptr, zero_words = 0;
         ggr::tile_list_gather_targets(plan, work, tiles, &rect_sorted, &zero_area, &zero_words);
         // (preprocess already wrote the keys into g.keys_a and the identity permutation into g.vals_a)
-        ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, &dk, &order, s,
+        ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, (uint32_t)segs, &dk, &order, s,
                               /*hist_zeroed=*/true /*by preprocess_fwd*/,
                               /*block_max_ready=*/(uint32_t)((P1 + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS) /*likewise*/,
                               g.rect, rect_sorted, zero_area, zero_words);
@@ -297,7 +298,7 @@ int backward_impl(const GgrSettings* st, const ViewSet& vs, const GgrBackwardIn*
     const bool dbg = st->debug != 0;
     if (in->num_rendered != 0 && !in->binning_buffer) return fail(GGR_E_INVALID, "null binning buffer");
 
-    GeomLayout g = ggr_carve_geom((void*)in->geom_buffer, (size_t)P * NV);
+    GeomLayout g = ggr_carve_geom((void*)in->geom_buffer, (size_t)P * NV, ggr_sort_segments((size_t)NV));
     ImageLayout im = ggr_carve_image((void*)in->image_buffer, W, H, NV);
     const uint32_t* point_list = (const uint32_t*)in->binning_buffer;
     BwdScratch sc = ggr_carve_bwd(in->scratch, (size_t)P, (size_t)NV);
@@ -368,7 +369,10 @@ int ggr_backward_views(const GgrSettings* st, const GgrViews* views, const GgrBa
 }
 
 size_t ggr_image_bytes_inference(int32_t W, int32_t H, int32_t V) { return ggr_carve_image(nullptr, W, H, V > 0 ? V : 1).bytes_no_ckpt; }
-size_t ggr_geom_bytes_views(int32_t P, int32_t V) { return ggr_carve_geom(nullptr, (size_t)(P > 0 ? P : 0) * (size_t)(V > 0 ? V : 1)).bytes; }
+size_t ggr_geom_bytes_views(int32_t P, int32_t V) {
+    const size_t v = (size_t)(V > 0 ? V : 1);
+    return ggr_carve_geom(nullptr, (size_t)(P > 0 ? P : 0) * v, ggr_sort_segments(v)).bytes;
+}
 size_t ggr_image_bytes_views(int32_t W, int32_t H, int32_t V) { return ggr_carve_image(nullptr, W, H, V > 0 ? V : 1).bytes; }
 size_t ggr_work_bytes_views(int32_t P, int32_t W, int32_t H, int32_t V) {
     const size_t v = (size_t)(V > 0 ? V : 1);

@@ -74,14 +74,16 @@ radix_block_max_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __
 #define GGR_HIST_THREADS 1024
 #define GGR_HIST_ITEMS 8
 __global__ void __launch_bounds__(GGR_HIST_THREADS)
-radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __restrict__ hist,
-                         const uint32_t* __restrict__ block_max, uint32_t nmax) {
+radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per segment*/, uint32_t blocks_per_seg,
+                         uint32_t* __restrict__ hist, const uint32_t* __restrict__ block_max, uint32_t nmax) {
     __shared__ uint32_t h[GGR_SORT_PASSES][GGR_SORT_MAX_BINS];
     __shared__ uint32_t wm[GGR_HIST_THREADS / 64];
     const int tid = threadIdx.x;
     // this block's keys: all loads issued before anything waits (the kernel is latency-bound)
     uint32_t ks[GGR_HIST_ITEMS];
-    const size_t base = (size_t)blockIdx.x * (GGR_HIST_THREADS * GGR_HIST_ITEMS);
+    const uint32_t seg = blockIdx.x / blocks_per_seg, bseg = blockIdx.x - seg * blocks_per_seg;
+    keys += (size_t)seg * n;
+    const size_t base = (size_t)bseg * (GGR_HIST_THREADS * GGR_HIST_ITEMS);
 #pragma unroll
     for (int u = 0; u < GGR_HIST_ITEMS; u++) {
         const size_t idx = base + (size_t)u * GGR_HIST_THREADS + tid;
@@ -120,7 +122,7 @@ radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* 
     for (uint32_t x = tid; x < GGR_SORT_PASSES * bins; x += GGR_HIST_THREADS) {
         const uint32_t p = x >> w, d = x & mask;
         const uint32_t c = h[p][d];
-        if (c) atomicAdd(&hist[GGR_HIST_TOTALS + p * GGR_SORT_MAX_BINS + d], c);
+        if (c) atomicAdd(&hist[GGR_HIST_TOTALS + (seg * GGR_SORT_PASSES + p) * GGR_SORT_MAX_BINS + d], c);
     }
 }
 
@@ -130,8 +132,9 @@ radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* 
 template <bool GATHER>
 __global__ void __launch_bounds__(GGR_SORT_THREADS)
 radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int pass,
-                      uint32_t ntiles, uint32_t* __restrict__ hist, const uint2* __restrict__ gather_src,
+                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n /*keys per segment*/,
+                      int pass, uint32_t ntiles /*per segment*/, uint32_t nseg, uint32_t* __restrict__ hist,
+                      const uint2* __restrict__ gather_src,
                       uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
     constexpr int NW = GGR_SORT_THREADS / 64;
     constexpr int DPT = GGR_SORT_MAX_BINS / GGR_SORT_THREADS;  // digits per thread at the widest digit
@@ -143,7 +146,14 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     __shared__ uint32_t tile_sh;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) tile_sh = atomicAdd(&hist[GGR_HIST_TICKETS + pass], 1u);
+    // segments are dealt round robin to the workgroups, so that all of them progress together
+    const uint32_t seg = blockIdx.x % nseg;
+    if (tid == 0) tile_sh = atomicAdd(&hist[GGR_HIST_TICKETS + pass * GGR_SORT_MAX_SEGMENTS + seg], 1u);
+    {
+        const size_t so = (size_t)seg * n;
+        keys_in += so; vals_in += so; keys_out += so; vals_out += so;
+        if (GATHER) gather_dst += so;
+    }
     const uint32_t w = hist[GGR_HIST_PARAMS];            // bits per digit (block-uniform)
     const uint32_t bins = 1u << w, mask = bins - 1u;
     const uint32_t shift = (uint32_t)pass * w;
@@ -152,14 +162,14 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
 #pragma unroll
     for (int q = 0; q < DPT; q++) {
         const uint32_t d = tid + q * GGR_SORT_THREADS;
-        tot[q] = d < bins ? hist[GGR_HIST_TOTALS + pass * GGR_SORT_MAX_BINS + d] : 0u;
+        tot[q] = d < bins ? hist[GGR_HIST_TOTALS + (seg * GGR_SORT_PASSES + pass) * GGR_SORT_MAX_BINS + d] : 0u;
     }
     for (uint32_t x = tid; x < NW * GGR_SORT_MAX_BINS / 2; x += GGR_SORT_THREADS)
         reinterpret_cast<uint32_t*>(&wcount[0][0])[x] = 0u;
     __syncthreads();
     const uint32_t tile = tile_sh;
     PROBE(0);
-    uint32_t* status = hist + GGR_HIST_STATUS + ((size_t)pass * ntiles << GGR_SORT_MAX_BITS);
+    uint32_t* status = hist + ggr_sort_status_base(nseg) + (((size_t)pass * nseg + seg) * ntiles << GGR_SORT_MAX_BITS);
 
     const size_t base = (size_t)tile * GGR_SORT_TILE + (size_t)wave * (64 * GGR_SORT_ITEMS);
     uint32_t key[GGR_SORT_ITEMS], val[GGR_SORT_ITEMS], rank[GGR_SORT_ITEMS];
@@ -383,29 +393,31 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
 const uint32_t* radix_sort_fault_word(const uint32_t* hist) { return hist + GGR_HIST_FAULT; }
 
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                      uint32_t* hist, size_t n, uint32_t** keys_out, uint32_t** vals_out,
+                      uint32_t* hist, size_t n, uint32_t segments, uint32_t** keys_out, uint32_t** vals_out,
                       hipStream_t s, bool hist_zeroed, uint32_t block_max_ready, const uint2* gather_src, uint2* gather_dst,
                       uint32_t* zero_area, uint32_t zero_words) {
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     if (n > 0) {
-        const uint32_t ntiles = (uint32_t)ggr_sort_blocks(n);
+        const uint32_t S = segments ? segments : 1;
+        const size_t nseg = n / S;  // (n is a multiple of S)
+        const uint32_t ntiles = (uint32_t)ggr_sort_blocks(nseg);
         const uint32_t nmax = block_max_ready ? block_max_ready : (uint32_t)((n + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS);
-        uint32_t* block_max = hist + ggr_sort_zero_words(n);
+        uint32_t* block_max = hist + ggr_sort_zero_words(n, S);
         if (!hist_zeroed)  // (ggr_forward: preprocess_fwd clears the area — one launch less)
-            (void)hipMemsetAsync(hist, 0, ggr_sort_zero_words(n) * sizeof(uint32_t), s);
+            (void)hipMemsetAsync(hist, 0, ggr_sort_zero_words(n, S) * sizeof(uint32_t), s);
         if (!block_max_ready)  // (ggr_forward: preprocess_fwd leaves them)
             hipLaunchKernelGGL(radix_block_max_kernel, dim3(nmax), dim3(GGR_PRE_THREADS), 0, s, kin, n, block_max);
-        const unsigned hist_blocks =
-            (unsigned)((n + GGR_HIST_THREADS * GGR_HIST_ITEMS - 1) / (GGR_HIST_THREADS * GGR_HIST_ITEMS));
-        hipLaunchKernelGGL(radix_global_hist_kernel, dim3(hist_blocks), dim3(GGR_HIST_THREADS), 0, s, kin, n, hist,
+        const unsigned bps =
+            (unsigned)((nseg + GGR_HIST_THREADS * GGR_HIST_ITEMS - 1) / (GGR_HIST_THREADS * GGR_HIST_ITEMS));
+        hipLaunchKernelGGL(radix_global_hist_kernel, dim3(bps * S), dim3(GGR_HIST_THREADS), 0, s, kin, nseg, bps, hist,
                            block_max, nmax);
         for (int p = 0; p < GGR_SORT_PASSES; p++) {
             if (p == GGR_SORT_PASSES - 1 && gather_src)
-                hipLaunchKernelGGL(radix_onesweep_kernel<true>, dim3(ntiles), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
-                                   kout, vout, n, p, ntiles, hist, gather_src, gather_dst, zero_area, zero_words);
+                hipLaunchKernelGGL(radix_onesweep_kernel<true>, dim3(ntiles * S), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
+                                   kout, vout, nseg, p, ntiles, S, hist, gather_src, gather_dst, zero_area, zero_words);
             else
-                hipLaunchKernelGGL(radix_onesweep_kernel<false>, dim3(ntiles), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
-                                   kout, vout, n, p, ntiles, hist, nullptr, nullptr, nullptr, 0u);
+                hipLaunchKernelGGL(radix_onesweep_kernel<false>, dim3(ntiles * S), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
+                                   kout, vout, nseg, p, ntiles, S, hist, nullptr, nullptr, nullptr, 0u);
             uint32_t* t = kin; kin = kout; kout = t;
             t = vin; vin = vout; vout = t;
         }

@@ -57,19 +57,27 @@
 static inline size_t ggr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) / GGR_SORT_TILE; }
-// Sort work area (u32 words): digit totals of the 3 passes [0, 3072) | tickets, fault word, digit parameters
-// [3072, 3136) | look-back status words, 3 passes × tiles × 1024 | one key maximum per preprocess block.
-// Everything before the block maxima is zeroed by preprocess_fwd (ggr_sort_zero_words); the maxima are plain stores.
-#define GGR_HIST_TOTALS 0
-#define GGR_HIST_TICKETS (GGR_SORT_PASSES * GGR_SORT_MAX_BINS)
-#define GGR_HIST_FAULT (GGR_HIST_TICKETS + 8)
-#define GGR_HIST_PARAMS (GGR_HIST_TICKETS + 16)   // [0] = bits per digit
-#define GGR_HIST_STATUS (GGR_HIST_TICKETS + 64)
-static inline size_t ggr_sort_zero_words(size_t n) {
-    return GGR_HIST_STATUS + (size_t)GGR_SORT_PASSES * ggr_sort_blocks(n ? n : 1) * GGR_SORT_MAX_BINS;
+// The sort is SEGMENTED: the n keys are S segments of n/S keys, each sorted on its own into its own range (S = 1: a
+// plain sort).  A launch set of V views sorts V segments — the per-view orders are all the tile lists need — with V
+// independent ticket sequences and look-back chains in the same three launches: a chain over the V·P/4096 tiles of all
+// views is what made one 4 M-key sort cost as much as four 1 M-key sorts one after the other.
+// Sort work area (u32 words): header [0, 256): tickets [pass·64 + segment], fault word, digit parameters | digit totals,
+// (segment·3 + pass)·1024 + digit | look-back status words, ((pass·S + segment)·tiles_per_segment + tile)·bins + digit |
+// one key maximum per preprocess block.  Everything before the block maxima is zeroed by preprocess_fwd
+// (ggr_sort_zero_words); the maxima are plain stores.
+#define GGR_SORT_MAX_SEGMENTS 64
+#define GGR_HIST_TICKETS 0
+#define GGR_HIST_FAULT 192
+#define GGR_HIST_PARAMS 200   // [0] = bits per digit
+#define GGR_HIST_TOTALS 256
+static inline size_t ggr_sort_segments(size_t views) { return views >= 1 && views <= GGR_SORT_MAX_SEGMENTS ? views : 1; }
+__host__ __device__ static inline size_t ggr_sort_status_base(size_t S) { return GGR_HIST_TOTALS + S * GGR_SORT_PASSES * GGR_SORT_MAX_BINS; }
+static inline size_t ggr_sort_zero_words(size_t n, size_t S = 1) {
+    const size_t tps = ggr_sort_blocks((n ? n : 1) / S ? (n ? n : 1) / S : 1);
+    return ggr_sort_status_base(S) + (size_t)GGR_SORT_PASSES * S * tps * GGR_SORT_MAX_BINS;
 }
-static inline size_t ggr_sort_hist_words(size_t n) {
-    return ggr_sort_zero_words(n) + ((n ? n : 1) + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS;
+static inline size_t ggr_sort_hist_words(size_t n, size_t S = 1) {
+    return ggr_sort_zero_words(n, S) + ((n ? n : 1) + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS;
 }
 
 struct GeomLayout {
@@ -88,7 +96,8 @@ struct GeomLayout {
     size_t bytes;
 };
 
-static inline GeomLayout ggr_carve_geom(void* base, size_t P) {
+// P = (view, Gaussian) pairs of the launch set; `segments` = ggr_sort_segments(views)
+static inline GeomLayout ggr_carve_geom(void* base, size_t P, size_t segments = 1) {
     GeomLayout L;
     char* p = (char*)base;
     size_t o = 0;
@@ -104,8 +113,8 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P) {
     L.keys_b = (uint32_t*)take(Pp * 4);
     L.vals_a = (uint32_t*)take(Pp * 4);
     L.vals_b = (uint32_t*)take(Pp * 4);
-    L.hist = (uint32_t*)take(ggr_sort_hist_words(Pp) * 4);
-    L.counters = (uint32_t*)take(64 * 4);
+    L.counters = (uint32_t*)take(64 * 4);  // (before the sort area: its offset must not depend on `segments`)
+    L.hist = (uint32_t*)take(ggr_sort_hist_words(Pp, segments) * 4);
     L.bytes = o;
     return L;
 }
@@ -121,8 +130,11 @@ static inline size_t ggr_point_list_bytes(size_t N) { return ggr_align((N ? N : 
 // fills the chip as it is (measured: 16 slots at 8160 tiles, 0.44 → 0.48 ms).
 // Blend backward, no checkpoints → 16 slots:  480×352, 1.01 M pixel-aligned Gaussians 0.434 → 0.271 ms;
 // 960×640, 4.9 M: 1.03 → 0.86 ms; 256×256, 10 k: 0.050 → 0.038 ms.  Forward cost of writing them: < 1 %.
+#ifndef GGR_CKPT_MID
+#define GGR_CKPT_MID 16
+#endif
 static inline int ggr_ckpt_slots(size_t tiles) {  // slot 0 holds the final sums; 0 = no checkpoints
-    return (tiles == 0 || tiles >= 4096) ? 0 : 16;
+    return (tiles == 0 || tiles >= 4096) ? 0 : tiles >= 2048 ? GGR_CKPT_MID : 16;
 }
 static inline int ggr_bwd_segments(size_t tiles) { const int k = ggr_ckpt_slots(tiles); return k ? k : 1; }
 #define GGR_CKPT_FLOATS 5  // T, Σw·r, Σw·g, Σw·b, Σw·z — each a [H·W] plane: ckpt[(slot·5 + v)·H·W + pixel]
@@ -236,8 +248,9 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
 // n/256 producer blocks must be in the work area (preprocess_fwd; `block_max_ready` = false makes the sort compute
 // them itself: tools/sort_bench.hip)
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                      uint32_t* hist, size_t n, uint32_t** keys_out, uint32_t** vals_out,
-                      hipStream_t s, bool hist_zeroed = false /*the caller already cleared ggr_sort_zero_words(n)*/,
+                      uint32_t* hist, size_t n, uint32_t segments /*n must be a multiple*/, uint32_t** keys_out,
+                      uint32_t** vals_out, hipStream_t s,
+                      bool hist_zeroed = false /*the caller already cleared ggr_sort_zero_words(n, segments)*/,
                       uint32_t block_max_ready = 0 /*> 0: that many key maxima are already in the work area*/,
                       const uint2* gather_src = nullptr /*last pass also writes gather_dst[pos] = gather_src[val]*/,
                       uint2* gather_dst = nullptr, uint32_t* zero_area = nullptr /*and clears these words*/,

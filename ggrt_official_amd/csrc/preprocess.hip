@@ -306,7 +306,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            GeomLayout g, InputForm inf, hipStream_t s) {
     if (P <= 0) return;
     // the depth sort's work area (binning.hip), sized for the V·P keys of all views
-    const uint32_t zero_words = (uint32_t)ggr_sort_zero_words((size_t)P * vs.V);
+    const uint32_t zero_words = (uint32_t)ggr_sort_zero_words((size_t)P * vs.V, ggr_sort_segments((size_t)vs.V));
     const int threads = GGR_PRE_THREADS;
     const int blocks = (P + threads - 1) / threads;
     const int deg = ggr_sh_degree(D, shs ? M : 25, inf.sh_cap);

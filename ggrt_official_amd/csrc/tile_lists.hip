@@ -257,9 +257,12 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
     unsigned long long* same = (unsigned long long*)lds;  // [band_tiles] lane masks: who holds tile t in this step
     uint32_t* cursor = lds + 2 * band_tiles;
     uint32_t* l_id = cursor + band_tiles;
-    constexpr uint32_t HALF = GGR_BIN_CHUNK / 2;  // the chunk is walked in two halves: 8 KB of list instead of 16,
-    uint32_t* l_xy = l_id + HALF;                 // i.e. 13 instead of 7 resident waves per CU for a walk whose
-    uint32_t* l_wh = l_xy + HALF;                 // steps are chains of LDS round trips
+#ifndef GGR_SCATTER_PARTS
+#define GGR_SCATTER_PARTS 4
+#endif
+    constexpr uint32_t HALF = GGR_BIN_CHUNK / GGR_SCATTER_PARTS;  // the chunk is walked in parts (4: 4 KB of list instead of 16):
+    uint32_t* l_xy = l_id + HALF;                 // more resident waves per CU for a walk whose steps are chains
+    uint32_t* l_wh = l_xy + HALF;                 // of LDS round trips (1 / 2 / 4 parts at C3: 0.092 / 0.075 / 0.072 ms)
     uint32_t* l_pre = l_wh + HALF;
     uint32_t* mark = l_pre + HALF;
     // XCD-affine work order.  Workgroup b runs on XCD b mod 8, and every XCD has its own L2: when the waves that
@@ -301,11 +304,11 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
     const uint32_t band_n = hi - lo;
     const uint32_t row_lo = lo / grid_x, row_hi = (hi - 1) / grid_x + 1;
 #pragma unroll
-  for (int half = 0; half < 2; half++) {
+  for (int half = 0; half < GGR_SCATTER_PARTS; half++) {
     uint32_t nh = 0, S = 0;
 #pragma unroll
-    for (int qq = 0; qq < NB / 2; qq++) {
-        const int q = half * (NB / 2) + qq;
+    for (int qq = 0; qq < NB / GGR_SCATTER_PARTS; qq++) {
+        const int q = half * (NB / GGR_SCATTER_PARTS) + qq;
         const uint32_t g = gq[q];
         uint32_t x0, y0, x1, y1;
         unpack_rect(rq[q], x0, y0, x1, y1);
@@ -494,7 +497,7 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
     (void)rect;
     if (T == 0 || P == 0) return;
     const WorkArea w = carve_work(pl, (void*)work, T);
-    const size_t lds = (3 * (size_t)pl.sband_tiles + 4 * (GGR_BIN_CHUNK / 2) + 64) * 4;
+    const size_t lds = (3 * (size_t)pl.sband_tiles + 4 * (GGR_BIN_CHUNK / GGR_SCATTER_PARTS) + 64) * 4;
     const uint32_t bands8 = (pl.nsbands + 7u) / 8u;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks * bands8 * 8u), dim3(64), lds, s, (uint32_t)P, order,
                        w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, point_list, capacity,

@@ -17,7 +17,9 @@ namespace ggr { extern __device__ unsigned long long ggr_probe[3][8][2048]; }
 int main(int argc, char** argv) {
     size_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 1000000;
     int nbits = argc > 2 ? atoi(argv[2]) : 27;   // mode 1: significant bits of the random keys (≤ 30)
-    int mode = argc > 3 ? atoi(argv[3]) : 2;  // 1: random, 2: depth keys (float bits of z in [1.5, 50) − bits of 0.2f), 3: with ties + culled
+    int mode = argc > 3 ? atoi(argv[3]) : 2;
+    uint32_t segs = argc > 4 ? (uint32_t)atoi(argv[4]) : 1;  // sort `segs` equal segments independently (n is rounded down)
+    n -= n % segs;  // 1: random, 2: depth keys (float bits of z in [1.5, 50) − bits of 0.2f), 3: with ties + culled
     std::vector<uint32_t> hk(n), hv(n);
     uint32_t seed = 12345;
     auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
@@ -36,7 +38,7 @@ int main(int argc, char** argv) {
     }
     uint32_t *ka, *kb, *va, *vb, *hist;
     CK(hipMalloc(&ka, n * 4)); CK(hipMalloc(&kb, n * 4)); CK(hipMalloc(&va, n * 4)); CK(hipMalloc(&vb, n * 4));
-    CK(hipMalloc(&hist, ggr_sort_hist_words(n) * 4));
+    CK(hipMalloc(&hist, ggr_sort_hist_words(n, segs) * 4));
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     uint32_t *ko, *vo;
@@ -44,20 +46,22 @@ int main(int argc, char** argv) {
     for (int it = 0; it < 8; it++) {
         CK(hipMemcpy(ka, hk.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(va, hv.data(), n * 4, hipMemcpyHostToDevice));
         CK(hipEventRecord(e0, s));
-        ggr::radix_sort_pairs(ka, kb, va, vb, hist, n, &ko, &vo, s);
+        ggr::radix_sort_pairs(ka, kb, va, vb, hist, n, segs, &ko, &vo, s);
         CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
     }
     std::vector<uint32_t> rk(n), rv(n);
     CK(hipMemcpy(rk.data(), ko, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(rv.data(), vo, n * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> idx(n); std::iota(idx.begin(), idx.end(), 0u);
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return hk[a] < hk[b]; });
+    for (uint32_t sg = 0; sg < segs; sg++)
+        std::stable_sort(idx.begin() + (n / segs) * sg, idx.begin() + (n / segs) * (sg + 1),
+                         [&](uint32_t a, uint32_t b) { return hk[a] < hk[b]; });
     size_t bad = 0;
     for (size_t j = 0; j < n; j++) if (rk[j] != hk[idx[j]] || rv[j] != hv[idx[j]]) bad++;
     uint32_t hw[80];
-    CK(hipMemcpy(hw, hist + GGR_HIST_TICKETS, sizeof hw, hipMemcpyDeviceToHost));
-    printf("n=%zu mode=%d  best %.3f ms (incl. the memset + block-max launches the product does not need)  digit bits %u  fault %u  mismatches=%zu\n",
-           n, mode, best, hw[16], hw[8], bad);
+    CK(hipMemcpy(hw, hist + GGR_HIST_FAULT, sizeof(uint32_t) * 16, hipMemcpyDeviceToHost));
+    printf("n=%zu mode=%d segments=%u  best %.3f ms (incl. the memset + block-max launches the product does not need)  digit bits %u  fault %u  mismatches=%zu\n",
+           n, mode, segs, best, hw[8], hw[0], bad);
 #ifdef GGR_SORT_PROBE
     {   // phase durations of the LAST run, per pass: mean over tiles (µs) of [ticket→loads issued+scan, rank, barrier wait,
         // look-back, barrier wait, scatter issue] and the span first-start → last-end
