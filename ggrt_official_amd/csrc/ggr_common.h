@@ -130,11 +130,9 @@ static inline size_t ggr_point_list_bytes(size_t N) { return ggr_align((N ? N : 
 // fills the chip as it is (measured: 16 slots at 8160 tiles, 0.44 → 0.48 ms).
 // Blend backward, no checkpoints → 16 slots:  480×352, 1.01 M pixel-aligned Gaussians 0.434 → 0.271 ms;
 // 960×640, 4.9 M: 1.03 → 0.86 ms; 256×256, 10 k: 0.050 → 0.038 ms.  Forward cost of writing them: < 1 %.
-#ifndef GGR_CKPT_MID
-#define GGR_CKPT_MID 16
-#endif
+// (4 views of 660 tiles = 2640 tiles in one launch set: 16 / 8 / 4 slots measured the same within noise)
 static inline int ggr_ckpt_slots(size_t tiles) {  // slot 0 holds the final sums; 0 = no checkpoints
-    return (tiles == 0 || tiles >= 4096) ? 0 : tiles >= 2048 ? GGR_CKPT_MID : 16;
+    return (tiles == 0 || tiles >= 4096) ? 0 : 16;
 }
 static inline int ggr_bwd_segments(size_t tiles) { const int k = ggr_ckpt_slots(tiles); return k ? k : 1; }
 #define GGR_CKPT_FLOATS 5  // T, Σw·r, Σw·g, Σw·b, Σw·z — each a [H·W] plane: ckpt[(slot·5 + v)·H·W + pixel]

@@ -58,7 +58,7 @@ class GaussianRasterizationSettings(NamedTuple):
     aux_affine: Optional[tuple] = None          # (a, b): depth output = Σ max(a + b·z/s, 0)·α·T (GGRt's depth pass)
     tanfov: Optional[torch.Tensor] = None       # device [2]: overrides tanfovx / tanfovy without a read-back (camera_setup)
     sh_max_degree: int = 4  # highest SH band evaluated.  4: GGRt's rasterizer fork as recollected (sh_degree = 4 with 25
-    #                         coefficients evaluates the nine degree-4 terms; unverifiable here, INTEGRATION.md §5);
+    #                         coefficients evaluates the nine degree-4 terms; unverifiable here, INTEGRATION.md §7);
     #                         3: graphdeco upstream (coefficients 16.. ignored, zero gradient)
 
 

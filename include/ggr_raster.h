@@ -67,7 +67,7 @@ typedef struct GgrSettings {
     int32_t sh_max_degree;   /* 0 = default (4).  4: the nine degree-4 terms are evaluated and differentiated when
                                 D >= 4 and M >= 25 — what GGRt's rasterizer fork (dcharatan/diff-gaussian-
                                 rasterization-modified, reference README.md:17-18) does to the builder's recollection;
-                                NOT verifiable in this build (INTEGRATION.md §5).  3: graphdeco upstream — coefficients
+                                NOT verifiable in this build (INTEGRATION.md §7).  3: graphdeco upstream — coefficients
                                 16.. are ignored and get zero gradient. */
 } GgrSettings;
 
