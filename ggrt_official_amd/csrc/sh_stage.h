@@ -23,12 +23,15 @@ __device__ __forceinline__ void stage_sh_rows(float* __restrict__ sh_lds, const 
         const size_t total = (size_t)nG * row;
         const float* src = shs + g0 * row;
         const int n4 = (int)(total >> 2);
-        for (int j0 = 0; j0 < n4; j0 += 10 * 256) {
-            float4 v[10];
+        // (GGRt's rows: 256 × 75 floats = 4800 float4 = 18.75 per thread: ONE trip with 19 loads in flight; with 10 per
+        // trip the second trip waited for the first)
+        constexpr int U = 19;
+        for (int j0 = 0; j0 < n4; j0 += U * 256) {
+            float4 v[U];
 #pragma unroll
-            for (int it = 0; it < 10; it++) v[it] = reinterpret_cast<const float4*>(src)[min(j0 + it * 256 + tid, n4 - 1)];
+            for (int it = 0; it < U; it++) v[it] = reinterpret_cast<const float4*>(src)[min(j0 + it * 256 + tid, n4 - 1)];
 #pragma unroll
-            for (int it = 0; it < 10; it++) {
+            for (int it = 0; it < U; it++) {
                 const int j = j0 + it * 256 + tid;
                 if (j < n4) reinterpret_cast<float4*>(sh_lds)[j] = v[it];
             }

@@ -166,3 +166,26 @@ def test_decoder_batched_equals_per_view_loop():
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     for a, bb in zip(outs[0][2], outs[1][2]):
         assert rel_l2(bb, a) < 2e-5
+
+
+def test_views_sync_free_matches_exact_mode():
+    """`list_capacity` (no read-back, graph-capturable) covers the lists of ALL views of the launch set."""
+    from ggrt_official_amd import last_forward_status
+    P, W, H, V = 7000, 112, 80, 3
+    sc = make_scene(P, W, H, sh_degree=2, seed=8).to(dev)
+    view, full, campos, tanfov = [t.to(dev) for t in _cameras(W, H, V)]
+    bgs = torch.zeros(V, 3, device=dev)
+    outs = []
+    for cap in (0, 400_000, 2_000):   # exact, roomy, overflowing
+        rs = sc.settings()._replace(list_capacity=cap)
+        m = sc.means3D.clone().requires_grad_(True)
+        color, radii, depth = rasterize_views(m, sc.opacities, view, full, campos, bgs, tanfov, rs, shs=sc.shs,
+                                              cov3D_precomp=sc.cov3D)
+        color.sum().backward()
+        n, overflow = last_forward_status()
+        outs.append((color.detach().clone(), m.grad.clone(), n, overflow))
+    assert outs[0][2] == outs[1][2] > 0 and not outs[1][3]
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert rel_l2(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy()) < 1e-5
+    assert outs[2][3] and outs[2][2] == outs[0][2]          # overflow raised, true count still reported
+    assert torch.isfinite(outs[2][0]).all()
