@@ -8,12 +8,11 @@
 //                      fetch is ONE 48-B gather instead of three gathers from three SoA arrays
 //                      (f = view-space z or the caller's aux feature; qmax = 2·ln(255·opacity): the largest
 //                      dᵀ·conic·d at which α still reaches 1/255)
-//     depth_key[P]     u32   float bits of view z (0xFFFFFFFF if culled)
 //     tiles_touched[P] u32
 //     rect[P]          u32×2 packed tile rect (minx | miny<<16, maxx | maxy<<16)
 //     clamped[P]       u32   bit c set ⇔ SH colour channel c was clamped at 0
 //     cov3D[P]         6 × f32 (scale/rot path only; otherwise the caller's cov3D_precomp is used)
-//     depth-sort double buffers (keys/vals) + radix work area, counters
+//     depth-sort double buffers (keys = depth bits − bits of 0.2f, 0 if culled; vals = ids), counters, radix work area
 //   work buffer   (forward only, obtained from the allocator, may be released after ggr_forward)
 //     table[chunks][tiles] u32, gsum[groups][tiles] u32, tile_start[tiles] u32   (tile_lists.hip)
 //   binning buffer (kept for backward)
@@ -82,7 +81,6 @@ static inline size_t ggr_sort_hist_words(size_t n, size_t S = 1) {
 
 struct GeomLayout {
     float4* splat;
-    uint32_t* depth_key;
     uint32_t* tiles_touched;
     uint2* rect;
     uint32_t* clamped;
@@ -104,7 +102,6 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P, size_t segments = 
     size_t Pp = P ? P : 1;
     auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes); return r; };
     L.splat = (float4*)take(Pp * 48);
-    L.depth_key = (uint32_t*)take(Pp * 4);
     L.tiles_touched = (uint32_t*)take(Pp * 4);
     L.rect = (uint2*)take(Pp * 8);
     L.clamped = (uint32_t*)take(Pp * 4);

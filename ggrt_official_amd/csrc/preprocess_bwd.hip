@@ -133,7 +133,6 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dop = 0.f, dcp[3] = {0.f, 0.f, 0.f};
     const int K = (deg + 1) * (deg + 1);
-    bool any_live = false;
 
     // the per-view loads (gradient record, radius, clamp bits) are requested ONE VIEW AHEAD: with them inside the
     // iteration that uses them every view is a dependent ≈ 2 µs round trip per block
@@ -157,7 +156,6 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float4 r1 = n1;  // mean.y, conic xx, xy, yy
         const float2 r2 = n2;  // opacity, z
         const bool live = in_range && nrad > 0;
-        any_live = any_live || live;
         if (MULTI && v + 1 < NV) {
             const float4* rec = recs + (GGR_G2D_STRIDE / 4) * (o + P);
             n0 = rec[0]; n1 = rec[1]; n2 = *reinterpret_cast<const float2*>(rec + 2); nrad = radii[o + P];
@@ -595,7 +593,6 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
         }
     }
-    (void)any_live;
 }
 
 // dL/d(camera of view v)[k] = Σ_blocks pose_acc[(v·nblocks + b)·64 + k]  (one workgroup per (component, view), fixed

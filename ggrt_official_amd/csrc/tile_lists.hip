@@ -411,7 +411,7 @@ TileListPlan plan_tile_lists(size_t P, size_t T) {
     p.band_tiles = (uint32_t)(T < 4096 ? (T ? T : 1) : 4096);
     p.nbands = (uint32_t)((T + p.band_tiles - 1) / p.band_tiles);
     if (p.nbands == 0) p.nbands = 1;
-    {   // aim for ≥ ~8192 independent walks (chunks × bands); a band is 64 … 1024 tiles.
+    {   // aim for ≥ ~8192 independent walks (chunks × bands); a band is 64 … 512 tiles.
         // The band COUNT is a multiple of 8: bin_scatter gives each band to one XCD (see there), so equal
         // counts per XCD keep the eight of them balanced.  (An earlier attempt at the same idea changed the
         // band sizes at the same time and showed no gain; with the sizes kept and only the block → (band, chunk)
