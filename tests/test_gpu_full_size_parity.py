@@ -9,6 +9,8 @@ five gradient tensors the reference's backward returns:
 * C5'  1 013 760 pixel-aligned Gaussians, 480×352, SH degree 4 / M = 25  (config 5's per-rank shape)
 * C4'  1 146 880 pixel-aligned Gaussians, 448×320, SH degree 4 / M = 25  (config 4: GGRt's LLFF eval shape — the
        eval loop is forward-only, eval/eval_ggrt.py:317; gradients are compared anyway)
+* C6'  4 915 200 pixel-aligned Gaussians, 960×640 (the Waymo eval shape, reference waymo.py:88-90): the scale check —
+       1200 sort tiles (more than are resident at once), 2400 image tiles with depth segments
 * C4' colour + depth through the call-site layer (`render_color_and_depth`-style: aux feature) is covered by
   tests/test_callsite_fused.py at small size and by the a4 goldens.
 
@@ -27,7 +29,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name", ["C3", "C5p", "C4p"])
+@pytest.mark.parametrize("name", ["C3", "C5p", "C4p", "C6p"])
 def test_full_size_image_lists_and_gradients(name):
     sc = make_scene(seed=0, **CONFIGS[name])
     dL = upstream_gradient(sc.width, sc.height)

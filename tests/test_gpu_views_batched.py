@@ -189,3 +189,20 @@ def test_views_sync_free_matches_exact_mode():
     assert rel_l2(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy()) < 1e-5
     assert outs[2][3] and outs[2][2] == outs[0][2]          # overflow raised, true count still reported
     assert torch.isfinite(outs[2][0]).all()
+
+
+def test_more_views_than_sort_segments():
+    """Beyond 64 views the depth sort falls back to ONE segment over all (view, Gaussian) keys: same results."""
+    P, W, H, V = 300, 48, 32, 70
+    sc = make_scene(P, W, H, sh_degree=1, seed=2).to(dev)
+    view, full, campos, tanfov = [t.to(dev) for t in _cameras(W, H, V)]
+    bgs = torch.rand(V, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    with torch.no_grad():
+        color, radii, depth = rasterize_views(sc.means3D, sc.opacities, view, full, campos, bgs, tanfov, sc.settings(),
+                                              shs=sc.shs, cov3D_precomp=sc.cov3D)
+        for v in (0, 1, 33, 69):
+            r = sc.settings()._replace(viewmatrix=view[v], projmatrix=full[v], campos=campos[v], bg=bgs[v],
+                                       tanfovx=float(tanfov[v, 0]), tanfovy=float(tanfov[v, 1]))
+            c1, r1, d1 = GaussianRasterizer(r)(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D),
+                                               opacities=sc.opacities, shs=sc.shs, cov3D_precomp=sc.cov3D)
+            assert torch.equal(color[v], c1) and torch.equal(radii[v], r1) and torch.equal(depth[v], d1)
