@@ -511,6 +511,9 @@ def main():
                 import callsite_bench
                 rec["callsite_ggrt_shape"] = callsite_bench.measure(str(dev), steps=10, warmup=3)
                 log(f"call site at GGRt's shape: {rec['callsite_ggrt_shape']}")
+                # … and four target views of the same Gaussians: per-view loop vs ONE launch set
+                rec["callsite_ggrt_views4"] = callsite_bench.measure_views(str(dev), steps=10, warmup=3, views=4)
+                log(f"four views at GGRt's shape: {rec['callsite_ggrt_views4']}")
             except Exception as e:
                 log(f"call-site leg skipped: {type(e).__name__}: {e}")
         if world == 1 and not args.no_secondary and args.config == "C3":
