@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libggr_raster.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -47,6 +47,7 @@ class GgrForwardOut(C.Structure):
         ("out_color", C.c_void_p), ("radii", C.c_void_p), ("out_depth", C.c_void_p), ("geom_buffer", C.c_void_p),
         ("image_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("num_rendered", C.c_int64),
         ("stage_ms", C.c_void_p), ("binning_capacity", C.c_int64), ("no_backward", C.c_int32),
+        ("backward_scratch", C.c_void_p),
     ]
 
 
@@ -54,7 +55,7 @@ class GgrBackwardIn(C.Structure):
     _fields_ = [
         ("fwd", GgrForwardIn), ("radii", C.c_void_p), ("geom_buffer", C.c_void_p), ("image_buffer", C.c_void_p),
         ("binning_buffer", C.c_void_p), ("num_rendered", C.c_int64), ("dL_dout_color", C.c_void_p),
-        ("dL_dout_depth", C.c_void_p), ("scratch", C.c_void_p),
+        ("dL_dout_depth", C.c_void_p), ("scratch", C.c_void_p), ("scratch_zeroed", C.c_int32),
     ]
 
 

@@ -263,9 +263,12 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     }
     tm.mark();
 
-    // 5. blend
+    // 5. blend (clears the caller's backward scratch on the side; an image without tiles launches nothing)
+    if (out->backward_scratch && tiles == 0)
+        HIP_TRY(hipMemsetAsync(out->backward_scratch, 0, ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s));
     ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, vs.bg, out->out_color, im.final_T, im.n_contrib,
-                          out->out_depth, out->no_backward ? nullptr : im.ckpt, im.ckpt_slots, im.tile_top, NV, s);
+                          out->out_depth, out->no_backward ? nullptr : im.ckpt, im.ckpt_slots, im.tile_top, NV,
+                          out->backward_scratch, ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s);
     KCHECK(dbg, s, "blend_fwd");
     tm.mark();
     tm.finish();
@@ -304,7 +307,8 @@ int backward_impl(const GgrSettings* st, const ViewSet& vs, const GgrBackwardIn*
     BwdScratch sc = ggr_carve_bwd(in->scratch, (size_t)P, (size_t)NV);
 
     StageTimer tm(s, out->stage_ms, GGR_BWD_STAGES);
-    HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));  // dL_dmeans2D / dL_dopacities are written by preprocess_bwd
+    if (!in->scratch_zeroed)  // (else: this frame's forward cleared it inside its blend kernel)
+        HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));  // dL_dmeans2D / dL_dopacities are written by preprocess_bwd
     tm.mark();
 
     if (in->num_rendered != 0) {  // (-1: sync-free forward, count known on the device only)

@@ -202,10 +202,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             fin = _lib.GgrForwardIn(means3D=_ptr(means3D_c), shs=_ptr(sh_c), colors_precomp=_ptr(cp_c),
                                     opacities=_ptr(op_c), scales=_ptr(sc_c), rotations=_ptr(rot_c),
                                     cov3D_precomp=_ptr(cov_c), aux_precomp=_ptr(aux_c), **form)
+            # the backward's per-Gaussian gradient records: cleared by the forward on the side (inside its blend kernel)
+            scratch = None if infer else torch.empty((lib.ggr_backward_scratch_bytes(P),), dtype=torch.uint8, device=dev)
             fout = _lib.GgrForwardOut(out_color=color.data_ptr(), radii=_ptr(radii), out_depth=depth.data_ptr(),
                                       geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
                                       binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0,
-                                      no_backward=int(infer))
+                                      no_backward=int(infer), backward_scratch=_ptr(scratch))
             capacity = int(getattr(rs, "list_capacity", 0) or 0)
             if capacity > 0:  # sync-free mode: bring the list buffer, no read-back inside ggr_forward
                 holder["bin"] = torch.empty((lib.ggr_binning_bytes(capacity, W, H),), dtype=torch.uint8, device=dev)
@@ -228,7 +230,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                          None if aux is None else aux.shape)
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         ctx.save_for_backward(means3D_c, sh_c, cp_c, op_c, sc_c, rot_c, cov_c, bg, view, proj, cam, radii, geom,
-                              img, holder.get("bin"), aux_c)
+                              img, holder.get("bin"), aux_c, scratch)
+        ctx.scratch_fresh = scratch is not None  # (a second backward over this forward clears a scratch of its own)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth
 
@@ -236,7 +239,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_color, _grad_radii, grad_depth):
         lib = _lib.load()
         rs = ctx.raster_settings
-        (means3D, sh, cp, op, sc, rot, cov, bg, view, proj, cam, radii, geom, img, binb, aux) = ctx.saved_tensors
+        (means3D, sh, cp, op, sc, rot, cov, bg, view, proj, cam, radii, geom, img, binb, aux, fwd_scratch) = ctx.saved_tensors
         P, M, H, W = ctx.dims
         dev = means3D.device
         need_pose = any(ctx.needs_input_grad[8:11])
@@ -260,7 +263,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_view = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pose else None
             d_proj = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pose else None
             d_cam = torch.empty((3,), dtype=torch.float32, device=dev) if need_pose else None
-            scratch = torch.empty((lib.ggr_backward_scratch_bytes(P),), dtype=torch.uint8, device=dev)
+            zeroed = bool(getattr(ctx, "scratch_fresh", False)) and fwd_scratch is not None
+            ctx.scratch_fresh = False
+            scratch = fwd_scratch if zeroed else torch.empty((lib.ggr_backward_scratch_bytes(P),), dtype=torch.uint8, device=dev)
 
             st = _settings_struct(rs, P, M, bg, view, proj, cam)
             bin_ = _lib.GgrBackwardIn(
@@ -269,7 +274,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       aux_precomp=_ptr(aux), **form),
                 radii=_ptr(radii), geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
                 binning_buffer=_ptr(binb), num_rendered=ctx.num_rendered, dL_dout_color=grad_color.data_ptr(),
-                dL_dout_depth=_ptr(grad_depth), scratch=scratch.data_ptr())
+                dL_dout_depth=_ptr(grad_depth), scratch=scratch.data_ptr(), scratch_zeroed=int(zeroed))
             bout = _lib.GgrBackwardOut(
                 dL_dmeans3D=d_means3D.data_ptr(), dL_dmeans2D=d_means2D.data_ptr(), dL_dshs=_ptr(d_sh),
                 dL_dcolors_precomp=_ptr(d_cp), dL_dopacities=d_op.data_ptr(), dL_dcov3D=d_cov.data_ptr(),
@@ -362,10 +367,12 @@ class _RasterizeViews(torch.autograd.Function):
             fin = _lib.GgrForwardIn(means3D=_ptr(means3D_c), shs=_ptr(sh_c), colors_precomp=_ptr(cp_c),
                                     opacities=_ptr(op_c), scales=_ptr(sc_c), rotations=_ptr(rot_c),
                                     cov3D_precomp=_ptr(cov_c), aux_precomp=_ptr(aux_c), **form)
+            scratch = None if infer else torch.empty((lib.ggr_backward_scratch_bytes_views(P, V),), dtype=torch.uint8,
+                                                     device=dev)
             fout = _lib.GgrForwardOut(out_color=color.data_ptr(), radii=_ptr(radii), out_depth=depth.data_ptr(),
                                       geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
                                       binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0,
-                                      no_backward=int(infer))
+                                      no_backward=int(infer), backward_scratch=_ptr(scratch))
             capacity = int(getattr(rs, "list_capacity", 0) or 0)
             if capacity > 0:  # sync-free mode: the capacity covers the lists of ALL views
                 holder["bin"] = torch.empty((lib.ggr_binning_bytes(capacity, W, H),), dtype=torch.uint8, device=dev)
@@ -387,7 +394,8 @@ class _RasterizeViews(torch.autograd.Function):
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None,
                    means2D is not None)
         ctx.save_for_backward(means3D_c, sh_c, cp_c, op_c, sc_c, rot_c, cov_c, bg_c, view, proj, cam, radii, geom,
-                              img, holder.get("bin"), aux_c, tf_c, sc_in)
+                              img, holder.get("bin"), aux_c, tf_c, sc_in, scratch)
+        ctx.scratch_fresh = scratch is not None
         ctx.mark_non_differentiable(radii)
         return color, radii, depth
 
@@ -395,7 +403,8 @@ class _RasterizeViews(torch.autograd.Function):
     def backward(ctx, grad_color, _grad_radii, grad_depth):
         lib = _lib.load()
         rs = ctx.raster_settings
-        (means3D, sh, cp, op, sc, rot, cov, bg, view, proj, cam, radii, geom, img, binb, aux, tf, sc_in) = ctx.saved_tensors
+        (means3D, sh, cp, op, sc, rot, cov, bg, view, proj, cam, radii, geom, img, binb, aux, tf, sc_in,
+         fwd_scratch) = ctx.saved_tensors
         P, M, H, W, V = ctx.dims
         dev = means3D.device
         need_pose = any(ctx.needs_input_grad[7:10])
@@ -416,7 +425,10 @@ class _RasterizeViews(torch.autograd.Function):
             d_view = e(V, 4, 4) if need_pose else None
             d_proj = e(V, 4, 4) if need_pose else None
             d_cam = e(V, 3) if need_pose else None
-            scratch = torch.empty((lib.ggr_backward_scratch_bytes_views(P, V),), dtype=torch.uint8, device=dev)
+            zeroed = bool(getattr(ctx, "scratch_fresh", False)) and fwd_scratch is not None
+            ctx.scratch_fresh = False
+            scratch = fwd_scratch if zeroed else torch.empty((lib.ggr_backward_scratch_bytes_views(P, V),),
+                                                             dtype=torch.uint8, device=dev)
             st = _settings_struct(rs._replace(tanfovx=0.0, tanfovy=0.0, tanfov=None), P, M, None, None, None, None)
             vw = _lib.GgrViews(num_views=V, viewmatrix=view.data_ptr(), projmatrix=proj.data_ptr(), campos=cam.data_ptr(),
                                bg=bg.data_ptr(), tanfov=tf.data_ptr(), input_scale=_ptr(sc_in))
@@ -426,7 +438,7 @@ class _RasterizeViews(torch.autograd.Function):
                                       aux_precomp=_ptr(aux), **form),
                 radii=_ptr(radii), geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
                 binning_buffer=_ptr(binb), num_rendered=ctx.num_rendered, dL_dout_color=grad_color.data_ptr(),
-                dL_dout_depth=_ptr(grad_depth), scratch=scratch.data_ptr())
+                dL_dout_depth=_ptr(grad_depth), scratch=scratch.data_ptr(), scratch_zeroed=int(zeroed))
             bout = _lib.GgrBackwardOut(
                 dL_dmeans3D=d_means3D.data_ptr(), dL_dmeans2D=d_means2D.data_ptr(), dL_dshs=_ptr(d_sh),
                 dL_dcolors_precomp=_ptr(d_cp), dL_dopacities=d_op.data_ptr(), dL_dcov3D=d_cov.data_ptr(),

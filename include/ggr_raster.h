@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 4
+#define GGR_ABI_VERSION 5
 
 enum {
     GGR_OK = 0,
@@ -123,6 +123,10 @@ typedef struct GgrForwardOut {
                               the per-pixel checkpoints of the segmented backward (images below 4096 tiles: 320 B per
                               pixel) are neither written nor needed, and image_buffer may be the smaller
                               ggr_image_bytes_inference() bytes.  0: as before. */
+    void* backward_scratch; /* IN, optional.  The ggr_backward_scratch_bytes() buffer the caller will hand to this frame's
+                              ggr_backward: the forward clears it on the side (inside the forward blend kernel, whose
+                              memory pipe is idle) and the backward, told so by GgrBackwardIn.scratch_zeroed, skips its own
+                              64-byte-per-Gaussian memset.  NULL: the backward clears it itself. */
 } GgrForwardOut;
 
 /* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */
@@ -149,6 +153,8 @@ typedef struct GgrBackwardIn {
     const float* dL_dout_color;  /* [3,H,W] */
     const float* dL_dout_depth;  /* [H,W] or NULL (GGRt discards out_depth) */
     void* scratch;               /* ggr_backward_scratch_bytes(P) bytes, caller-allocated */
+    int32_t scratch_zeroed;      /* 1: `scratch` was this frame's GgrForwardOut.backward_scratch and has not been used by
+                                    a backward since (a second backward over the same forward must pass 0) */
 } GgrBackwardIn;
 
 /* Gradients in the order autograd returns them.  Buffers are overwritten
