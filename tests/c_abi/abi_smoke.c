@@ -1,5 +1,6 @@
 /* abi_smoke.c — drives the C ABI from plain C (no Python, no torch): hipMalloc'd buffers, one forward and one
- * backward, checked against the closed form of a single centred Gaussian:
+ * backward — and the same through the several-views entry points — checked against the closed form of a single centred
+ * Gaussian:
  *   colour(centre pixel) = c·alpha + (1-alpha)·bg,  alpha = min(0.99, opacity·exp(-½ dᵀ conic d)).
  * Build: hipcc -x c tests/c_abi/abi_smoke.c -Iinclude -Lggrt_official_amd -lggr_raster -lamdhip64 -lm -o abi_smoke
  * This is the binding a non-Python host would write. */
@@ -106,6 +107,58 @@ int main(void) {
     const float want_gop = (colors[0] - bg[0]) + (colors[1] - bg[1]) + (colors[2] - bg[2]);
     if (fabsf(h_gop[0] - want_gop) > 1e-5f || h_gop[1] != 0.f) { fprintf(stderr, "dL/dopacity = %f %f, want %f 0\n", h_gop[0], h_gop[1], want_gop); bad = 1; }
     for (int c = 3; c < 6; c++) if (h_gcol[c] != 0.f) { fprintf(stderr, "culled Gaussian has a colour gradient\n"); bad = 1; }
+
+    /* ---- two views of the same Gaussians in ONE launch set (ggr_forward_views / ggr_backward_views): view 0 is the camera
+       above, view 1 the same camera with another background — each view's centre pixel has its own closed form, the
+       Gaussian gradients come back summed over the views, the forward clears the backward's scratch on the side ---- */
+    {
+        enum { V = 2 };
+        float views2[V*16], projs2[V*16], cams2[V*3] = {0,0,0, 0,0,0}, bgs2[V*3] = {0.25f,0.5f,0.75f, 0.f,1.f,0.f};
+        float tans2[V*2] = {tanx, tany, tanx, tany};
+        memcpy(views2, view, sizeof view); memcpy(views2 + 16, view, sizeof view);
+        memcpy(projs2, proj, sizeof proj); memcpy(projs2 + 16, proj, sizeof proj);
+        GgrViews vw; memset(&vw, 0, sizeof vw);
+        vw.num_views = V; vw.viewmatrix = upload(views2, V*16); vw.projmatrix = upload(projs2, V*16);
+        vw.campos = upload(cams2, V*3); vw.bg = upload(bgs2, V*3); vw.tanfov = upload(tans2, V*2);
+        float *v_color, *v_depth; int32_t* v_radii; void *v_geom, *v_img, *v_scratch;
+        CHECK(hipMalloc((void**)&v_color, V*3*W*H*4)); CHECK(hipMalloc((void**)&v_depth, V*W*H*4));
+        CHECK(hipMalloc((void**)&v_radii, V*P*4));
+        CHECK(hipMalloc(&v_geom, ggr_geom_bytes_views(P, V))); CHECK(hipMalloc(&v_img, ggr_image_bytes_views(W, H, V)));
+        CHECK(hipMalloc(&v_scratch, ggr_backward_scratch_bytes_views(P, V)));
+        GgrForwardOut vo; memset(&vo, 0, sizeof vo);
+        vo.out_color = v_color; vo.radii = v_radii; vo.out_depth = v_depth; vo.geom_buffer = v_geom; vo.image_buffer = v_img;
+        vo.backward_scratch = v_scratch;
+        Two vmem; memset(&vmem, 0, sizeof vmem);
+        if (ggr_forward_views(&st, &vw, &in, &vo, two_alloc, &vmem, NULL) != GGR_OK) { fprintf(stderr, "forward_views: %s\n", ggr_last_error()); return 1; }
+        CHECK(hipDeviceSynchronize());
+        static float hv[V*3*W*H];
+        CHECK(hipMemcpy(hv, v_color, sizeof hv, hipMemcpyDeviceToHost));
+        for (int v = 0; v < V; v++)
+            for (int c = 0; c < 3; c++) {
+                const float want = colors[c] * alpha + (1.f - alpha) * bgs2[3*v + c];
+                const float got = hv[(v*3 + c)*W*H + cy*W + cx];
+                if (fabsf(got - want) > 1e-5f) { fprintf(stderr, "view %d channel %d: got %f want %f\n", v, c, got, want); bad = 1; }
+            }
+        if (vo.num_rendered != 2 * out.num_rendered) { fprintf(stderr, "views num_rendered %lld\n", (long long)vo.num_rendered); bad = 1; }
+        static float hdL2[V*3*W*H]; memset(hdL2, 0, sizeof hdL2);
+        for (int v = 0; v < V; v++) for (int c = 0; c < 3; c++) hdL2[(v*3 + c)*W*H + cy*W + cx] = 1.f;
+        float* d_dL2 = upload(hdL2, V*3*W*H);
+        float* g_m2d2; CHECK(hipMalloc((void**)&g_m2d2, V*P*3*4));
+        GgrBackwardIn vbi; memset(&vbi, 0, sizeof vbi);
+        vbi.fwd = in; vbi.radii = v_radii; vbi.geom_buffer = v_geom; vbi.image_buffer = v_img; vbi.binning_buffer = vo.binning_buffer;
+        vbi.num_rendered = vo.num_rendered; vbi.dL_dout_color = d_dL2; vbi.scratch = v_scratch; vbi.scratch_zeroed = 1;
+        GgrBackwardOut vbo = bo; vbo.dL_dmeans2D = g_m2d2;
+        if (ggr_backward_views(&st, &vw, &vbi, &vbo, NULL) != GGR_OK) { fprintf(stderr, "backward_views: %s\n", ggr_last_error()); return 1; }
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(h_gcol, g_col, sizeof h_gcol, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h_gop, g_op, sizeof h_gop, hipMemcpyDeviceToHost));
+        /* summed over the two views: dL/dcolour = 2·alpha; dL/dopacity = Σ_views Σ_c (colour_c − bg_c) */
+        for (int c = 0; c < 3; c++) if (fabsf(h_gcol[c] - 2.f * alpha) > 1e-6f) { fprintf(stderr, "views dL/dcolour[%d] = %f\n", c, h_gcol[c]); bad = 1; }
+        float want2 = 0.f;
+        for (int v = 0; v < V; v++) for (int c = 0; c < 3; c++) want2 += colors[c] - bgs2[3*v + c];
+        if (fabsf(h_gop[0] - want2) > 1e-5f) { fprintf(stderr, "views dL/dopacity = %f, want %f\n", h_gop[0], want2); bad = 1; }
+        hipFree(vmem.p[0]); hipFree(vmem.p[1]);
+    }
 
     hipFree(mem.p[0]); hipFree(mem.p[1]);
     printf(bad ? "C ABI SMOKE FAILED\n" : "C ABI SMOKE OK (num_rendered %lld, radius %d)\n", (long long)out.num_rendered, h_radii[0]);
