@@ -51,7 +51,9 @@
 #define GGR_PRE_THREADS 256       // preprocess_fwd block size: one key maximum per block is left for the sort
 
 // tile-list builder: Gaussians (in depth order) per chunk
+#ifndef GGR_BIN_CHUNK
 #define GGR_BIN_CHUNK 1024
+#endif
 
 static inline size_t ggr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
