@@ -82,8 +82,15 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
-// MULTI = false: one view, the loop over views folds away at compile time; MULTI = true: run-time loop over the views
-template <bool MULTI>
+// MULTI = false: one view, the loop over views folds away at compile time; MULTI = true: run-time loop over the views.
+// KC = 0: the block's SH rows are staged whole (sh_stage.h).  KC = 16 / 25 (one view, degree 3 / 4): the rows go
+// through LDS one THIRD at a time — KC floats per Gaussian: one colour channel of channel-major rows, floats
+// [J·KC, (J+1)·KC) of k-major ones — with the next third's loads in flight while the current one is consumed.  A whole
+// 75-float row per Gaussian is 76.8 KB of LDS per block = 2 blocks per CU, and the kernel then runs at 2.9 TB/s; a third
+// is 25.6 KB (tools/sh_stage_bench.hip: the bare access pattern 0.105 → 0.082 ms at 1 M × 75 floats, 0.063 → 0.050 at
+// 48; the rows' lines are fetched three times, L2 hits after the first).  Every channel still sums its coefficients in
+// ascending k, so the colours stay bit-identical to the whole-row path.
+template <bool MULTI, int KC>
 __global__ void __launch_bounds__(GGR_PRE_THREADS)
 preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -136,13 +143,35 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     }
     float cp_in[3] = {0.f, 0.f, 0.f};
     if (colors_precomp) { cp_in[0] = colors_precomp[3 * il]; cp_in[1] = colors_precomp[3 * il + 1]; cp_in[2] = colors_precomp[3 * il + 2]; }
+    // chunked staging (KC > 0): per trip the block copies RPI = ⌊256 / KC⌋ rows' thirds, thread t float t mod KC of row
+    // t / KC (KC = 25: 250 of the 256 threads) — so addresses and LDS slots advance by constants from trip to trip and
+    // nothing but the loaded values is carried through the geometry code
+    constexpr int KCN = KC > 0 ? KC : 1, KC_STRIDE = KC | 1, RPI = GGR_PRE_THREADS / KCN,
+                  ITS = KC > 0 ? (GGR_PRE_THREADS + RPI - 1) / RPI : 1;
+    float ch_v[ITS];
+    const float* ch_src = nullptr;
+    const int ch_step = inf.sh_channel_major ? M : KC;  // where the next third starts in a row
+    const int ch_g = (int)threadIdx.x / KCN, ch_k = (int)threadIdx.x - ch_g * KCN;
+    const bool ch_act = ch_g < RPI;
+    int ch_last = 0;  // last row of this block
+    auto load_third = [&](int J) {
+        const float* src = ch_src + J * ch_step;  // (uniform base + 32-bit lane offset: one address register per load)
+#pragma unroll
+        for (int it = 0; it < ITS; it++)  // (clamped: every load is issued; rows past the block's last are not kept)
+            ch_v[it] = src[(uint32_t)min(ch_g + it * RPI, ch_last) * (uint32_t)(3 * M) + (uint32_t)ch_k];
+    };
     if (shs) {
         const size_t g0 = (size_t)blockIdx.x * blockDim.x;
         const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
         const size_t row = (size_t)M * 3;
-        if (sh_compact) stage_sh_rows_compact(sh_lds, shs, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
-        else stage_sh_rows(sh_lds, shs, g0, nG, row, copy_row, sh_stride, sh_flat);
-        __syncthreads();
+        if (KC == 0) {
+            if (sh_compact) stage_sh_rows_compact(sh_lds, shs, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
+            else stage_sh_rows(sh_lds, shs, g0, nG, row, copy_row, sh_stride, sh_flat);
+            __syncthreads();
+        } else {
+            ch_src = shs + g0 * row;
+            ch_last = nG - 1;
+        }
     }
     const bool in_range = i < P;  // (threads past P run on Gaussian P-1's inputs and store nothing)
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
@@ -186,6 +215,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             }
         }
 
+        // ---- geometry: visible (in front of the near plane, invertible 2D covariance, touches a tile) or culled ----
+        bool vis = false;
+        float px = 0.f, py = 0.f, con0 = 0.f, con1 = 0.f, con2 = 0.f;
         float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
         float t1 = V[1] * p0 + V[5] * p1 + V[9] * p2 + V[13];
         const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
@@ -226,39 +258,20 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             const float det = a * c - b * b;
             if (det != 0.0f) {
                 const float det_inv = 1.f / det;
-                const float con0 = c * det_inv, con1 = -b * det_inv, con2 = a * det_inv;
+                con0 = c * det_inv; con1 = -b * det_inv; con2 = a * det_inv;
                 const float mid = 0.5f * (a + c);
                 const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
                 const float l1 = mid + sq, l2 = mid - sq;
                 const int rad = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
-                const float px = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
-                const float py = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
+                px = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
+                py = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
                 const int rminx = min(gx, max(0, (int)((px - (float)rad) / (float)GGR_TILE)));
                 const int rminy = min(gy, max(0, (int)((py - (float)rad) / (float)GGR_TILE)));
                 const int rmaxx = min(gx, max(0, (int)((px + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
                 const int rmaxy = min(gy, max(0, (int)((py + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
                 const int area = (rmaxx - rminx) * (rmaxy - rminy);
                 if (area != 0) {
-                    float rgb[3];
-                    if (colors_precomp) {
-                        rgb[0] = cp_in[0]; rgb[1] = cp_in[1]; rgb[2] = cp_in[2];
-                    } else {
-                        const int deg = sh_deg;
-                        float d0 = p0 - campos[0], d1 = p1 - campos[1], d2 = p2 - campos[2];
-                        const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-                        d0 /= len; d1 /= len; d2 /= len;
-                        float B[25];
-                        sh_basis(deg, d0, d1, d2, B);
-                        const int K = (deg + 1) * (deg + 1);
-                        const float* sh = sh_lds + threadIdx.x * sh_stride;
-                        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-                        for (int k = 0; k < K; k++) {
-                            r0 += B[k] * sh[k * sh_ks]; r1 += B[k] * sh[k * sh_ks + sh_cs]; r2 += B[k] * sh[k * sh_ks + 2 * sh_cs];
-                        }
-                        r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
-                        clamp_bits = (r0 < 0.f ? 1u : 0u) | (r1 < 0.f ? 2u : 0u) | (r2 < 0.f ? 4u : 0u);
-                        rgb[0] = fmaxf(r0, 0.f); rgb[1] = fmaxf(r1, 0.f); rgb[2] = fmaxf(r2, 0.f);
-                    }
+                    vis = true;
                     rad_out = rad;
                     key_out = __float_as_uint(t2) - GGR_KEY_BASE;  // > 0: t2 > 0.2f
                     tiles_out = (uint32_t)area;
@@ -266,16 +279,70 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     const uint32_t yo = (uint32_t)(v * gy);
                     rect_out = make_uint2((uint32_t)rminx | (((uint32_t)rminy + yo) << 16),
                                           (uint32_t)rmaxx | (((uint32_t)rmaxy + yo) << 16));
-                    s0 = make_float4(px, py, con0, con1);
-                    s1 = make_float4(con2, opac, rgb[0], rgb[1]);
-                    // 4th blended feature: the caller's aux value, or view z, or (fused GGRt depth pass, :240-269)
-                    // max(a + b·z_unscaled, 0) with z_unscaled = z / s
-                    float feat = t2;
-                    if (aux_precomp) feat = aux_in;
-                    else if (inf.aux_affine) feat = fmaxf(inf.aux_a + inf.aux_b * (t2 / in_s), 0.f);
-                    s2 = make_float4(rgb[2], feat, 2.f * logf(255.f * opac), 0.f);  // .z = qmax for the box cull
                 }
             }
+        }
+
+        // ---- colour ---------------------------------------------------------------------------------------------------
+        float rgb[3] = {0.f, 0.f, 0.f};
+        if (colors_precomp) {
+            rgb[0] = cp_in[0]; rgb[1] = cp_in[1]; rgb[2] = cp_in[2];
+        } else if (KC > 0 || vis) {
+            // (chunked staging: every thread walks the thirds — the barriers between them are block-wide; a culled
+            //  Gaussian's sums are dropped below)
+            const int deg = KC == 16 ? 3 : KC == 25 ? 4 : sh_deg;
+            float d0 = p0 - campos[0], d1 = p1 - campos[1], d2 = p2 - campos[2];
+            const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+            d0 /= len; d1 /= len; d2 /= len;
+            float B[25];
+            sh_basis(deg, d0, d1, d2, B);
+            float r[3] = {0.f, 0.f, 0.f};
+            if (KC == 0) {
+                const int K = (deg + 1) * (deg + 1);
+                const float* sh = sh_lds + threadIdx.x * sh_stride;
+                for (int k = 0; k < K; k++) {
+                    r[0] += B[k] * sh[k * sh_ks]; r[1] += B[k] * sh[k * sh_ks + sh_cs]; r[2] += B[k] * sh[k * sh_ks + 2 * sh_cs];
+                }
+            } else {
+                const float* seg = sh_lds + threadIdx.x * KC_STRIDE;
+                const bool cm = inf.sh_channel_major != 0;
+                // (the first third is requested here, not before the geometry: its 26 values carried through that code
+                //  cost a wave per SIMD — 170 instead of 148 VGPRs at KC = 25 — and the block's neighbours on the CU
+                //  cover the round trip)
+                load_third(0);
+#pragma unroll
+                for (int J = 0; J < 3; J++) {
+                    if (J) __syncthreads();  // the previous third has been consumed
+#pragma unroll
+                    for (int it = 0; it < ITS; it++)
+                        if (ch_act && ch_g + it * RPI < GGR_PRE_THREADS) sh_lds[(ch_g + it * RPI) * KC_STRIDE + ch_k] = ch_v[it];
+                    if (J < 2) load_third(J + 1);
+                    __syncthreads();
+                    if (cm) {   // third J = channel J, coefficients 0 … KC-1
+#pragma unroll
+                        for (int k = 0; k < KCN; k++) r[J] += B[k] * seg[k];
+                    } else {    // third J = floats [J·KC, (J+1)·KC) of the k-major row: float f = coefficient f / 3, channel f mod 3
+#pragma unroll
+                        for (int e = 0; e < KCN; e++) {
+                            const int f = J * KCN + e;
+                            r[f % 3] += B[f / 3] * seg[e];
+                        }
+                    }
+                }
+            }
+            r[0] += 0.5f; r[1] += 0.5f; r[2] += 0.5f;
+            if (vis) clamp_bits = (r[0] < 0.f ? 1u : 0u) | (r[1] < 0.f ? 2u : 0u) | (r[2] < 0.f ? 4u : 0u);
+            rgb[0] = fmaxf(r[0], 0.f); rgb[1] = fmaxf(r[1], 0.f); rgb[2] = fmaxf(r[2], 0.f);
+        }
+        if (vis) {
+            s0 = make_float4(px, py, con0, con1);
+            s1 = make_float4(con2, opac, rgb[0], rgb[1]);
+            // 4th blended feature: the caller's aux value, or view z, or (fused GGRt depth pass, :240-269)
+            // max(a + b·z_unscaled, 0) with z_unscaled = z / s
+            float feat = t2;
+            if (aux_precomp) feat = aux_in;
+            else if (inf.aux_affine) feat = fmaxf(inf.aux_a + inf.aux_b * (t2 / in_s), 0.f);
+            s2 = make_float4(rgb[2], feat, 2.f * logf(255.f * opac), 0.f);  // .z = qmax for the box cull
         }
         if (in_range) {
             radii[o] = rad_out;
@@ -315,17 +382,19 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     const size_t rowf = (size_t)(3 * (deg + 1) * (deg + 1));
     const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
     const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
-    const size_t lds = shs ? (size_t)threads * row_stride * sizeof(float) : 0;
-    if (vs.V > 1)
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
-                           colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
-                           aux_precomp, vs, W, H, radii, g.splat, g.keys_a, g.vals_a, g.tiles_touched, g.rect,
-                           g.clamped, g.cov3D, g.hist, zero_words, g.hist + zero_words, inf);
-    else
-        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,
-                           colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
-                           aux_precomp, vs, W, H, radii, g.splat, g.keys_a, g.vals_a, g.tiles_touched, g.rect,
-                           g.clamped, g.cov3D, g.hist, zero_words, g.hist + zero_words, inf);
+    // one view at degree 3 / 4: the rows go through LDS a third at a time (see the kernel's header)
+    const int kc = (shs && vs.V == 1 && (deg == 3 || deg == 4)) ? (deg + 1) * (deg + 1) : 0;
+    const size_t lds = !shs ? 0 : kc ? (size_t)threads * (kc | 1) * sizeof(float) : (size_t)threads * row_stride * sizeof(float);
+#define GGR_LAUNCH_PFWD(MULTI_, KC_)                                                                                      \
+    hipLaunchKernelGGL((preprocess_fwd_kernel<MULTI_, KC_>), dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,  \
+                       colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp, aux_precomp, vs, W, H, \
+                       radii, g.splat, g.keys_a, g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D, g.hist,          \
+                       zero_words, g.hist + zero_words, inf)
+    if (vs.V > 1) GGR_LAUNCH_PFWD(true, 0);
+    else if (kc == 16) GGR_LAUNCH_PFWD(false, 16);
+    else if (kc == 25) GGR_LAUNCH_PFWD(false, 25);
+    else GGR_LAUNCH_PFWD(false, 0);
+#undef GGR_LAUNCH_PFWD
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D,
