@@ -143,23 +143,10 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     }
     float cp_in[3] = {0.f, 0.f, 0.f};
     if (colors_precomp) { cp_in[0] = colors_precomp[3 * il]; cp_in[1] = colors_precomp[3 * il + 1]; cp_in[2] = colors_precomp[3 * il + 2]; }
-    // chunked staging (KC > 0): per trip the block copies RPI = ⌊256 / KC⌋ rows' thirds, thread t float t mod KC of row
-    // t / KC (KC = 25: 250 of the 256 threads) — so addresses and LDS slots advance by constants from trip to trip and
-    // nothing but the loaded values is carried through the geometry code
-    constexpr int KCN = KC > 0 ? KC : 1, KC_STRIDE = KC | 1, RPI = GGR_PRE_THREADS / KCN,
-                  ITS = KC > 0 ? (GGR_PRE_THREADS + RPI - 1) / RPI : 1;
-    float ch_v[ITS];
-    const float* ch_src = nullptr;
-    const int ch_step = inf.sh_channel_major ? M : KC;  // where the next third starts in a row
-    const int ch_g = (int)threadIdx.x / KCN, ch_k = (int)threadIdx.x - ch_g * KCN;
-    const bool ch_act = ch_g < RPI;
-    int ch_last = 0;  // last row of this block
-    auto load_third = [&](int J) {
-        const float* src = ch_src + J * ch_step;  // (uniform base + 32-bit lane offset: one address register per load)
-#pragma unroll
-        for (int it = 0; it < ITS; it++)  // (clamped: every load is issued; rows past the block's last are not kept)
-            ch_v[it] = src[(uint32_t)min(ch_g + it * RPI, ch_last) * (uint32_t)(3 * M) + (uint32_t)ch_k];
-    };
+    // chunked staging (KC > 0): sh_stage.h ShThirds
+    constexpr int KCN = KC > 0 ? KC : 1, KC_STRIDE = KC | 1;
+    ShThirds<KCN> thirds;
+    float ch_v[ShThirds<KCN>::ITS];
     if (shs) {
         const size_t g0 = (size_t)blockIdx.x * blockDim.x;
         const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
@@ -169,8 +156,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             else stage_sh_rows(sh_lds, shs, g0, nG, row, copy_row, sh_stride, sh_flat);
             __syncthreads();
         } else {
-            ch_src = shs + g0 * row;
-            ch_last = nG - 1;
+            thirds.init(shs + g0 * row, nG, (int)row, inf.sh_channel_major ? M : KC);
         }
     }
     const bool in_range = i < P;  // (threads past P run on Gaussian P-1's inputs and store nothing)
@@ -309,14 +295,12 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 // (the first third is requested here, not before the geometry: its 26 values carried through that code
                 //  cost a wave per SIMD — 170 instead of 148 VGPRs at KC = 25 — and the block's neighbours on the CU
                 //  cover the round trip)
-                load_third(0);
+                thirds.load(ch_v, 0);
 #pragma unroll
                 for (int J = 0; J < 3; J++) {
                     if (J) __syncthreads();  // the previous third has been consumed
-#pragma unroll
-                    for (int it = 0; it < ITS; it++)
-                        if (ch_act && ch_g + it * RPI < GGR_PRE_THREADS) sh_lds[(ch_g + it * RPI) * KC_STRIDE + ch_k] = ch_v[it];
-                    if (J < 2) load_third(J + 1);
+                    thirds.store(sh_lds, ch_v);
+                    if (J < 2) thirds.load(ch_v, J + 1);
                     __syncthreads();
                     if (cm) {   // third J = channel J, coefficients 0 … KC-1
 #pragma unroll

@@ -8,6 +8,7 @@
 // campos) — an extension beyond the reference.
 #include "ggr_common.h"
 #include "sh_stage.h"
+#include <algorithm>
 
 namespace ggr {
 
@@ -73,9 +74,68 @@ __device__ __forceinline__ void sh_basis25(int deg, float x, float y, float z, f
     }
 }
 
+// The SH terms of a direction (x, y, z): T(k, B_k, ∂B_k/∂x, ∂B_k/∂y, ∂B_k/∂z) for every coefficient k of degree ≤ deg, in
+// the rasterizer's sign convention (band 4: oracle/ggr_oracle.c header, plain polynomial derivatives).  Needs x, y, z
+// in scope; unused values fold away.  F: statement placed in front of every band (a scheduling fence, or nothing).
+#define GGR_SH_TERMS(T, deg, F)                                                                                            \
+    {                                                                                                                     \
+        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;                                    \
+        T(0, SH_C0, 0.f, 0.f, 0.f)                                                                                        \
+        if ((deg) > 0) {                                                                                                  \
+            F                                                                                                             \
+            T(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)                                                                            \
+            T(2, SH_C1 * z, 0.f, 0.f, SH_C1)                                                                              \
+            T(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)                                                                            \
+            if ((deg) > 1) {                                                                                              \
+                F                                                                                                         \
+                T(4, bSH_C2[0] * xy, bSH_C2[0] * y, bSH_C2[0] * x, 0.f)                                                   \
+                T(5, bSH_C2[1] * yz, 0.f, bSH_C2[1] * z, bSH_C2[1] * y)                                                   \
+                T(6, bSH_C2[2] * (2.f * zz - xx - yy), bSH_C2[2] * -2.f * x, bSH_C2[2] * -2.f * y, bSH_C2[2] * 4.f * z)  \
+                T(7, bSH_C2[3] * xz, bSH_C2[3] * z, 0.f, bSH_C2[3] * x)                                                   \
+                T(8, bSH_C2[4] * (xx - yy), bSH_C2[4] * 2.f * x, bSH_C2[4] * -2.f * y, 0.f)                               \
+                if ((deg) > 2) {                                                                                          \
+                    F                                                                                                     \
+                    T(9, bSH_C3[0] * y * (3.f * xx - yy), bSH_C3[0] * 6.f * xy, bSH_C3[0] * 3.f * (xx - yy), 0.f)         \
+                    T(10, bSH_C3[1] * xy * z, bSH_C3[1] * yz, bSH_C3[1] * xz, bSH_C3[1] * xy)                             \
+                    T(11, bSH_C3[2] * y * (4.f * zz - xx - yy), bSH_C3[2] * -2.f * xy,                                    \
+                      bSH_C3[2] * (-3.f * yy + 4.f * zz - xx), bSH_C3[2] * 8.f * yz)                                      \
+                    T(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), bSH_C3[3] * -6.f * xz,                        \
+                      bSH_C3[3] * -6.f * yz, bSH_C3[3] * 3.f * (2.f * zz - xx - yy))                                      \
+                    F                                                                                                     \
+                    T(13, bSH_C3[4] * x * (4.f * zz - xx - yy), bSH_C3[4] * (-3.f * xx + 4.f * zz - yy),                  \
+                      bSH_C3[4] * -2.f * xy, bSH_C3[4] * 8.f * xz)                                                        \
+                    T(14, bSH_C3[5] * z * (xx - yy), bSH_C3[5] * 2.f * xz, bSH_C3[5] * -2.f * yz, bSH_C3[5] * (xx - yy))  \
+                    T(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)       \
+                    if ((deg) > 3) {                                                                                      \
+                        F                                                                                                 \
+                        const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f, c21 = 21.f * zz - 3.f;                      \
+                        const float xmy = xx - yy, x3y = xx - 3.f * yy, y3x = 3.f * xx - yy;                              \
+                        T(16, bSH_C4[0] * xy * xmy, bSH_C4[0] * y * y3x, bSH_C4[0] * x * x3y, 0.f)                        \
+                        T(17, bSH_C4[1] * yz * y3x, bSH_C4[1] * 6.f * xy * z, bSH_C4[1] * 3.f * z * xmy, bSH_C4[1] * y * y3x) \
+                        T(18, bSH_C4[2] * xy * a7, bSH_C4[2] * y * a7, bSH_C4[2] * x * a7, bSH_C4[2] * 14.f * xy * z)     \
+                        T(19, bSH_C4[3] * yz * b7, 0.f, bSH_C4[3] * z * b7, bSH_C4[3] * y * c21)                          \
+                        T(20, bSH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f), 0.f, 0.f, bSH_C4[4] * z * (140.f * zz - 60.f)) \
+                        F                                                                                                 \
+                        T(21, bSH_C4[5] * xz * b7, bSH_C4[5] * z * b7, 0.f, bSH_C4[5] * x * c21)                          \
+                        T(22, bSH_C4[6] * xmy * a7, bSH_C4[6] * 2.f * x * a7, bSH_C4[6] * -2.f * y * a7, bSH_C4[6] * 14.f * z * xmy) \
+                        T(23, bSH_C4[7] * xz * x3y, bSH_C4[7] * 3.f * z * xmy, bSH_C4[7] * -6.f * xy * z, bSH_C4[7] * x * x3y) \
+                        T(24, bSH_C4[8] * (xx * x3y - yy * y3x), bSH_C4[8] * 4.f * x * x3y, bSH_C4[8] * -4.f * y * y3x, 0.f) \
+                    }                                                                                                     \
+                }                                                                                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+
 // MULTI = false: one view, the loop over views folds away at compile time (the reference's backward, and its register
 // budget); MULTI = true: the launch set's views in a run-time loop
-template <bool POSE, bool MULTI>
+// KC = 16 / 25 (one view, degree 3 / 4, rows of more than 64 floats): the SH rows never sit whole in LDS (76.8 KB per
+// block at GGRt's 75 floats = 2 blocks per CU).  They are READ one third at a time (sh_stage.h ShThirds) for the
+// view-direction term; the gradient rows — rank one, B_k(direction)·dL/dcolour_c — are then built by their owner
+// threads and copied out flat in three ROW ranges (whole 128-B lines; written by column thirds the partial lines cost
+// more than the occupancy gives: tools/sh_stage_bench.hip, 0.149 ms whole rows / 0.214 column thirds / 0.129 this).
+// CM (KC > 0 only): channel-major rows — a template parameter because with both row forms in one kernel the compiler
+// shares the basis gradients across the two branches: 199 VGPRs instead of 162 / 131.
+template <bool POSE, bool MULTI, int KC, bool CM>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                       int has_colors_precomp, const float* __restrict__ scales,
@@ -121,7 +181,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             for (int k = 0; k < 6; k++) cin_in[k] = cov3D[6 * il + k];
         }
     }
-    if (use_sh) {
+    if (use_sh && KC == 0) {
         if (sh_compact) stage_sh_rows_compact(sh_lds, shs, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
         else stage_sh_rows(sh_lds, shs, g0, nG, sh_row, copy_row, sh_stride, sh_flat);
         __syncthreads();
@@ -375,7 +435,102 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     }
 
     // ---- outputs: sums over the views -------------------------------------------------------------------------
-    if (use_sh) {
+    if (use_sh && KC > 0) {
+        constexpr int KCN = KC > 0 ? KC : 1, DEG = KC == 16 ? 3 : 4;
+        // ---- (1) view-direction term: dL/dmean += (∂dir/∂mean)ᵀ Σ_k ∇B_k(dir) · (sh_k · dL/dcolour), rows read by thirds ----
+        ShThirds<KCN> thirds;
+        float ch_v[ShThirds<KCN>::ITS];
+        thirds.init(shs + g0 * sh_row, nG, (int)sh_row, inf.sh_channel_major ? M : KC);
+        thirds.load(ch_v, 0);
+        const float4 c0 = recs[(GGR_G2D_STRIDE / 4) * il];  // r, g, b, –
+        const bool live = in_range && radii[il] > 0;
+        const uint32_t cl = clamped[il];
+        // a culled Gaussian walks the thirds too (block-wide barriers) with a zero colour gradient and a fixed direction
+        float dc[3] = {live && !(cl & 1u) ? c0.x : 0.f, live && !(cl & 2u) ? c0.y : 0.f, live && !(cl & 4u) ? c0.z : 0.f};
+        const float in_s = vs.input_scale ? vs.input_scale[0] : 1.0f;
+        const float vx = live ? in_s * m0 - vs.campos[0] : 0.f, vy = live ? in_s * m1 - vs.campos[1] : 0.f,
+                    vz = live ? in_s * m2 - vs.campos[2] : 1.f;
+        const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+        float x = vx / len, y = vy / len, z = vz / len;
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        constexpr bool cm = CM;
+        const float* seg = sh_lds + threadIdx.x * ShThirds<KCN>::STRIDE;
+#pragma unroll
+        for (int J = 0; J < 3; J++) {
+            if (J) __syncthreads();  // the previous third has been consumed
+            thirds.store(sh_lds, ch_v);
+            if (J < 2) thirds.load(ch_v, J + 1);
+            __syncthreads();
+            // (the basis gradients are formed anew in every third: shared across the three unrolled copies they are
+            //  ≈ 100 live values next to the 26 in flight — 240 VGPRs instead of ≈ 130)
+            __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z));
+            // third J: channel J of channel-major rows (coefficient k at k), floats [J·KC, (J+1)·KC) of k-major ones
+            // (coefficient k, channel c at 3k + c − J·KC)
+#define SH_DIR_CM(k, Bk, bx, by, bz) { const float sd = seg[k] * dc[J]; ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd; }
+#define SH_DIR_KM(k, Bk, bx, by, bz)                                                                   \
+    _Pragma("unroll") for (int c = 0; c < 3; c++)                                                      \
+        if ((3 * (k) + c) / KCN == J) {                                                                \
+            const float sd = seg[3 * (k) + c - J * KCN] * dc[c];                                       \
+            ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                      \
+        }
+            // (band by band: a compiler fence between the bands keeps the third's 25 LDS reads and the bands' basis
+            //  gradients from all being live at once)
+#define SH_FENCE __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(xx), "+v"(yy), "+v"(zz), "+v"(xy), "+v"(yz), "+v"(xz), "+v"(ddx), "+v"(ddy), "+v"(ddz) :: "memory");
+            if (cm) GGR_SH_TERMS(SH_DIR_CM, DEG, SH_FENCE)
+            if (!cm) GGR_SH_TERMS(SH_DIR_KM, DEG, SH_FENCE)
+#undef SH_FENCE
+#undef SH_DIR_CM
+#undef SH_DIR_KM
+        }
+        float dcam[3] = {0.f, 0.f, 0.f};
+        if (live) {
+            const float sum2 = vx * vx + vy * vy + vz * vz;
+            const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            const float gx_ = ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
+            const float gy_ = (-vx * vy * ddx + (sum2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
+            const float gz_ = (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * inv32;
+            dmean[0] += in_s * gx_; dmean[1] += in_s * gy_; dmean[2] += in_s * gz_;
+            if (POSE) { dcam[0] = -gx_; dcam[1] = -gy_; dcam[2] = -gz_; }
+        }
+        if (POSE) {  // dL/dcampos partial joins the row the main loop wrote (same threads: 32..34)
+            __shared__ float cred3[4][4];
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float scm = wave_sum_lane63(dcam[k]);
+                if (lane == 63) cred3[wave][k] = scm;
+            }
+            __syncthreads();
+            if (threadIdx.x >= 32 && threadIdx.x < 35) {
+                const int k = threadIdx.x - 32;
+                pose_acc[(size_t)blockIdx.x * 64 + threadIdx.x] += cred3[0][k] + cred3[1][k] + cred3[2][k] + cred3[3][k];
+            }
+        }
+        // ---- (2) dL/dSH rows, three row ranges of the block: owners build, everybody copies out ------------------------
+        const int rowlen = (int)sh_row;
+        const int pk = cm ? 1 : 3, pc = cm ? M : 1;   // coefficient k, channel c sits at k·pk + c·pc
+#pragma unroll 1
+        for (int R = 0; R < 3; R++) {
+            const int r0 = 84 * R, r1 = R == 2 ? 256 : r0 + 84;   // (84 rows: a multiple of 4 → 16-B aligned ranges)
+            __syncthreads();  // LDS free (the thirds / the previous range have been read)
+            if ((int)threadIdx.x >= r0 && (int)threadIdx.x < r1 && in_range) {
+                float* rowp = sh_lds + ((int)threadIdx.x - r0) * rowlen;
+#define SH_ROW(k, Bk, bx, by, bz) { const float b_ = (Bk); rowp[(k) * pk] = b_ * dc[0]; rowp[(k) * pk + pc] = b_ * dc[1]; rowp[(k) * pk + 2 * pc] = b_ * dc[2]; }
+                GGR_SH_TERMS(SH_ROW, DEG, )
+#undef SH_ROW
+                for (int k = KCN; k < M; k++) { rowp[k * pk] = 0.f; rowp[k * pk + pc] = 0.f; rowp[k * pk + 2 * pc] = 0.f; }  // bands not evaluated
+            }
+            __syncthreads();
+            const int nrow = min(r1, nG) - r0;
+            if (nrow > 0) {
+                const int total = nrow * rowlen, n4 = total >> 2;
+                float* dst = dL_dsh + (g0 + r0) * sh_row;
+                for (int j = threadIdx.x; j < n4; j += 256)
+                    reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(sh_lds)[j];
+                for (int j = (n4 << 2) + threadIdx.x; j < total; j += 256) dst[j] = sh_lds[j];
+            }
+        }
+    } else if (use_sh) {
         // dL/dSH[k][c] = Σ_views B_k(direction of the view) · dL/dcolour_c(view), one colour channel at a time: 25
         // accumulators instead of 75 (the basis is recomputed per (channel, view) — the kernel is HBM-bound, not
         // VALU-bound — where 75 accumulators carried through the view loop cost 256 VGPRs + spills).  The Gaussian's
@@ -420,46 +575,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const float sd = s0 * dc0 + s1 * dc1 + s2 * dc2;                                               \
     ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                          \
 }
-            SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)
-            if (deg > 0) {
-                SH_TERM(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)
-                SH_TERM(2, SH_C1 * z, 0.f, 0.f, SH_C1)
-                SH_TERM(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)
-                if (deg > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    SH_TERM(4, bSH_C2[0] * xy, bSH_C2[0] * y, bSH_C2[0] * x, 0.f)
-                    SH_TERM(5, bSH_C2[1] * yz, 0.f, bSH_C2[1] * z, bSH_C2[1] * y)
-                    SH_TERM(6, bSH_C2[2] * (2.f * zz - xx - yy), bSH_C2[2] * -2.f * x, bSH_C2[2] * -2.f * y, bSH_C2[2] * 4.f * z)
-                    SH_TERM(7, bSH_C2[3] * xz, bSH_C2[3] * z, 0.f, bSH_C2[3] * x)
-                    SH_TERM(8, bSH_C2[4] * (xx - yy), bSH_C2[4] * 2.f * x, bSH_C2[4] * -2.f * y, 0.f)
-                    if (deg > 2) {
-                        SH_TERM(9, bSH_C3[0] * y * (3.f * xx - yy), bSH_C3[0] * 6.f * xy, bSH_C3[0] * 3.f * (xx - yy), 0.f)
-                        SH_TERM(10, bSH_C3[1] * xy * z, bSH_C3[1] * yz, bSH_C3[1] * xz, bSH_C3[1] * xy)
-                        SH_TERM(11, bSH_C3[2] * y * (4.f * zz - xx - yy), bSH_C3[2] * -2.f * xy,
-                                bSH_C3[2] * (-3.f * yy + 4.f * zz - xx), bSH_C3[2] * 8.f * yz)
-                        SH_TERM(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), bSH_C3[3] * -6.f * xz,
-                                bSH_C3[3] * -6.f * yz, bSH_C3[3] * 3.f * (2.f * zz - xx - yy))
-                        SH_TERM(13, bSH_C3[4] * x * (4.f * zz - xx - yy), bSH_C3[4] * (-3.f * xx + 4.f * zz - yy),
-                                bSH_C3[4] * -2.f * xy, bSH_C3[4] * 8.f * xz)
-                        SH_TERM(14, bSH_C3[5] * z * (xx - yy), bSH_C3[5] * 2.f * xz, bSH_C3[5] * -2.f * yz,
-                                bSH_C3[5] * (xx - yy))
-                        SH_TERM(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)
-                        if (deg > 3) {  // band 4 (oracle/ggr_oracle.c header): plain polynomial derivatives
-                            const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f, c21 = 21.f * zz - 3.f;
-                            const float xmy = xx - yy, x3y = xx - 3.f * yy, y3x = 3.f * xx - yy;
-                            SH_TERM(16, bSH_C4[0] * xy * xmy, bSH_C4[0] * y * y3x, bSH_C4[0] * x * x3y, 0.f)
-                            SH_TERM(17, bSH_C4[1] * yz * y3x, bSH_C4[1] * 6.f * xy * z, bSH_C4[1] * 3.f * z * xmy, bSH_C4[1] * y * y3x)
-                            SH_TERM(18, bSH_C4[2] * xy * a7, bSH_C4[2] * y * a7, bSH_C4[2] * x * a7, bSH_C4[2] * 14.f * xy * z)
-                            SH_TERM(19, bSH_C4[3] * yz * b7, 0.f, bSH_C4[3] * z * b7, bSH_C4[3] * y * c21)
-                            SH_TERM(20, bSH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f), 0.f, 0.f, bSH_C4[4] * z * (140.f * zz - 60.f))
-                            SH_TERM(21, bSH_C4[5] * xz * b7, bSH_C4[5] * z * b7, 0.f, bSH_C4[5] * x * c21)
-                            SH_TERM(22, bSH_C4[6] * xmy * a7, bSH_C4[6] * 2.f * x * a7, bSH_C4[6] * -2.f * y * a7, bSH_C4[6] * 14.f * z * xmy)
-                            SH_TERM(23, bSH_C4[7] * xz * x3y, bSH_C4[7] * 3.f * z * xmy, bSH_C4[7] * -6.f * xy * z, bSH_C4[7] * x * x3y)
-                            SH_TERM(24, bSH_C4[8] * (xx * x3y - yy * y3x), bSH_C4[8] * 4.f * x * x3y, bSH_C4[8] * -4.f * y * y3x, 0.f)
-                        }
-                    }
-                }
-            }
+            GGR_SH_TERMS(SH_TERM, deg, )
 #undef SH_TERM
             const float sum2 = vx * vx + vy * vy + vz * vz;
             const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
@@ -642,20 +758,35 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     const size_t rowf = (size_t)(3 * (deg + 1) * (deg + 1));
     const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
     const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
-    const size_t lds = (!has_colors_precomp && shs) ? (size_t)256 * row_stride * sizeof(float) : 0;
-#define GGR_LAUNCH_PBWD(POSE_, MULTI_)                                                                                   \
-    hipLaunchKernelGGL((preprocess_bwd_kernel<POSE_, MULTI_>), dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs,     \
+    const bool multi = vs.V > 1;
+    // one view at degree 3 / 4 with long rows: rows read by thirds, gradient rows written by row ranges (kernel header)
+    const bool use_sh = !has_colors_precomp && shs;
+    const int kc = (use_sh && !multi && (deg == 3 || deg == 4) && 3 * M > 64 &&
+                    (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0) ? (deg + 1) * (deg + 1) : 0;
+    const size_t lds = !use_sh ? 0 : kc ? sizeof(float) * (size_t)std::max(256 * (kc | 1), 88 * 3 * M)
+                                        : (size_t)256 * row_stride * sizeof(float);
+#define GGR_LAUNCH_PBWD(POSE_, MULTI_, KC_, CM_)                                                                            \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<POSE_, MULTI_, KC_, CM_>), dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs, \
                        has_colors_precomp, scales, rotations, scale_modifier, cov3D, vs, W, H, radii, clamped, grad2d,     \
                        has_dz, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales,   \
                        dL_drotations, dL_daux, pose_acc, inf, cov_is_input)
-    const bool multi = vs.V > 1;
+#define GGR_LAUNCH_PBWD_P(POSE_)                                                                                         \
+    do {                                                                                                                  \
+        if (multi) GGR_LAUNCH_PBWD(POSE_, true, 0, false);                                                                \
+        else if (kc == 16 && inf.sh_channel_major) GGR_LAUNCH_PBWD(POSE_, false, 16, true);                               \
+        else if (kc == 16) GGR_LAUNCH_PBWD(POSE_, false, 16, false);                                                      \
+        else if (kc == 25 && inf.sh_channel_major) GGR_LAUNCH_PBWD(POSE_, false, 25, true);                               \
+        else if (kc == 25) GGR_LAUNCH_PBWD(POSE_, false, 25, false);                                                      \
+        else GGR_LAUNCH_PBWD(POSE_, false, 0, false);                                                                     \
+    } while (0)
     if (pose_acc) {
-        if (multi) GGR_LAUNCH_PBWD(true, true); else GGR_LAUNCH_PBWD(true, false);
+        GGR_LAUNCH_PBWD_P(true);
         hipLaunchKernelGGL(pose_finish_kernel, dim3(35, vs.V), dim3(256), 0, s, pose_acc, blocks, dL_dview, dL_dproj,
                            dL_dcampos);
     } else {
-        if (multi) GGR_LAUNCH_PBWD(false, true); else GGR_LAUNCH_PBWD(false, false);
+        GGR_LAUNCH_PBWD_P(false);
     }
+#undef GGR_LAUNCH_PBWD_P
 #undef GGR_LAUNCH_PBWD
 }
 

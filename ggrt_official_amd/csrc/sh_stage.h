@@ -123,4 +123,35 @@ __device__ __forceinline__ void write_sh_rows_compact(float* __restrict__ dL_dsh
     }
 }
 
+// ---- one third of every row at a time (preprocess_fwd / preprocess_bwd, one view, degree 3 / 4) ----------------------
+// A whole 75-float row per Gaussian is 76.8 KB of LDS per 256-thread block = 2 blocks per CU; a third (KC floats: one
+// colour channel of channel-major rows, floats [J·KC, (J+1)·KC) of k-major ones) is 25.6 KB.  Per trip the block copies
+// RPI = ⌊256 / KC⌋ rows' thirds, thread t float t mod KC of row t / KC (KC = 25: 250 of the 256 threads), so addresses
+// and LDS slots advance by constants from trip to trip and only the loaded values are carried (tools/sh_stage_bench.hip).
+template <int KC>
+struct ShThirds {
+    static constexpr int STRIDE = KC | 1, RPI = 256 / KC, ITS = (256 + RPI - 1) / RPI;
+    const float* src;   // the block's first row
+    int g, k, last;     // this thread's row inside a trip, its float inside the third, the block's last row
+    uint32_t row;       // floats per row in global memory
+    int step;           // floats from one third to the next inside a row
+    __device__ __forceinline__ void init(const float* block_rows, int nG, int row_floats, int third_step) {
+        src = block_rows; row = (uint32_t)row_floats; step = third_step; last = nG - 1;
+        g = (int)threadIdx.x / KC; k = (int)threadIdx.x - g * KC;
+    }
+    // request third J (uniform base + 32-bit lane offset: one address register per load; clamped rows: every load
+    // is issued, rows past the block's last are not kept)
+    __device__ __forceinline__ void load(float (&v)[ITS], int J) const {
+        const float* s = src + J * step;
+#pragma unroll
+        for (int it = 0; it < ITS; it++) v[it] = s[(uint32_t)min(g + it * RPI, last) * row + (uint32_t)k];
+    }
+    // the loaded third into LDS, row r at r·STRIDE
+    __device__ __forceinline__ void store(float* lds, const float (&v)[ITS]) const {
+#pragma unroll
+        for (int it = 0; it < ITS; it++)
+            if (g < RPI && g + it * RPI < 256) lds[(g + it * RPI) * STRIDE + k] = v[it];
+    }
+};
+
 }  // namespace ggr
