@@ -55,7 +55,7 @@ def check_grads(grads, ref, keys, tag="", rtol=None):
     largest error are set aside.  Why rows are set aside: the same α/T threshold flips that move single pixels of the
     image (check_image) add or drop one (pixel, Gaussian) term of a gradient sum — a discrete event, not rounding.
     At C3 (1 M Gaussians, dL/dcolor ≈ 1.6e-7 per pixel) ONE such term in ONE Gaussian is 7.8e-5 of the whole means3D
-    gradient norm while every other row agrees to 9e-7 (scripts/grad_outliers.py)."""
+    gradient norm while every other row agrees to 9e-7 (tests/tools/grad_outliers.py)."""
     for k in keys:
         a = np.asarray(grads[k], np.float64)
         b = np.asarray(ref[k], np.float64)

@@ -3,7 +3,7 @@ usage: python scripts/grad_outliers.py C3"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 from ggrt_official_amd.synthetic import CONFIGS, make_scene, upstream_gradient
