@@ -1,6 +1,6 @@
 // sort_bench.hip — standalone micro-benchmark + self-check of ggr::radix_sort_pairs (dev tool).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ggrt_official_amd/csrc tools/sort_bench.hip \
-//        ggrt_official_amd/csrc/binning.hip -o /tmp/sort_bench
+//        ggrt_official_amd/csrc/binning.hip -o /tmp/sort_bench      (phase probes: add -DGGR_SORT_PROBE -fgpu-rdc)
 #include "ggr_common.h"
 #ifdef GGR_SORT_PROBE
 namespace ggr { extern __device__ unsigned long long ggr_probe[3][8][2048]; }
@@ -77,6 +77,13 @@ int main(int argc, char** argv) {
             }
             printf("  pass %d: scan+loads %.2f rank %.2f bar %.2f lookback %.2f bar %.2f scatter %.2f us (mean per tile); first start -> last end %.2f us\n",
                    p, ph[0] / nt, ph[1] / nt, ph[2] / nt, ph[3] / nt, ph[4] / nt, ph[5] / nt, (double)(t1 - t0) / 100.0);
+            // by tile index (groups of 32): when the tile started, when it began / ended its look-back (µs after the first start)
+            printf("    tiles  start  lookback-begin  lookback-end  (means)\n");
+            for (size_t g0 = 0; g0 < nt; g0 += 32) {
+                double a = 0, b = 0, c = 0; size_t m = std::min<size_t>(32, nt - g0);
+                for (size_t t = g0; t < g0 + m; t++) { a += (double)(pr[p][0][t] - t0); b += (double)(pr[p][3][t] - t0); c += (double)(pr[p][4][t] - t0); }
+                printf("    %4zu-%-4zu %6.2f %6.2f %6.2f\n", g0, g0 + m - 1, a / m / 100.0, b / m / 100.0, c / m / 100.0);
+            }
         }
     }
 #endif
