@@ -30,10 +30,11 @@ namespace ggr {
 // agent-scope atomic loads (bypass the reader's L1), so no fence is needed and no ordering between
 // different words is assumed.  Tiles take their index from an atomic ticket, so a tile only ever
 // waits for tiles whose workgroups are already running: no dispatch-order assumption.
-// A sort tile looks back GGR_LOOKBACK predecessors per trip (all loads in flight together) while all tiles of the
-// sort are resident at once (≤ 384 tiles: they run in lockstep and every tile starts far from the inclusive frontier),
-// one per trip beyond that (measured, tools/sort_bench.hip: 1 M keys 0.098 ms with 8 per trip / 0.101 with 1;
-// 4 M keys 0.335 / 0.313 ms — in the pipelined regime the extra polls only add traffic).
+// While all tiles of a sort are resident at once (≤ 384 tiles: they run in lockstep and every tile starts far from the
+// inclusive frontier) the look-back is a three-level tree of span-8 / span-64 aggregates — three dependent round trips
+// for every tile (see the kernel); beyond that a tile walks back one predecessor per trip until it meets an inclusive
+// prefix (measured, tools/sort_bench.hip: 4 M keys 0.313 ms with 1 per trip / 0.335 with 8 — in the pipelined regime
+// the extra polls only add traffic).
 
 #define GGR_FLAG_AGG 1u
 #define GGR_FLAG_INCL 2u
@@ -169,7 +170,9 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     __syncthreads();
     const uint32_t tile = tile_sh;
     PROBE(0);
-    uint32_t* status = hist + ggr_sort_status_base(nseg) + (((size_t)pass * nseg + seg) * ntiles << GGR_SORT_MAX_BITS);
+    const bool tree = ntiles * nseg <= GGR_SORT_TREE_MAX_TILES;  // (uniform; the host sized the status area by the same rule)
+    const size_t level_words = (size_t)ntiles << GGR_SORT_MAX_BITS;
+    uint32_t* status = hist + ggr_sort_status_base(nseg) + ((size_t)pass * nseg + seg) * level_words * (tree ? GGR_SORT_LEVELS : 1);
 
     const size_t base = (size_t)tile * GGR_SORT_TILE + (size_t)wave * (64 * GGR_SORT_ITEMS);
     uint32_t key[GGR_SORT_ITEMS], val[GGR_SORT_ITEMS], rank[GGR_SORT_ITEMS];
@@ -274,14 +277,66 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
 #pragma unroll
             for (int ww = 0; ww < NW; ww++) { cw[ww] = wcount[ww][d]; total += cw[ww]; }
             uint32_t* mine = status + (size_t)tile * bins + d;
+            uint32_t excl = 0;
+            if (tree) {
+                // ---- tree look-back (all tiles of the sort resident at once: they reach this point within ≈ 3 µs of each
+                // other, and walking back 8 predecessors per trip costs the last tiles ≈ 6 round trips —
+                // profiles/r02_sort_phase_probe.txt).  Three levels of status words, each (1 ≪ 30) | count:
+                //   L0[t] = tile t's count;  L1[t] = Σ L0 over tiles max(0, t−7) … t;  L2[t] = Σ L0 over max(0, t−63) … t.
+                // A tile sums L0 of its 7 predecessors, publishes L1, sums L1 of t−8, t−16, … t−56, publishes L2, sums L2 of
+                // t−64, t−128, …: three dependent round trips whatever the tile.  It only ever waits for lower tickets.
+                constexpr uint32_t FLAG = 1u << 30;
+                uint32_t* const l0 = status + d;
+                uint32_t* const l1 = l0 + level_words;
+                uint32_t* const l2 = l1 + level_words;
+                __hip_atomic_store(l0 + (size_t)tile * bins, FLAG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t spins = 0;
+                bool fault = false;
+                // sum of `cnt` (≤ 7) flagged words src[(t0 − step·j)·bins], j = 0 … cnt−1: all loads of a trip in flight together
+                auto gather7 = [&](const uint32_t* src, int t0, int step, int cnt) -> uint32_t {
+                    uint32_t got = 0, sum = 0;
+                    const uint32_t want = (1u << cnt) - 1u;
+                    while (got != want) {
+                        uint32_t v[7];
+#pragma unroll
+                        for (int j = 0; j < 7; j++)
+                            v[j] = (j < cnt && !((got >> j) & 1u))
+                                       ? __hip_atomic_load(src + (size_t)(t0 - step * j) * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                        uint32_t fresh = 0;
+#pragma unroll
+                        for (int j = 0; j < 7; j++)
+                            if (v[j] >> 30) { sum += v[j] & GGR_COUNT_MASK; fresh |= 1u << j; }
+                        got |= fresh;
+                        if (got != want && !fresh) {
+                            if (++spins > GGR_SPIN_LIMIT) { fault = true; break; }  // never hang
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    return sum;
+                };
+                if (tile > 0) {
+                    const int t = (int)tile;
+                    // (after a timeout the words are still published — the sort's result is void, GGR_E_HIP, but nobody
+                    //  else should wait for this tile — and no further level is awaited)
+                    uint32_t s = total + gather7(l0, t - 1, 1, min(7, t));                    // tiles max(0, t−7) … t
+                    __hip_atomic_store(l1 + (size_t)tile * bins, FLAG | (s & GGR_COUNT_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t >= 8 && !fault) s += gather7(l1, t - 8, 8, min(7, t / 8));          // … max(0, t−63) … t
+                    __hip_atomic_store(l2 + (size_t)tile * bins, FLAG | (s & GGR_COUNT_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t >= 64 && !fault) s += gather7(l2, t - 64, 64, min(7, t / 64));      // everything before
+                    excl = s - total;
+                    if (fault) atomicOr(&hist[GGR_HIST_FAULT], GGR_FAULT_SPIN);
+                } else {
+                    __hip_atomic_store(l1 + (size_t)tile * bins, FLAG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(l2 + (size_t)tile * bins, FLAG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
             __hip_atomic_store(mine, ((tile == 0 ? GGR_FLAG_INCL : GGR_FLAG_AGG) << 30) | total, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t excl = 0;
             if (tile > 0) {
                 int t = (int)tile - 1;
                 uint32_t spins = 0;
                 bool done = false;
-                const int depth = ntiles > 384u ? 1 : GGR_LOOKBACK;  // (uniform)
+                const int depth = 1;  // (pipelined regime: more polls per trip only add traffic — 4 M keys 0.313 ms with 1, 0.335 with 8)
                 while (!done) {
                     uint32_t v[GGR_LOOKBACK];
 #pragma unroll
@@ -308,6 +363,7 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
                 }
                 __hip_atomic_store(mine, (GGR_FLAG_INCL << 30) | ((excl + total) & GGR_COUNT_MASK), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+            }
             }
             // (only this thread touches digit d's column: no barrier between the reads above and these writes)
             dbase[d] += excl;

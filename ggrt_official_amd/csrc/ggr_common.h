@@ -73,9 +73,15 @@ static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) 
 #define GGR_HIST_TOTALS 256
 static inline size_t ggr_sort_segments(size_t views) { return views >= 1 && views <= GGR_SORT_MAX_SEGMENTS ? views : 1; }
 __host__ __device__ static inline size_t ggr_sort_status_base(size_t S) { return GGR_HIST_TOTALS + S * GGR_SORT_PASSES * GGR_SORT_MAX_BINS; }
+// look-back status words per (pass, segment): GGR_SORT_LEVELS arrays of [tiles][MAX_BINS] — level 0 the tiles' own digit
+// counts (and, in the walking look-back of big sorts, their inclusive prefixes), levels 1 / 2 the span-8 / span-64
+// aggregates of the tree look-back (binning.hip)
+#define GGR_SORT_LEVELS 3
+#define GGR_SORT_TREE_MAX_TILES 384   // up to here all tiles of a sort are resident at once and look back through the tree
 static inline size_t ggr_sort_zero_words(size_t n, size_t S = 1) {
     const size_t tps = ggr_sort_blocks((n ? n : 1) / S ? (n ? n : 1) / S : 1);
-    return ggr_sort_status_base(S) + (size_t)GGR_SORT_PASSES * S * tps * GGR_SORT_MAX_BINS;
+    const size_t levels = tps * S <= GGR_SORT_TREE_MAX_TILES ? GGR_SORT_LEVELS : 1;
+    return ggr_sort_status_base(S) + (size_t)GGR_SORT_PASSES * S * tps * GGR_SORT_MAX_BINS * levels;
 }
 static inline size_t ggr_sort_hist_words(size_t n, size_t S = 1) {
     return ggr_sort_zero_words(n, S) + ((n ? n : 1) + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS;
