@@ -105,3 +105,23 @@ def test_colors_precomp_with_aux_feature():
     assert rel_l2(ah.grad.cpu().numpy(), a64.grad.numpy()) < 1e-3
     assert rel_l2(ch.grad.cpu().numpy(), c64.grad.numpy()) < 1e-3
     assert rel_l2(mh.grad.cpu().numpy(), m64.grad.numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("P", [1, 5, 83, 84, 85, 168, 169, 255, 257])
+@pytest.mark.parametrize("cap", [4, 3])
+def test_long_sh_rows_with_few_gaussians(P, cap):
+    """25-coefficient SH rows (GGRt's) take the long-row paths of the preprocess kernels: rows through LDS a third at a
+    time, gradient rows written in three row ranges of 84 / 84 / 88 Gaussians.  Block sizes that leave ranges empty,
+    end inside a range or on its border; both `sh_max_degree` settings."""
+    sc = make_scene(P, 64, 48, sh_degree=4, profile="A", seed=P)
+    dL = upstream_gradient(64, 48, seed=3)
+    st = oracle_forward(sc, sh_cap=cap)
+    ref = c_oracle.backward(st, dL.numpy())
+    color, radii, _, grads = hip_forward_backward(sc, dL, sh_max_degree=cap)
+    assert np.array_equal(radii, st.radii)
+    check_image(color, st.color, tag="few_gaussians")
+    if st.num_rendered:
+        assert rel_l2(grads["shs"], ref["shs"]) < 2e-5 and rel_l2(grads["means3D"], ref["means3D"]) < 2e-5
+    K = (cap + 1) ** 2
+    assert np.all(grads["shs"][:, K:, :] == 0)
+    assert np.all(grads["shs"][st.radii <= 0] == 0)   # culled Gaussians: zero rows
