@@ -130,11 +130,13 @@ radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per 
 // GATHER (last pass of the depth sort only): every pair also carries an 8-byte payload looked up by its value,
 // gather_dst[final position] = gather_src[val] — the tile rect of the Gaussian, so that the tile-list kernels can
 // stream the rects in depth order without a separate gather launch; the pass also clears `zero_area`.
-template <bool GATHER>
+// ITEMS keys per thread (8 … 16): a sort of a little more than 256 tiles of 4096 keys (GGRt's LLFF eval frame:
+// 1 146 880 Gaussians = 281 tiles on 256 CUs) runs with larger tiles instead of doubling up on 25 CUs.
+template <bool GATHER, int ITEMS>
 __global__ void __launch_bounds__(GGR_SORT_THREADS)
 radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n /*keys per segment*/,
-                      int pass, uint32_t ntiles /*per segment*/, uint32_t nseg, uint32_t* __restrict__ hist,
+                      int pass, uint32_t ntiles /*per segment*/, uint32_t nseg, int tree_lookback, uint32_t* __restrict__ hist,
                       const uint2* __restrict__ gather_src,
                       uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
     constexpr int NW = GGR_SORT_THREADS / 64;
@@ -142,7 +144,7 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     __shared__ uint16_t wcount[NW][GGR_SORT_MAX_BINS];  // per-wave digit counters (a wave holds 512 keys), later per-wave prefixes
     __shared__ uint32_t dbase[GGR_SORT_MAX_BINS];       // global start of this tile's run of every digit
     __shared__ uint32_t texcl[GGR_SORT_MAX_BINS];       // start of that run inside the tile's locally sorted order
-    __shared__ uint2 sorted[GGR_SORT_TILE];             // the tile's (key, val) pairs — then its payloads — in output order
+    __shared__ uint2 sorted[(GGR_SORT_THREADS * ITEMS)];             // the tile's (key, val) pairs — then its payloads — in output order
     __shared__ uint32_t wsum[NW];
     __shared__ uint32_t tile_sh;
     const int tid = threadIdx.x;
@@ -170,27 +172,27 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     __syncthreads();
     const uint32_t tile = tile_sh;
     PROBE(0);
-    const bool tree = ntiles * nseg <= GGR_SORT_TREE_MAX_TILES;  // (uniform; the host sized the status area by the same rule)
+    const bool tree = tree_lookback != 0;  // (uniform; decided by the host together with the size of the status area)
     const size_t level_words = (size_t)ntiles << GGR_SORT_MAX_BITS;
     uint32_t* status = hist + ggr_sort_status_base(nseg) + ((size_t)pass * nseg + seg) * level_words * (tree ? GGR_SORT_LEVELS : 1);
 
-    const size_t base = (size_t)tile * GGR_SORT_TILE + (size_t)wave * (64 * GGR_SORT_ITEMS);
-    uint32_t key[GGR_SORT_ITEMS], val[GGR_SORT_ITEMS], rank[GGR_SORT_ITEMS];
+    const size_t base = (size_t)tile * (GGR_SORT_THREADS * ITEMS) + (size_t)wave * (64 * ITEMS);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-    for (int r = 0; r < GGR_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
         const bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
         val[r] = valid ? vals_in[idx] : 0u;
     }
-    uint2 pay[GATHER ? GGR_SORT_ITEMS : 1];
+    uint2 pay[GATHER ? ITEMS : 1];
     if (GATHER) {
         for (uint32_t wz = blockIdx.x * GGR_SORT_THREADS + tid; wz < zero_words; wz += gridDim.x * GGR_SORT_THREADS)
             zero_area[wz] = 0u;
         // issued now, consumed after the ranking and the look-back: the random 8-B reads hide behind them
 #pragma unroll
-        for (int r = 0; r < GGR_SORT_ITEMS; r++) {
+        for (int r = 0; r < ITEMS; r++) {
             const size_t idx = base + r * 64 + lane;
             pay[r] = idx < n ? gather_src[val[r]] : make_uint2(0u, 0u);
         }
@@ -230,9 +232,9 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     // (a) the match masks of all eight rounds first — ballots only, the rounds are independent of each other —
     // (b) then the chain through the wave's counters: two dependent LDS operations per round and nothing else
     // (with the ballots inside the chain a round cost ≈ 0.4 µs: tools/sort_bench.hip -DGGR_SORT_PROBE)
-    uint32_t before[GGR_SORT_ITEMS], cnt[GGR_SORT_ITEMS];
+    uint32_t before[ITEMS], cnt[ITEMS];
 #pragma unroll
-    for (int r = 0; r < GGR_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
         const uint32_t d = (key[r] >> shift) & mask;
         uint64_t m = __ballot(idx < n);
@@ -249,7 +251,7 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
         cnt[r] = (uint32_t)__popcll(m);
     }
 #pragma unroll
-    for (int r = 0; r < GGR_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
         const bool valid = idx < n;
         const uint32_t d = (key[r] >> shift) & mask;
@@ -406,19 +408,19 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     // Local reorder: the tile's pairs go through LDS into (digit, wave, round, lane) order — the order of the output —
     // and thread i then stores elements i, i + 512, …: consecutive lanes write consecutive addresses inside a digit's
     // run instead of 64 unrelated 4-byte stores per instruction.
-    uint32_t lpos[GGR_SORT_ITEMS];
+    uint32_t lpos[ITEMS];
 #pragma unroll
-    for (int r = 0; r < GGR_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
         const uint32_t d = (key[r] >> shift) & mask;
         lpos[r] = texcl[d] + wcount[wave][d] + rank[r];
         if (idx < n) sorted[lpos[r]] = make_uint2(key[r], val[r]);
     }
     __syncthreads();
-    const uint32_t tile_n = (uint32_t)min((size_t)GGR_SORT_TILE, n - (size_t)tile * GGR_SORT_TILE);
-    uint32_t gpos[GGR_SORT_ITEMS];
+    const uint32_t tile_n = (uint32_t)min((size_t)(GGR_SORT_THREADS * ITEMS), n - (size_t)tile * (GGR_SORT_THREADS * ITEMS));
+    uint32_t gpos[ITEMS];
 #pragma unroll
-    for (int k = 0; k < GGR_SORT_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         const uint32_t j = tid + k * GGR_SORT_THREADS;
         gpos[k] = 0;
         if (j < tile_n) {
@@ -432,13 +434,13 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     if (GATHER) {
         __syncthreads();  // every pair has been read: the same LDS now carries the payloads
 #pragma unroll
-        for (int r = 0; r < GGR_SORT_ITEMS; r++) {
+        for (int r = 0; r < ITEMS; r++) {
             const size_t idx = base + r * 64 + lane;
             if (idx < n) sorted[lpos[r]] = pay[r];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < GGR_SORT_ITEMS; k++) {
+        for (int k = 0; k < ITEMS; k++) {
             const uint32_t j = tid + k * GGR_SORT_THREADS;
             if (j < tile_n) gather_dst[gpos[k]] = sorted[j];
         }
@@ -456,7 +458,13 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
     if (n > 0) {
         const uint32_t S = segments ? segments : 1;
         const size_t nseg = n / S;  // (n is a multiple of S)
-        const uint32_t ntiles = (uint32_t)ggr_sort_blocks(nseg);
+        // tile size: 4096 keys, or 5120 … 8192 if that brings the sort down to one tile per CU (≤ 2.1 M keys)
+        int items = 8;
+        for (int it = 8; it <= 16 && S * ggr_sort_blocks(nseg) > 256; it += 2)
+            if (S * ((nseg + (size_t)it * GGR_SORT_THREADS - 1) / ((size_t)it * GGR_SORT_THREADS)) <= 256) { items = it; break; }
+        const uint32_t ntiles = (uint32_t)((nseg + (size_t)items * GGR_SORT_THREADS - 1) / ((size_t)items * GGR_SORT_THREADS));
+        // (the status area was sized — and cleared — for tiles of 4096 keys: ggr_sort_zero_words; same rule here)
+        const int tree = ggr_sort_blocks(nseg) * S <= GGR_SORT_TREE_MAX_TILES ? 1 : 0;
         const uint32_t nmax = block_max_ready ? block_max_ready : (uint32_t)((n + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS);
         uint32_t* block_max = hist + ggr_sort_zero_words(n, S);
         if (!hist_zeroed)  // (ggr_forward: preprocess_fwd clears the area — one launch less)
@@ -467,16 +475,27 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
             (unsigned)((nseg + GGR_HIST_THREADS * GGR_HIST_ITEMS - 1) / (GGR_HIST_THREADS * GGR_HIST_ITEMS));
         hipLaunchKernelGGL(radix_global_hist_kernel, dim3(bps * S), dim3(GGR_HIST_THREADS), 0, s, kin, nseg, bps, hist,
                            block_max, nmax);
+#define GGR_PASS(GATHER_, ITEMS_, SRC_, DST_, ZA_, ZW_)                                                                    \
+    hipLaunchKernelGGL((radix_onesweep_kernel<GATHER_, ITEMS_>), dim3(ntiles * S), dim3(GGR_SORT_THREADS), 0, s, kin, vin,  \
+                       kout, vout, nseg, p, ntiles, S, tree, hist, SRC_, DST_, ZA_, ZW_)
         for (int p = 0; p < GGR_SORT_PASSES; p++) {
-            if (p == GGR_SORT_PASSES - 1 && gather_src)
-                hipLaunchKernelGGL(radix_onesweep_kernel<true>, dim3(ntiles * S), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
-                                   kout, vout, nseg, p, ntiles, S, hist, gather_src, gather_dst, zero_area, zero_words);
-            else
-                hipLaunchKernelGGL(radix_onesweep_kernel<false>, dim3(ntiles * S), dim3(GGR_SORT_THREADS), 0, s, kin, vin,
-                                   kout, vout, nseg, p, ntiles, S, hist, nullptr, nullptr, nullptr, 0u);
+            if (p == GGR_SORT_PASSES - 1 && gather_src) {
+                if (items == 8) GGR_PASS(true, 8, gather_src, gather_dst, zero_area, zero_words);
+                else if (items == 10) GGR_PASS(true, 10, gather_src, gather_dst, zero_area, zero_words);
+                else if (items == 12) GGR_PASS(true, 12, gather_src, gather_dst, zero_area, zero_words);
+                else if (items == 14) GGR_PASS(true, 14, gather_src, gather_dst, zero_area, zero_words);
+                else GGR_PASS(true, 16, gather_src, gather_dst, zero_area, zero_words);
+            } else {
+                if (items == 8) GGR_PASS(false, 8, nullptr, nullptr, nullptr, 0u);
+                else if (items == 10) GGR_PASS(false, 10, nullptr, nullptr, nullptr, 0u);
+                else if (items == 12) GGR_PASS(false, 12, nullptr, nullptr, nullptr, 0u);
+                else if (items == 14) GGR_PASS(false, 14, nullptr, nullptr, nullptr, 0u);
+                else GGR_PASS(false, 16, nullptr, nullptr, nullptr, 0u);
+            }
             uint32_t* t = kin; kin = kout; kout = t;
             t = vin; vin = vout; vout = t;
         }
+#undef GGR_PASS
     }
     *keys_out = kin;
     *vals_out = vin;
