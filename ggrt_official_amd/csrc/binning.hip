@@ -72,8 +72,12 @@ radix_block_max_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __
 
 // digit totals of all three passes in one read of the keys.  Every block first reduces the producer blocks' key
 // maxima (n/256 words, one round trip, in flight together with its keys) to the digit width.
+#ifndef GGR_HIST_THREADS
 #define GGR_HIST_THREADS 1024
+#endif
+#ifndef GGR_HIST_ITEMS
 #define GGR_HIST_ITEMS 8
+#endif
 __global__ void __launch_bounds__(GGR_HIST_THREADS)
 radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per segment*/, uint32_t blocks_per_seg,
                          uint32_t* __restrict__ hist, const uint32_t* __restrict__ block_max, uint32_t nmax) {
@@ -101,7 +105,7 @@ radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per 
     m = wave_max_u32(m);
     if ((tid & 63) == 0) wm[tid >> 6] = m;
     __syncthreads();
-    m = wave_max_u32(wm[tid & 15]);  // (lanes 0..15 hold the 16 wave maxima, the others repeat them)
+    m = wave_max_u32(wm[tid & (GGR_HIST_THREADS / 64 - 1)]);  // (the first lanes hold the wave maxima, the others repeat them)
     const uint32_t bits = m ? 32u - (uint32_t)__builtin_clz(m) : 1u;
     uint32_t w = (bits + 2u) / 3u;
     if (w > GGR_SORT_MAX_BITS) {
