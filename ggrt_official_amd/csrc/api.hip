@@ -82,6 +82,7 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
 // per host thread and device: one pinned word + one event for the num_rendered read-back of the exact mode (a
 // thread has at most one forward between its launch and its sync, so the slot is never shared; never freed — a
 // thread_local destructor could run after the HIP runtime is gone)
+#define GGR_READBACK_ARMED 0xFFFFFFFEu  // (counts stop at 0x7FFFFFFF, 0xFFFFFFFF reports a sort fault)
 struct ReadbackSlot {
     uint32_t* host = nullptr;
     hipEvent_t ev = nullptr;
@@ -215,6 +216,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // buffer allocated and the scatter queued by the time the GPU gets there (a device→host memcpy into pageable
     // memory + stream sync left the GPU idle for that long)
     ReadbackSlot* rb = (!sync_free && P > 0) ? readback_slot() : nullptr;
+    if (rb) *(volatile uint32_t*)rb->host = GGR_READBACK_ARMED;
     if (P > 0) {
         ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, capacity, s,
                                     /*rects_gathered=*/true, rb ? rb->host : nullptr, rb ? rb->ev : nullptr,
@@ -233,15 +235,24 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     uint32_t* point_list = nullptr;
     if (!sync_free) {
         if (rb) {
-            HIP_TRY(hipEventSynchronize(rb->ev));  // the single host sync of forward
-            num_rendered = *(volatile uint32_t*)rb->host;
+            // the single host sync of forward.  N is written by the FIRST block of the last tile-list kernel: the host
+            // watches the pinned word (armed with a sentinel no count can take) instead of waiting for that kernel's
+            // end, and falls back to the event behind it if the word has not changed after a while
+            volatile uint32_t* hw = (volatile uint32_t*)rb->host;
+            uint32_t v = *hw;
+            for (uint32_t spins = 0; v == GGR_READBACK_ARMED; v = *hw) {
+                if ((++spins & 0x3FFu) == 0 && hipEventQuery(rb->ev) == hipSuccess) { v = *hw; break; }
+                __builtin_ia32_pause();
+            }
+            if (v == GGR_READBACK_ARMED) { HIP_TRY(hipEventSynchronize(rb->ev)); v = *hw; }
+            num_rendered = v;
         } else {
             uint32_t two[2] = {0u, 0u};
             HIP_TRY(hipMemcpyAsync(two, g.counters, 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             num_rendered = (two[1] & 2u) ? 0xFFFFFFFFu : two[0];
         }
-        if (num_rendered == 0xFFFFFFFFu)  // raised by the scan kernel, see bin_tile_scan_kernel
+        if (num_rendered == 0xFFFFFFFFu)  // raised by the tile-list kernel that writes N (bin_group_prefix_kernel)
             return fail(GGR_E_HIP, "depth sort fault: a look-back spin hit its bound (GPU preempted or halted?) or a view depth >= 6.8e37; frame not rendered");
         if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
         out->num_rendered = (int64_t)num_rendered;

@@ -12,8 +12,9 @@
 //
 //   K1 count    chunk c = 1024 consecutive positions of `order`; per (chunk, tile band) one workgroup
 //               histograms the chunk's rects into LDS (ds_add, order irrelevant) → table[c][t]
-//   K2a/b/c     exclusive prefix of table over chunks per tile (grouped: G groups of chunks so that the
-//               scan has T·G-way parallelism), exclusive scan over tiles → tile_start, ranges, N;
+//   K2a, K2b/c  exclusive prefix of table over chunks per tile (grouped: G groups of chunks so that the
+//               scan has T·G-way parallelism), exclusive scan over tiles → ranges, N (formed by every block of
+//               K2b/c for its own 256 tiles — no launch of its own);
 //               table[c][t] becomes the ABSOLUTE list position of chunk c's first entry for tile t
 //   K3 scatter  per (chunk, tile band) ONE wave walks its chunk's (Gaussian, tile) pairs in order, 64 consecutive
 //               pairs ("slots") per step; the band's cursors live in LDS (initialised from table[c][·]).  Lanes
@@ -23,7 +24,7 @@
 //               point_list[pos].  One XCD owns a band (its list lines are then merged in ONE L2).
 //
 // HBM traffic: table (chunks·T·4 B, 32 MB at C3) written once, read/written once, read once; rects read
-// twice per band; N·4 B of ids written.  ≈ 0.25 GB instead of ≈ 0.9 GB for emit + 2 radix passes, and 5
+// twice per band; N·4 B of ids written.  ≈ 0.25 GB instead of ≈ 0.9 GB for emit + 2 radix passes, and 4
 // launches instead of 12.  A tile band is ≤ 4096 tiles (16 KB of LDS) so any image size works.
 #include "ggr_common.h"
 #include <stdlib.h>
@@ -156,78 +157,60 @@ bin_group_sum_kernel(const uint32_t* __restrict__ table, uint32_t T, uint32_t nc
     if (s) atomicAdd(&total[t], s);  // G atomics per tile at most
 }
 
-// ---- K2b: ONE block: exclusive scan of the per-tile totals → tile_start, ranges, N --------------------
-__global__ void __launch_bounds__(1024)
-bin_tile_scan_kernel(uint32_t T, uint32_t* __restrict__ tile_start /*in: totals, out: starts*/,
-                     uint2* __restrict__ ranges, uint32_t* __restrict__ total_out /*[0] = N, [1] = overflow*/,
-                     uint32_t capacity /*entries the caller's list buffer holds (sync-free mode); ~0u = exact*/,
-                     uint32_t* __restrict__ host_total /*pinned host word that also receives N, or NULL*/,
-                     const uint32_t* __restrict__ sort_fault /*the depth sort's look-back timeout word, or NULL*/) {
-    // each thread owns E CONSECUTIVE tiles (E = ⌈T/1024⌉ rounded up to a multiple of 8, ≤ 64 per slab): local
-    // sums, ONE block-wide scan of the 1024 partials, then the running starts — instead of T/1024 sequential
-    // 1024-wide scans (16 µs → a few µs at 8160 tiles)
-    __shared__ uint32_t sh[1024];
-    __shared__ uint32_t carry;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    constexpr uint32_t E = 8;
-    for (uint32_t t0 = 0; t0 < T; t0 += 1024 * E) {
-        const uint32_t first = t0 + tid * E;
-        uint32_t cnt[E], local = 0;
+// ---- K2b/c: table[c][t] ← absolute position of chunk c's first entry in tile t's list; tile ranges; N -----------------
+// The exclusive scan of the per-tile totals used to be a launch of its own (ONE block, ≈ 11 µs for ≈ 3 µs of work, and
+// ≈ 8 µs of that is what any dependent launch costs).  Every block here now forms the start of ITS 256 tiles itself:
+// Σ totals of all tiles before them (≤ 32 KB from L2, 32 loads per thread in flight) + a block scan of its own.  The
+// blocks of group 0 write the tile ranges; block (0, 0) — dispatched first — is the one that owns the LAST tiles, so N
+// reaches the host's pinned word while the rest of the launch is still rewriting the table.
+__global__ void __launch_bounds__(256)
+bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchunks, uint32_t chunks_per_group,
+                        const uint32_t* __restrict__ gsum, const uint32_t* __restrict__ total /*[T] per-tile totals (K2a)*/,
+                        uint2* __restrict__ ranges, uint32_t* __restrict__ total_out /*[0] = N, [1] = overflow | fault*/,
+                        uint32_t capacity /*entries the caller's list buffer holds (sync-free mode); ~0u = exact*/,
+                        uint32_t* __restrict__ host_total /*pinned host word that also receives N, or NULL*/,
+                        const uint32_t* __restrict__ sort_fault /*the depth sort's look-back timeout word, or NULL*/) {
+    __shared__ uint32_t w_part[4], w_own[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t bx = gridDim.x - 1u - blockIdx.x, g = blockIdx.y;
+    const uint32_t first = bx * 256u, t = first + tid;
+    // totals of all tiles in front of this block's (independent loads, 8 in flight per trip)
+    uint32_t part = 0;
+    for (uint32_t i0 = 0; i0 < first; i0 += 8 * 256) {
+        uint32_t v[8];
 #pragma unroll
-        for (uint32_t e = 0; e < E; e++) {
-            cnt[e] = first + e < T ? tile_start[first + e] : 0u;
-            local += cnt[e];
-        }
-        // block scan = DPP scan inside each wave + a scan of the 16 wave totals (2 barriers instead of 20)
-        const uint32_t in_wave = wave_scan_add(local);
-        if ((tid & 63u) == 63u) sh[tid >> 6] = in_wave;
-        __syncthreads();
-        if (tid < 64) {
-            const uint32_t wt = tid < 16 ? sh[tid] : 0u;
-            const uint32_t ws = wave_scan_add(wt);
-            if (tid < 16) sh[16 + tid] = ws - wt;  // exclusive prefix of the wave totals
-        }
-        __syncthreads();
-        const uint32_t incl = in_wave + sh[16 + (tid >> 6)], c = carry;
-        uint32_t start = c + incl - local;
+        for (uint32_t u = 0; u < 8; u++) { const uint32_t i = i0 + u * 256 + tid; v[u] = i < first ? total[i] : 0u; }
 #pragma unroll
-        for (uint32_t e = 0; e < E; e++) {
-            if (first + e < T) {
-                tile_start[first + e] = start;
-                // sync-free mode: a list that does not fit the caller's buffer is cut at its end (the overflow
-                // flag tells the caller that this frame is incomplete) — nothing ever reads or writes beyond it
-                const uint32_t rs = min(start, capacity), re = min(start + cnt[e], capacity);
-                ranges[first + e] = re > rs ? make_uint2(rs, re) : make_uint2(0u, 0u);
-            }
-            start += cnt[e];
-        }
-        __syncthreads();
-        if (tid == 1023) carry = c + incl;
-        __syncthreads();
+        for (uint32_t u = 0; u < 8; u++) part += v[u];
     }
-    if (tid == 0) {
+    const uint32_t own = t < T ? total[t] : 0u;
+    const uint32_t incl = wave_scan_add(own), psum = wave_scan_add(part);
+    if (lane == 63u) { w_own[wave] = incl; w_part[wave] = psum; }
+    __syncthreads();
+    uint32_t base = w_part[0] + w_part[1] + w_part[2] + w_part[3];
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t ww = 0; ww < 4; ww++) before += ww < wave ? w_own[ww] : 0u;
+    const uint32_t start = base + before + incl - own;  // tile t's list starts here
+    if (g == 0 && t < T) {
+        // sync-free mode: a list that does not fit the caller's buffer is cut at its end (the overflow
+        // flag tells the caller that this frame is incomplete) — nothing ever reads or writes beyond it
+        const uint32_t rs = min(start, capacity), re = min(start + own, capacity);
+        ranges[t] = re > rs ? make_uint2(rs, re) : make_uint2(0u, 0u);
+    }
+    if (g == 0 && bx == gridDim.x - 1u && tid == 0) {
+        const uint32_t n_all = base + w_own[0] + w_own[1] + w_own[2] + w_own[3];
         // a look-back spin of the depth sort that ran into its bound leaves a mis-sorted order behind: the frame
         // must not be used.  Status word: bit 0 = list overflow, bit 1 = sort fault; the exact mode's host word
         // carries ~0u instead of N (ggr_forward fails with GGR_E_HIP on it).
         const bool fault = sort_fault && *sort_fault != 0u;
-        total_out[0] = carry;
-        total_out[1] = (carry > capacity ? 1u : 0u) | (fault ? 2u : 0u);
-        if (host_total) {
-            __hip_atomic_store(host_total, fault ? 0xFFFFFFFFu : carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        total_out[0] = n_all;
+        total_out[1] = (n_all > capacity ? 1u : 0u) | (fault ? 2u : 0u);
+        if (host_total) __hip_atomic_store(host_total, fault ? 0xFFFFFFFFu : n_all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-}
-
-// ---- K2c: table[c][t] ← absolute position of chunk c's first entry in tile t's list ------------------
-__global__ void __launch_bounds__(256)
-bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchunks, uint32_t chunks_per_group,
-                        const uint32_t* __restrict__ gsum, const uint32_t* __restrict__ tile_start) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     if (t >= T) return;
     const uint32_t c0 = g * chunks_per_group, c1 = min(nchunks, c0 + chunks_per_group);
-    uint32_t run = tile_start[t];
+    uint32_t run = start;
 #pragma unroll 8
     for (uint32_t gg = 0; gg < g; gg++) run += gsum[(size_t)gg * T + t];  // exclusive prefix over groups
     // counts first (independent loads, 8 in flight), then the running positions
@@ -484,11 +467,9 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     const unsigned tb = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
                        pl.chunks_per_group, w.gsum, w.tile_start);
-    hipLaunchKernelGGL(bin_tile_scan_kernel, dim3(1), dim3(1024), 0, s, (uint32_t)T, w.tile_start, ranges, total_out,
-                       capacity, host_total, sort_fault);
-    if (after_scan) (void)hipEventRecord(after_scan, s);
     hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
-                       pl.chunks_per_group, w.gsum, w.tile_start);
+                       pl.chunks_per_group, w.gsum, w.tile_start, ranges, total_out, capacity, host_total, sort_fault);
+    if (after_scan) (void)hipEventRecord(after_scan, s);  // (N is in the host word long before: written by the launch's first block)
 }
 
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
