@@ -10,10 +10,13 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 namespace {
 
 thread_local char g_err[512] = "";
+const char kSpinFault[] = "depth sort: a look-back spin hit its bound (GPU preempted or halted?); frame not rendered";
+const char kRangeFault[] = "depth sort: a sort key beyond 30 bits reached the sort (keys must come from preprocess_fwd); frame not rendered";
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -82,7 +85,7 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
 // per host thread and device: one pinned word + one event for the num_rendered read-back of the exact mode (a
 // thread has at most one forward between its launch and its sync, so the slot is never shared; never freed — a
 // thread_local destructor could run after the HIP runtime is gone)
-#define GGR_READBACK_ARMED 0xFFFFFFFEu  // (counts stop at 0x7FFFFFFF, 0xFFFFFFFF reports a sort fault)
+#define GGR_READBACK_ARMED GGR_HOST_ARMED  // (counts stop at 0x7FFFFFFF; GGR_HOST_FAULT_* report a sort fault)
 struct ReadbackSlot {
     uint32_t* host = nullptr;
     hipEvent_t ev = nullptr;
@@ -94,12 +97,45 @@ ReadbackSlot* readback_slot() {
     ReadbackSlot& r = slots[dev];
     if (!r.host) {
         void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return nullptr;
+        // coherent (fine-grained) on purpose: the kernel's system-scope store must become visible to the spinning
+        // host while the kernel is still running; a non-coherent mapping would only show it at the kernel's end
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); return nullptr; }
         r.host = (uint32_t*)p;
     }
     return &r;
 }
+
+// The exact mode's wait for num_rendered: the host watches the pinned word (armed with a sentinel no count can take)
+// and, every 1024 polls, asks `query` (hipEventQuery of the event behind the kernel that writes the word) whether the
+// kernel has ended.  Leaves on: the word changed; the query says "done" (the word is then re-read once — a
+// non-coherent mapping shows it only now); the query returns ANYTHING other than hipErrorNotReady (stream in error,
+// device lost: the word will never change) → GGR_E_HIP; or `timeout_s` seconds without either (a hung GPU) →
+// GGR_E_HIP.  The device-side spins are bounded the same way — nothing in a forward can wait forever.
+typedef hipError_t (*ReadbackQueryFn)(void*);
+#define GGR_READBACK_TIMEOUT_S 30.0
+int wait_readback(volatile uint32_t* hw, ReadbackQueryFn query, void* ctx, double timeout_s, uint32_t* value) {
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    uint32_t v = *hw;
+    for (uint32_t spins = 0; v == GGR_READBACK_ARMED; v = *hw) {
+        if ((++spins & 0x3FFu) == 0) {
+            const hipError_t q = query(ctx);
+            if (q == hipSuccess) { v = *hw; break; }
+            if (q != hipErrorNotReady)
+                return fail(GGR_E_HIP, "num_rendered read-back: the stream is in error (%s); frame not rendered", hipGetErrorString(q));
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s)
+                return fail(GGR_E_HIP, "num_rendered read-back: no answer from the GPU within %.0f s; frame not rendered", timeout_s);
+        }
+        __builtin_ia32_pause();
+    }
+    if (v == GGR_READBACK_ARMED) return fail(GGR_E_HIP, "num_rendered read-back: the tile-list kernel ended without writing the count");
+    *value = v;
+    return GGR_OK;
+}
+hipError_t query_event(void* ev) { return hipEventQuery((hipEvent_t)ev); }
 
 InputForm input_form(const GgrSettings* st, const GgrForwardIn* in) {
     InputForm f;
@@ -108,7 +144,7 @@ InputForm input_form(const GgrSettings* st, const GgrForwardIn* in) {
     f.aux_affine = (in->aux_affine && !in->aux_precomp) ? 1 : 0;
     f.aux_a = in->aux_a;
     f.aux_b = in->aux_b;
-    f.sh_cap = st->sh_max_degree == 3 ? 3 : 4;
+    f.sh_cap = st->sh_max_degree == 4 ? 4 : 3;  // default 3: INTEGRATION.md §7
     return f;
 }
 
@@ -229,31 +265,26 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     if (dbg && sync_free && P > 0) {  // debug mode may sync: check the sort's fault bit right here
         uint32_t two[2] = {0u, 0u};
         HIP_TRY(hipMemcpy(two, g.counters, 8, hipMemcpyDeviceToHost));
-        if (two[1] & 2u) return fail(GGR_E_HIP, "depth sort: a look-back spin hit its bound; frame not rendered");
+        if (two[1] & 2u) return fail(GGR_E_HIP, "%s", kSpinFault);
+        if (two[1] & 4u) return fail(GGR_E_LIMIT, "%s", kRangeFault);
     }
     uint32_t num_rendered = 0;
     uint32_t* point_list = nullptr;
     if (!sync_free) {
         if (rb) {
             // the single host sync of forward.  N is written by the FIRST block of the last tile-list kernel: the host
-            // watches the pinned word (armed with a sentinel no count can take) instead of waiting for that kernel's
-            // end, and falls back to the event behind it if the word has not changed after a while
-            volatile uint32_t* hw = (volatile uint32_t*)rb->host;
-            uint32_t v = *hw;
-            for (uint32_t spins = 0; v == GGR_READBACK_ARMED; v = *hw) {
-                if ((++spins & 0x3FFu) == 0 && hipEventQuery(rb->ev) == hipSuccess) { v = *hw; break; }
-                __builtin_ia32_pause();
-            }
-            if (v == GGR_READBACK_ARMED) { HIP_TRY(hipEventSynchronize(rb->ev)); v = *hw; }
-            num_rendered = v;
+            // watches the pinned word instead of waiting for that kernel's end (wait_readback above)
+            const int rc = wait_readback((volatile uint32_t*)rb->host, query_event, (void*)rb->ev, GGR_READBACK_TIMEOUT_S, &num_rendered);
+            if (rc != GGR_OK) return rc;
         } else {
             uint32_t two[2] = {0u, 0u};
             HIP_TRY(hipMemcpyAsync(two, g.counters, 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            num_rendered = (two[1] & 2u) ? 0xFFFFFFFFu : two[0];
+            num_rendered = (two[1] & 2u) ? GGR_HOST_FAULT_SPIN : (two[1] & 4u) ? GGR_HOST_FAULT_RANGE : two[0];
         }
-        if (num_rendered == 0xFFFFFFFFu)  // raised by the tile-list kernel that writes N (bin_group_prefix_kernel)
-            return fail(GGR_E_HIP, "depth sort fault: a look-back spin hit its bound (GPU preempted or halted?) or a view depth >= 6.8e37; frame not rendered");
+        // raised by the tile-list kernel that writes N (bin_group_prefix_kernel)
+        if (num_rendered == GGR_HOST_FAULT_SPIN) return fail(GGR_E_HIP, "%s", kSpinFault);
+        if (num_rendered == GGR_HOST_FAULT_RANGE) return fail(GGR_E_LIMIT, "%s", kRangeFault);
         if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
         out->num_rendered = (int64_t)num_rendered;
         tm.mark();
@@ -419,9 +450,31 @@ int ggr_forward_status(const void* geom_buffer, int32_t P, int64_t* num_rendered
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (num_rendered) *num_rendered = (int64_t)host[0];
     if (overflow) *overflow = (int32_t)(host[1] & 1u);
-    if (host[1] & 2u)
-        return fail(GGR_E_HIP, "depth sort: a look-back spin hit its bound (GPU preempted or halted?); the frame is invalid");
+    if (host[1] & 2u) return fail(GGR_E_HIP, "%s", kSpinFault);
+    if (host[1] & 4u) return fail(GGR_E_LIMIT, "%s", kRangeFault);
     return GGR_OK;
+}
+
+namespace {
+struct FakeQuery { int scenario; int calls; volatile uint32_t* word; };
+hipError_t fake_query(void* p) {
+    FakeQuery* q = (FakeQuery*)p;
+    q->calls++;
+    switch (q->scenario) {
+        case 0: if (q->calls == 3) *q->word = 1234u; return hipErrorNotReady;
+        case 1: return q->calls < 2 ? hipErrorNotReady : hipErrorLaunchFailure;
+        case 2: return hipErrorNotReady;
+        default: return hipSuccess;
+    }
+}
+}  // namespace
+
+int ggr_debug_readback_wait(int32_t scenario, double timeout_s, uint32_t* value) {
+    g_err[0] = 0;
+    if (scenario < 0 || scenario > 3 || !value) return fail(GGR_E_INVALID, "bad arguments");
+    volatile uint32_t word = GGR_READBACK_ARMED;
+    FakeQuery q{scenario, 0, &word};
+    return wait_readback(&word, fake_query, &q, timeout_s, value);
 }
 
 int ggr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present,

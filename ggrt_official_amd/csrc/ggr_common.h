@@ -45,6 +45,7 @@
 // with depths in [0.2, 13 000) has 27-bit keys, and the sort takes THREE passes of ⌈bits/3⌉-bit digits (≤ 10 bits, i.e.
 // every depth below 6.8e37) instead of four 8-bit ones.
 #define GGR_KEY_BASE 0x3E4CCCCDu  // __float_as_uint(0.2f)
+#define GGR_KEY_MAX 0x3FFFFFFFu   // preprocess clamps here (3 × 10 bits)
 #define GGR_SORT_PASSES 3
 #define GGR_SORT_MAX_BITS 10      // per digit
 #define GGR_SORT_MAX_BINS (1 << GGR_SORT_MAX_BITS)
@@ -69,6 +70,10 @@ static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) 
 #define GGR_SORT_MAX_SEGMENTS 64
 #define GGR_HIST_TICKETS 0
 #define GGR_HIST_FAULT 192
+// values of the exact mode's pinned num_rendered word that are not counts (counts stop at 0x7FFFFFFF)
+#define GGR_HOST_FAULT_SPIN 0xFFFFFFFFu    // a look-back spin of the depth sort hit its bound
+#define GGR_HOST_ARMED 0xFFFFFFFEu         // not written yet
+#define GGR_HOST_FAULT_RANGE 0xFFFFFFFDu   // a sort key beyond 30 bits (cannot happen behind preprocess_fwd, which clamps)
 #define GGR_HIST_PARAMS 200   // [0] = bits per digit
 #define GGR_HIST_TOTALS 256
 static inline size_t ggr_sort_segments(size_t views) { return views >= 1 && views <= GGR_SORT_MAX_SEGMENTS ? views : 1; }
@@ -210,7 +215,7 @@ struct InputForm {
                                // transpose copy of :77 and its backward
     int aux_affine;            // 1: blended feature = max(aux_a + aux_b·z/s, 0) instead of z — GGRt's depth pass
     float aux_a, aux_b;        //    (:240-269: depth as a degree-0 SH coefficient) without a per-Gaussian tensor
-    int sh_cap;                // highest SH band evaluated: 4 (GGRt's fork as recollected, default) or 3 (graphdeco)
+    int sh_cap;                // highest SH band evaluated: 3 (graphdeco / w-depth family, default) or 4
 };
 
 // The cameras of one launch set: V views of the SAME P Gaussians (V = 1: the reference's call).  Per-Gaussian state of

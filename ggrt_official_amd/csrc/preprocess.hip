@@ -259,7 +259,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 if (area != 0) {
                     vis = true;
                     rad_out = rad;
-                    key_out = __float_as_uint(t2) - GGR_KEY_BASE;  // > 0: t2 > 0.2f
+                    // > 0: t2 > 0.2f.  The three-pass sort takes 30-bit keys: depths ≥ 6.8e37 (incl. +inf) share the last key
+                    // and keep ascending id among themselves instead of voiding the frame (ggr_raster.h "depth order")
+                    key_out = min(__float_as_uint(t2) - GGR_KEY_BASE, GGR_KEY_MAX);
                     tiles_out = (uint32_t)area;
                     // tile rows of view v sit below those of views 0 … v-1 in the virtual stacked image
                     const uint32_t yo = (uint32_t)(v * gy);

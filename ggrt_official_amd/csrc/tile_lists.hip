@@ -201,12 +201,15 @@ bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchun
     if (g == 0 && bx == gridDim.x - 1u && tid == 0) {
         const uint32_t n_all = base + w_own[0] + w_own[1] + w_own[2] + w_own[3];
         // a look-back spin of the depth sort that ran into its bound leaves a mis-sorted order behind: the frame
-        // must not be used.  Status word: bit 0 = list overflow, bit 1 = sort fault; the exact mode's host word
-        // carries ~0u instead of N (ggr_forward fails with GGR_E_HIP on it).
-        const bool fault = sort_fault && *sort_fault != 0u;
+        // must not be used.  Status word: bit 0 = list overflow, bit 1 = look-back spin ran into its bound, bit 2 = a
+        // key beyond the sort's 30 bits (the sort's fault word shifted up by one); the exact mode's host word
+        // carries GGR_HOST_FAULT_SPIN / _RANGE instead of N (ggr_forward fails with GGR_E_HIP / GGR_E_LIMIT on them).
+        const uint32_t fault = sort_fault ? (*sort_fault & 3u) : 0u;
         total_out[0] = n_all;
-        total_out[1] = (n_all > capacity ? 1u : 0u) | (fault ? 2u : 0u);
-        if (host_total) __hip_atomic_store(host_total, fault ? 0xFFFFFFFFu : n_all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        total_out[1] = (n_all > capacity ? 1u : 0u) | (fault << 1);
+        if (host_total)
+            __hip_atomic_store(host_total, (fault & 1u) ? GGR_HOST_FAULT_SPIN : fault ? GGR_HOST_FAULT_RANGE : n_all,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (t >= T) return;
     const uint32_t c0 = g * chunks_per_group, c1 = min(nchunks, c0 + chunks_per_group);
@@ -407,7 +410,9 @@ TileListPlan plan_tile_lists(size_t P, size_t T) {
         // has 16 bands, two per XCD, interleaved — with 8 bands of 1020 tiles a frame whose upper half is empty left
         // four XCDs without work (scatter 0.079 → 0.166 ms); the uniform frame is as fast either way (0.079 / 0.077)
         while (nb > 8 && (Tn + nb - 1) / nb < 64) nb -= 8;        // … and of at least 64 where the image allows
-        if (const char* e = getenv("GGR_SCATTER_BANDS")) { const size_t v = (size_t)atoi(e); if (v >= 8 && v % 8 == 0 && (Tn + v - 1) / v <= 512) nb = v; }
+#ifdef GGR_DEV_SCATTER_BANDS  // dev builds only (GGR_EXTRA_HIPCC_FLAGS=-DGGR_DEV_SCATTER_BANDS=24): force the band count
+        { const size_t v = GGR_DEV_SCATTER_BANDS; if (v >= 8 && v % 8 == 0 && (Tn + v - 1) / v <= 512) nb = v; }
+#endif
         p.sband_tiles = (uint32_t)((Tn + nb - 1) / nb);
         p.nsbands = (uint32_t)nb;                                // (trailing bands may be empty: they exit at once)
     }

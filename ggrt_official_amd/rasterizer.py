@@ -57,9 +57,10 @@ class GaussianRasterizationSettings(NamedTuple):
     sh_channel_major: bool = False              # shs given as [P,3,M] (GGRt's harmonics layout) instead of [P,M,3]
     aux_affine: Optional[tuple] = None          # (a, b): depth output = Σ max(a + b·z/s, 0)·α·T (GGRt's depth pass)
     tanfov: Optional[torch.Tensor] = None       # device [2]: overrides tanfovx / tanfovy without a read-back (camera_setup)
-    sh_max_degree: int = 4  # highest SH band evaluated.  4: GGRt's rasterizer fork as recollected (sh_degree = 4 with 25
-    #                         coefficients evaluates the nine degree-4 terms; unverifiable here);
-    #                         3: graphdeco upstream (coefficients 16.. ignored, zero gradient)
+    sh_max_degree: int = 3  # highest SH band evaluated.  3 (default): graphdeco and its w-depth forks — the family the
+    #                         live call site's signature belongs to (3-tuple return, no `debug`: cuda_splatting.py:101-118)
+    #                         — ignore coefficients 16.. (zero gradient); 4: the nine degree-4 terms are evaluated when
+    #                         sh_degree >= 4 with >= 25 coefficients
 
 
 class StageProfile:
@@ -140,13 +141,13 @@ def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view
         sh_stride=int(M), num_points=int(P), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
         scale_modifier=float(rs.scale_modifier), bg=_ptr(bg), viewmatrix=_ptr(view), projmatrix=_ptr(proj),
         campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfov_dev=_ptr(tf),
-        sh_max_degree=int(getattr(rs, "sh_max_degree", 4) or 4))
+        sh_max_degree=int(getattr(rs, "sh_max_degree", 3) or 3))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                viewmatrix, projmatrix, campos, aux, raster_settings):
+                viewmatrix, projmatrix, campos, aux, raster_settings, grad_mode=True):
         lib = _lib.load()
         rs = raster_settings
         dev = means3D.device
@@ -183,7 +184,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             geom = torch.empty((lib.ggr_geom_bytes(P),), dtype=torch.uint8, device=dev)
             # nothing requires grad (torch.no_grad() / inference): no backward will replay this forward, so the
             # per-pixel checkpoints of the segmented backward are neither written nor allocated
-            infer = not any(ctx.needs_input_grad) if hasattr(ctx, "needs_input_grad") else not torch.is_grad_enabled()
+            # (needs_input_grad mirrors tensor.requires_grad even under no_grad — the call site's means2D sink always
+            #  requires grad — and inside a Function's forward the grad mode is always off: the caller's grad mode
+            #  comes in as an argument)
+            infer = (not grad_mode) or not any(ctx.needs_input_grad)
             img = torch.empty((lib.ggr_image_bytes_inference(W, H, 1) if infer else lib.ggr_image_bytes(W, H),),
                               dtype=torch.uint8, device=dev)
             holder = {}
@@ -301,7 +305,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_proj if ctx.needs_input_grad[9] else None,
             d_cam.reshape(ctx.saved_tensors[10].shape) if ctx.needs_input_grad[10] else None,
             d_aux.reshape(aux_shape) if d_aux is not None else None,
-            None,
+            None, None,
         )
 
 
@@ -310,7 +314,7 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrices,
-                projmatrices, campos, aux, means2D, raster_settings, bg, tanfov, input_scale):
+                projmatrices, campos, aux, means2D, raster_settings, bg, tanfov, input_scale, grad_mode=True):
         lib = _lib.load()
         rs = raster_settings
         dev = means3D.device
@@ -347,7 +351,7 @@ class _RasterizeViews(torch.autograd.Function):
             depth = torch.empty((V, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((V, P), dtype=torch.int32, device=dev)
             geom = torch.empty((lib.ggr_geom_bytes_views(P, V),), dtype=torch.uint8, device=dev)
-            infer = not any(ctx.needs_input_grad)
+            infer = (not grad_mode) or not any(ctx.needs_input_grad)
             img = torch.empty((lib.ggr_image_bytes_inference(W, H, V) if infer else lib.ggr_image_bytes_views(W, H, V),),
                               dtype=torch.uint8, device=dev)
             holder = {}
@@ -465,7 +469,7 @@ class _RasterizeViews(torch.autograd.Function):
             d_cam.reshape(cam_shape) if ctx.needs_input_grad[9] else None,
             d_aux.reshape(aux_shape) if d_aux is not None else None,
             d_means2D if has_m2d else None,
-            None, None, None, None,
+            None, None, None, None, None,
         )
 
 
@@ -489,7 +493,7 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, campos, bg, 
         raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
     return _RasterizeViews.apply(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                  viewmatrices, projmatrices, campos, aux_precomp, means2D, raster_settings, bg, tanfov,
-                                 input_scale)
+                                 input_scale, torch.is_grad_enabled())
 
 
 def camera_setup(extrinsics: torch.Tensor, intrinsics: torch.Tensor, near: torch.Tensor, far: torch.Tensor,
@@ -540,7 +544,8 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     """Function form, argument order of upstream's ``rasterize_gaussians`` (+ the optional aux feature)."""
     rs = raster_settings
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.campos, aux_precomp, rs)
+                                     cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.campos, aux_precomp, rs,
+                                     torch.is_grad_enabled())
 
 
 class GaussianRasterizer(nn.Module):

@@ -14,7 +14,8 @@ Reference quirks kept on purpose (drop-in parity):
   * ``scale_invariant`` divides translations / means by ``near`` and covariances by ``near²`` (:66-73);
   * the depth pass feeds depth as a degree-0 SH coefficient, so the rasterizer returns
     ``0.5 + C0·z`` per channel and the result is the channel mean (:256-269);
-  * ``sh_degree = isqrt(d_sh) - 1`` (GGRt: d_sh = 25 → 4; bands 0..3 are evaluated).
+  * ``sh_degree = isqrt(d_sh) - 1`` (GGRt: d_sh = 25 → 4); bands 0..min(sh_degree, ``SH_MAX_DEGREE``) are
+    evaluated — ``SH_MAX_DEGREE`` = 3 by default, 4 on request.
 """
 from __future__ import annotations
 
@@ -28,6 +29,11 @@ from torch import Tensor, nn
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 DepthRenderingMode = Literal["depth", "disparity", "relative_disparity", "log"]
+
+# Highest SH band the rasterizer evaluates for this call site (GaussianRasterizationSettings.sh_max_degree).
+# 3: what the rasterizer family behind the reference's live call site does with GGRt's sh_degree = 4 / 25
+# coefficients; set to 4 if the installed extension being replaced evaluates band 4.
+SH_MAX_DEGREE = 3
 
 
 @dataclass
@@ -174,7 +180,7 @@ def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, backgroun
         settings = GaussianRasterizationSettings(
             image_height=h, image_width=w, tanfovx=tan_host[i][0], tanfovy=tan_host[i][1],
             bg=background_color[i], scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i],
-            sh_degree=degree, campos=extrinsics[i, :3, 3], prefiltered=False)
+            sh_degree=degree, campos=extrinsics[i, :3, 3], prefiltered=False, sh_max_degree=SH_MAX_DEGREE)
         kwargs = dict(means3D=gaussian_means[i], shs=shs[i] if use_sh else None,
                       colors_precomp=None if use_sh else shs[i, :, 0, :],
                       opacities=gaussian_opacities[i, ..., None])
@@ -363,7 +369,8 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
         settings = GaussianRasterizationSettings(
             image_height=h, image_width=w, tanfovx=0.0, tanfovy=0.0, bg=background_color[idx[0]], scale_modifier=1.0,
             viewmatrix=view[idx[0]], projmatrix=full[idx[0]], sh_degree=degree, campos=campos[idx[0]],
-            prefiltered=False, list_capacity=list_capacity * len(idx), sh_channel_major=True, aux_affine=aux_affine)
+            prefiltered=False, list_capacity=list_capacity * len(idx), sh_channel_major=True, aux_affine=aux_affine,
+            sh_max_degree=SH_MAX_DEGREE)
         kw = dict(cov3D_precomp=g_cov[b]) if fused_cov else dict(scales=g_scales[b], rotations=g_rot[b])
         col, _, dep = rasterize_views(g_means[b], g_op[b][..., None], take(view), take(full), take(campos),
                                       take(background_color), tf, settings, shs=g_sh[b], aux_precomp=aux,
@@ -386,7 +393,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
             scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i], sh_degree=degree,
             campos=campos[i], prefiltered=False, list_capacity=list_capacity,
             input_scale=None if scale is None else scale[i:i + 1], sh_channel_major=True, aux_affine=aux_affine,
-            tanfov=None if tanfov is None else tanfov[i])
+            tanfov=None if tanfov is None else tanfov[i], sh_max_degree=SH_MAX_DEGREE)
         means = g_means[b]
         kw = dict(cov3D_precomp=g_cov[b]) if fused_cov else dict(scales=g_scales[b], rotations=g_rot[b])
         # means2D is only a gradient sink (`cuda_splatting.py:95-99`): its values are never read

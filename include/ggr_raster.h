@@ -64,11 +64,12 @@ typedef struct GgrSettings {
     int32_t debug;           /* 1: synchronise + check after every kernel */
     const float* tanfov_dev; /* device float[2] or NULL.  When given it overrides tanfovx / tanfovy, so that a host
                                 that derived them on the device (ggr_camera_setup) never has to read them back */
-    int32_t sh_max_degree;   /* 0 = default (4).  4: the nine degree-4 terms are evaluated and differentiated when
-                                D >= 4 and M >= 25 — what GGRt's rasterizer fork (dcharatan/diff-gaussian-
-                                rasterization-modified, reference README.md:17-18) does to the builder's recollection;
-                                NOT verifiable in this build.  3: graphdeco upstream — coefficients
-                                16.. are ignored and get zero gradient. */
+    int32_t sh_max_degree;   /* 0 = default (3).  3: bands 0..3 only, as the graphdeco rasterizer and its "w-depth"
+                                forks do — coefficients 16.. are ignored and get zero gradient.  This is the family
+                                the LIVE call site's signature belongs to (3-tuple return, no `debug` field:
+                                cuda_splatting.py:101-118), hence the default.  4: the nine
+                                degree-4 terms are evaluated and differentiated when D >= 4 and M >= 25 — for a
+                                host whose installed rasterizer does evaluate band 4 (not verifiable in this build). */
 } GgrSettings;
 
 /* Inputs of GaussianRasterizer.forward (cuda_splatting.py:118-125).
@@ -246,7 +247,17 @@ int ggr_camera_setup(int32_t n, const float* extrinsics /*[n,4,4] camera-to-worl
                      float* scale /*[n]*/, void* stream);
 
 /* Sync-free mode: num_rendered and the overflow flag of the forward that filled `geom_buffer` (synchronises).
- * No counterpart in the reference: upstream always reads num_rendered back inside rasterize_gaussians. */
+ * `num_points` is what sized that geom buffer: P for ggr_forward, P·V for ggr_forward_views.
+ * Returns GGR_E_HIP if a look-back spin of the depth sort ran into its bound (GPU preempted or halted: the frame
+ * is invalid), GGR_E_LIMIT if a sort key beyond 30 bits reached the sort.  The exact mode reports the same two
+ * conditions from ggr_forward itself, with the same codes.
+ * No counterpart in the reference: upstream always reads num_rendered back inside rasterize_gaussians.
+ *
+ * Depth order: the sort key is the float bits of the view depth less those of the near cull (0.2), 30 bits — any
+ * depth below 6.8e37 keeps its exact order (ties by ascending index, as the reference's stable 64-bit sort);
+ * Gaussians at or beyond 6.8e37 (incl. +inf) share the last key and are ordered by index among themselves.
+ * A launch set of up to 64 views sorts one segment per view; beyond 64 views the views share one segment (same
+ * lists, slower sort). */
 int ggr_forward_status(const void* geom_buffer, int32_t num_points, int64_t* num_rendered, int32_t* overflow,
                        void* stream);
 
@@ -263,6 +274,15 @@ int ggr_debug_unpack_binning(const void* binning_buffer, const void* image_buffe
                              int32_t width, int32_t height, uint32_t* point_list /*[N]*/,
                              int32_t* ranges /*[tiles,2]*/, float* final_T /*[H,W]*/,
                              int32_t* n_contrib /*[H,W]*/, void* stream);
+
+
+/* Self-test of the exact mode's num_rendered wait (no GPU work, no counterpart in the reference): runs the host-side
+ * wait loop of ggr_forward on a private word with an injected event-query result.
+ * scenario 0: the query reports "not ready" and the word receives 1234 after a few polls → GGR_OK (*value = 1234);
+ * scenario 1: the query reports an error status (a stream in error / a lost device) → GGR_E_HIP at once;
+ * scenario 2: the query never becomes ready and the word never changes (a hung GPU) → GGR_E_HIP after timeout_s;
+ * scenario 3: the query reports "done" but the word was never written → GGR_E_HIP. */
+int ggr_debug_readback_wait(int32_t scenario, double timeout_s, uint32_t* value);
 
 #ifdef __cplusplus
 }

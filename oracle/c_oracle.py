@@ -74,9 +74,9 @@ class OracleState:
 
 def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy,
             sh_degree=0, shs=None, colors_precomp=None, cov3D_precomp=None, scales=None,
-            rotations=None, scale_modifier=1.0, sh_cap=4) -> OracleState:
-    """``sh_cap``: highest SH band evaluated (4 = GGRt's fork as recollected, 3 = graphdeco upstream; see the
-    header of ggr_oracle.c)."""
+            rotations=None, scale_modifier=1.0, sh_cap=3) -> OracleState:
+    """``sh_cap``: highest SH band evaluated (3 = graphdeco / w-depth family, the default; 4 = band 4 as well; see
+    the header of ggr_oracle.c)."""
     L = lib()
     means3D = _f32(means3D)
     P = means3D.shape[0]

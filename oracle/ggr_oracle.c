@@ -29,12 +29,15 @@
  * call this file.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg use it.
  *
- * SH degree: the graphdeco rasterizer evaluates bands 0..3 only.  GGRt calls with sh_degree = 4 and 25
- * coefficients (cuda_splatting.py:75-77, encoder config d_sh = 25) through dcharatan's fork, which — to the
- * builder's and the round-1 advisor's recollection, NOT verifiable here — adds the nine degree-4 terms
- * (SH_C4).  Both behaviours are restated: `sh_cap` = 4 evaluates band 4 when D ≥ 4 and M ≥ 25, `sh_cap` = 3
- * is graphdeco's (coefficients 16.. ignored, zero gradient).  The degree-4 basis is the standard real SH
- * polynomial set (PlenOctree/svox2 `SH_C4`), its gradient the plain polynomial derivative.
+ * SH degree: the graphdeco rasterizer and its "w-depth" forks evaluate bands 0..3 only.  GGRt calls with
+ * sh_degree = 4 and 25 coefficients (cuda_splatting.py:75-77, encoder config d_sh = 25).  Its README names
+ * dcharatan's fork, but the LIVE call site unpacks a 3-tuple and builds the settings without a `debug` field
+ * (cuda_splatting.py:101-118) — the signature of the graphdeco-era w-depth family, not of dcharatan's
+ * (2-tuple, `debug` required) — so `sh_cap` = 3 (coefficients 16.. ignored, zero gradient) is the default.
+ * `sh_cap` = 4 (band 4 evaluated when D ≥ 4 and M ≥ 25) is restated as well, for a host whose rasterizer
+ * does evaluate it; neither can be verified against the installed extension here.  The
+ * degree-4 basis is the standard real SH polynomial set (PlenOctree/svox2 `SH_C4`), its gradient the plain
+ * polynomial derivative.
  *
  * Build: see oracle/Makefile   (gcc -O2 -ffp-contract=off -fopenmp → libggr_oracle.so)
  * Arithmetic: fp32 with explicit operation order, no FMA contraction; gradient

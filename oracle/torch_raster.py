@@ -39,9 +39,9 @@ SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.37317633
          -0.4570457994644658, 1.445305721320277, -0.5900435899266435)
 SH_C4 = (2.5033429417967046, -1.7701307697799304, 0.9461746957575601, -0.6690465435572892, 0.10578554691520431,
          -0.6690465435572892, 0.47308734787878004, -1.7701307697799304, 0.6258357354491761)
-# Highest SH band evaluated.  graphdeco's rasterizer stops at 3; GGRt passes sh_degree = 4 with 25 coefficients
-# through dcharatan's fork which (recollected, unverifiable here — see oracle/ggr_oracle.c) evaluates band 4.
-SH_CAP = 4
+# Highest SH band evaluated.  graphdeco's rasterizer and its w-depth forks (the family GGRt's live call site's
+# signature belongs to, see oracle/ggr_oracle.c) stop at 3; band 4 on request (sh_cap=4).
+SH_CAP = 3
 
 
 def sh_eff_degree(D: int, M: int, cap: int = SH_CAP) -> int:

@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 from oracle import torch_raster as tr  # noqa: E402
 
 RECORD = []
+SH_CAP = [3]  # highest SH band the stand-in rasterizer evaluates for the case being recorded
 
 
 class _Sub:
@@ -77,7 +78,7 @@ def install_stubs():
             color, radii, depth = tr.rasterize(
                 means3D, opacities, rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg, rs.image_width, rs.image_height,
                 rs.tanfovx, rs.tanfovy, rs.sh_degree, shs=shs, colors_precomp=colors_precomp,
-                cov3D_precomp=cov3D_precomp)
+                cov3D_precomp=cov3D_precomp, sh_cap=SH_CAP[0])
             return color, radii, depth
 
     dgr.GaussianRasterizationSettings = GaussianRasterizationSettings
@@ -161,8 +162,12 @@ def main():
     torch.manual_seed(0)
     cases = [
         # name, kwargs for make_inputs, image_shape, call
+        # GGRt's own form (sh_degree = 4, 25 coefficients) under BOTH readings of what the replaced extension does
+        # with band 4: cap 3 (the default) and cap 4
         ("color_d25_offcentre", dict(seed=1, b=2, g_count=300, d_sh=25, h=40, w=56, near_vals=[0.7, 1.3],
                                      far_vals=[60.0, 90.0], cx=0.46, cy=0.55), (40, 56), "color", {}),
+        ("color_d25_offcentre_shcap4", dict(seed=1, b=2, g_count=300, d_sh=25, h=40, w=56, near_vals=[0.7, 1.3],
+                                            far_vals=[60.0, 90.0], cx=0.46, cy=0.55), (40, 56), "color", {}),
         ("color_d16_noscale", dict(seed=2, b=1, g_count=250, d_sh=16, h=48, w=48, near_vals=[1.0],
                                    far_vals=[100.0]), (48, 48), "color", dict(scale_invariant=False)),
         ("color_d1", dict(seed=3, b=1, g_count=200, d_sh=1, h=32, w=48, near_vals=[2.0], far_vals=[50.0]),
@@ -180,6 +185,7 @@ def main():
     ]
     for name, ikw, shape, kind, extra in cases:
         RECORD.clear()
+        SH_CAP[0] = 4 if name.endswith("_shcap4") else 3
         inp = make_inputs(**ikw)
         if kind == "color":
             out = cs.render_cuda(inp["extrinsics"], inp["intrinsics"], inp["near"], inp["far"], shape,
@@ -195,6 +201,7 @@ def main():
         blob["extra_keys"] = np.asarray(list(extra.keys()))
         blob["extra_vals"] = np.asarray([str(v) for v in extra.values()])
         blob["n_views"] = np.asarray(len(RECORD))
+        blob["sh_cap"] = np.asarray(SH_CAP[0])
         for i, rec in enumerate(RECORD):
             for k, v in to_np(rec).items():
                 blob[f"view{i}_{k}"] = v
@@ -204,7 +211,7 @@ def main():
         print(f"{name}: {len(RECORD)} boundary calls, out {tuple(out.shape)}, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def deferred_backprop_golden(cs):
+def deferred_backprop_golden(cs, sh_cap=3):
     """The call pattern of the reference's fine-tune loop (finetune_ggrt_stable.py:112-142, "deferred
     back-propagation"): render the whole frame without a graph, take dL/d(rgb) of the image loss, then for every
     cell (i, j) of a crop_size × crop_size grid render again WITH a graph, slice the cell out of the image and
@@ -213,6 +220,7 @@ def deferred_backprop_golden(cs):
     zero outside the cell.  Recorded: the input gradients each cell produces when the boundary is served by the
     oracle (torch autograd)."""
     RECORD.clear()
+    SH_CAP[0] = sh_cap
     h, w, crop = 48, 64, 2
     inp = make_inputs(seed=11, b=1, g_count=320, d_sh=25, h=h, w=w, near_vals=[0.8], far_vals=[70.0], cx=0.47, cy=0.54)
     g = torch.Generator().manual_seed(99)
@@ -230,7 +238,7 @@ def deferred_backprop_golden(cs):
     rgb_pred_grad = rgb.grad
     oh, ow = h // crop, w // crop
     blob = {f"in_{k}": v for k, v in to_np(inp).items()}
-    blob.update(image_shape=np.asarray((h, w)), crop_size=np.asarray(crop), target=target.numpy(),
+    blob.update(image_shape=np.asarray((h, w)), crop_size=np.asarray(crop), sh_cap=np.asarray(sh_cap), target=target.numpy(),
                 rgb=rgb.detach().numpy(), rgb_pred_grad=rgb_pred_grad.numpy())
     for i in range(crop):
         for j in range(crop):
@@ -239,12 +247,15 @@ def deferred_backprop_golden(cs):
             patch.backward(rgb_pred_grad[:, :, oh * i: oh * (i + 1), ow * j: ow * (j + 1)])
             for n, t in zip(names, leaves):
                 blob[f"cell{i}{j}_grad_{n}"] = t.grad.numpy()
-    path = os.path.join(HERE, "deferred_backprop_d25.npz")
+    name = "deferred_backprop_d25" + ("_shcap4" if sh_cap == 4 else "")
+    path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **blob)
-    print(f"deferred_backprop_d25: {crop * crop} cells, {os.path.getsize(path) / 1024:.0f} KiB")
+    print(f"{name}: {crop * crop} cells, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":
     main()
     install_stubs()
-    deferred_backprop_golden(load_reference())
+    cs = load_reference()
+    deferred_backprop_golden(cs, sh_cap=3)
+    deferred_backprop_golden(cs, sh_cap=4)

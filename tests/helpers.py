@@ -47,7 +47,9 @@ def check_image(img, ref, name="color", tag="", psnr_min=None, flip_fraction=Non
 
 
 GRAD_RTOL_ALL = 1e-3     # the north-star's bar, on the whole tensor, threshold flips included
-FLIP_ROWS = 1e-5         # fraction of the Gaussians (at least 8) whose gradient a threshold flip may have touched
+FLIP_ROWS = 1e-5         # fraction of the Gaussians whose gradient a threshold flip may have touched — strictly
+#                          proportional: below 100 k rows NO row is set aside (with a floor of 8 rows a bug
+#                          confined to a few Gaussians of a small case was only held to the 1e-3 bar), 10 at 1 M rows
 
 
 def check_grads(grads, ref, keys, tag="", rtol=None):
@@ -63,9 +65,9 @@ def check_grads(grads, ref, keys, tag="", rtol=None):
         a2, b2 = a.reshape(rows, -1), b.reshape(rows, -1)
         r_all = rel_l2(a2, b2)
         err = np.linalg.norm(a2 - b2, axis=1)
-        drop = min(rows, max(8, int(FLIP_ROWS * rows)))
+        drop = min(rows, int(FLIP_ROWS * rows))
         keep = np.ones(rows, bool)
-        if rows > drop:
+        if rows > drop > 0:
             keep[np.argpartition(-err, drop - 1)[:drop]] = False
         r = float(np.linalg.norm((a2 - b2)[keep]) / max(np.linalg.norm(b2[keep]), 1e-30)) if keep.any() else 0.0
         record_metric(f"{tag}:{k}", kind=1, rel_l2=r, rel_l2_all=r_all)
@@ -73,7 +75,7 @@ def check_grads(grads, ref, keys, tag="", rtol=None):
         assert r <= (GRAD_RTOL if rtol is None else rtol), f"grad {k}: rel-L2 {r:.3e} ({drop} rows set aside; all rows {r_all:.3e})"
 
 
-def oracle_forward(sc: Scene, use_sh=True, use_cov=True, colors=None, sh_cap=4):
+def oracle_forward(sc: Scene, use_sh=True, use_cov=True, colors=None, sh_cap=3):
     n = lambda t: t.detach().cpu().numpy()
     kw = {}
     if use_sh:
@@ -102,7 +104,7 @@ def psnr(a, b) -> float:
 
 
 def hip_forward_backward(sc: Scene, dL_dcolor: torch.Tensor, use_sh=True, use_cov=True, colors=None,
-                         dL_ddepth=None, pose=False, sh_max_degree=4):
+                         dL_ddepth=None, pose=False, sh_max_degree=3):
     """Runs the product path (GaussianRasterizer on cuda:0).  Returns (color, radii, depth, grads)."""
     from ggrt_official_amd import GaussianRasterizer
     dev = torch.device("cuda:0")

@@ -19,6 +19,11 @@ from oracle import torch_raster as tr
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "callsite_*.npz")))
 
 
+def _sh_cap(z) -> int:
+    """Highest SH band the recorded boundary evaluated: 3 unless the fixture says 4."""
+    return int(z["sh_cap"]) if "sh_cap" in z.files else 3
+
+
 def _load(path):
     z = np.load(path, allow_pickle=False)
     inp = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
@@ -41,11 +46,17 @@ class _OracleRasterizer(torch.nn.Module):
         rs = self.rs
         return tr.rasterize(means3D, opacities, rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg, rs.image_width,
                             rs.image_height, rs.tanfovx, rs.tanfovy, rs.sh_degree, shs=shs,
-                            colors_precomp=colors_precomp, cov3D_precomp=cov3D_precomp, aux=aux_precomp)
+                            colors_precomp=colors_precomp, cov3D_precomp=cov3D_precomp, aux=aux_precomp,
+                            sh_cap=int(getattr(rs, "sh_max_degree", 3)))
 
 
 def test_golden_files_present():
-    assert len(GOLDEN) >= 6
+    assert len(GOLDEN) >= 8
+    # GGRt's own form (sh_degree 4, 25 coefficients) is pinned under both readings of band 4, and they differ
+    caps = {os.path.basename(p): _sh_cap(np.load(p)) for p in GOLDEN if "color_d25" in p}
+    assert sorted(caps.values()) == [3, 4]
+    a, b = (np.load(p)["out_image"] for p in GOLDEN if "color_d25" in p)
+    assert np.abs(a - b).max() > 1e-2
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[9:-4] for p in GOLDEN])
@@ -90,6 +101,7 @@ def test_boundary_arguments_match_reference(path):
 def test_images_match_reference_callsite_cpu(path, monkeypatch):
     z, inp, shape, kind, extra = _load(path)
     monkeypatch.setattr(splatting, "GaussianRasterizer", _OracleRasterizer)
+    monkeypatch.setattr(splatting, "SH_MAX_DEGREE", _sh_cap(z))
     out = _render(inp, shape, kind, extra, "cpu")
     np.testing.assert_allclose(out.detach().numpy(), z["out_image"], rtol=0, atol=2e-5)
 
@@ -106,8 +118,9 @@ def _render(inp, shape, kind, extra, dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[9:-4] for p in GOLDEN])
-def test_images_match_reference_callsite_hip(path):
+def test_images_match_reference_callsite_hip(path, monkeypatch):
     z, inp, shape, kind, extra = _load(path)
+    monkeypatch.setattr(splatting, "SH_MAX_DEGREE", _sh_cap(z))
     out = _render(inp, shape, kind, extra, "cuda:0").detach().cpu().numpy()
     ref = z["out_image"]
     d = np.abs(out - ref)
@@ -117,7 +130,7 @@ def test_images_match_reference_callsite_hip(path):
 def test_decoder_module_cpu(monkeypatch):
     """DecoderSplattingCUDA: [b,v] flattening, per-view Gaussian sharing, optional depth pass."""
     monkeypatch.setattr(splatting, "GaussianRasterizer", _OracleRasterizer)
-    z, inp, shape, kind, extra = _load([p for p in GOLDEN if "color_d25" in p][0])
+    z, inp, shape, kind, extra = _load([p for p in GOLDEN if p.endswith("color_d25_offcentre.npz")][0])
     b = 1
     v = inp["extrinsics"].shape[0]
     gs = splatting.Gaussians(means=inp["gaussian_means"][:b], covariances=inp["gaussian_covariances"][:b],
@@ -134,7 +147,7 @@ def test_decoder_module_cpu(monkeypatch):
 
 
 def _decoder_case():
-    z, inp, shape, kind, extra = _load([p for p in GOLDEN if "color_d25" in p][0])
+    z, inp, shape, kind, extra = _load([p for p in GOLDEN if p.endswith("color_d25_offcentre.npz")][0])
     v = inp["extrinsics"].shape[0]
     gs = splatting.Gaussians(means=inp["gaussian_means"][:1], covariances=inp["gaussian_covariances"][:1],
                              harmonics=inp["gaussian_sh_coefficients"][:1], opacities=inp["gaussian_opacities"][:1])

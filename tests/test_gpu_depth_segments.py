@@ -81,3 +81,25 @@ def test_inference_forward_skips_the_checkpoints():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     b[0].sum().backward()
     assert torch.isfinite(m.grad).all()
+
+
+def test_no_grad_with_a_grad_requiring_sink_is_still_inference():
+    """the call site's `means2D` sink always requires grad, and `ctx.needs_input_grad` mirrors
+    `requires_grad` even under `torch.no_grad()` — the inference path must key on the caller's grad mode.  Seen
+    through the allocator: the checkpoint area (320 B per pixel) must not be allocated."""
+    from ggrt_official_amd import GaussianRasterizer, _lib
+    W, H = 480, 352
+    sc = make_scene(20000, W, H, sh_degree=1, profile="B", seed=6).to("cuda:0")
+    lib = _lib.load()
+    full, small = lib.ggr_image_bytes(W, H), lib.ggr_image_bytes_inference(W, H, 1)
+    assert full > 40e6 > 10 * small
+    sink = torch.zeros_like(sc.means3D).requires_grad_()
+    args = dict(means3D=sc.means3D, means2D=sink, opacities=sc.opacities, shs=sc.shs, cov3D_precomp=sc.cov3D)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        out = GaussianRasterizer(sc.settings())(**args)
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() - base < full // 2
+    assert not out[0].requires_grad

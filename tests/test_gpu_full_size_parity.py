@@ -14,7 +14,7 @@ five gradient tensors the reference's backward returns:
 * C4' colour + depth through the call-site layer (`render_color_and_depth`-style: aux feature) is covered by
   tests/test_callsite_fused.py at small size and by the a4 goldens.
 
-Bars: tests/helpers.py (PSNR ≥ 120 dB, ≤ 0.02 % threshold-flip pixels, gradients rel-L2 ≤ 2e-5).
+Bars: tests/helpers.py (PSNR ≥ 110 dB, ≤ 0.02 % threshold-flip pixels, gradients rel-L2 ≤ 1e-3 over all rows and ≤ 2e-5 once the 1e-5·P rows with the largest error (threshold flips; none below 100 k rows) are set aside).
 """
 import numpy as np
 import pytest

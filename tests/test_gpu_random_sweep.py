@@ -45,9 +45,10 @@ def _case(i):
 def test_random_case(i):
     sc, use_scale_rot = _case(i)
     dL = upstream_gradient(sc.width, sc.height, seed=300 + i)
-    st = oracle_forward(sc, use_cov=not use_scale_rot)
+    cap = 3 + i % 2               # both settings of the highest evaluated SH band (only degree-4 cases can tell)
+    st = oracle_forward(sc, use_cov=not use_scale_rot, sh_cap=cap)
     ref = c_oracle.backward(st, dL.numpy())
-    color, radii, depth, grads = hip_forward_backward(sc, dL, use_cov=not use_scale_rot)
+    color, radii, depth, grads = hip_forward_backward(sc, dL, use_cov=not use_scale_rot, sh_max_degree=cap)
     assert np.array_equal(radii, st.radii)
     check_image(color, st.color)
     names = ["means3D", "means2D", "shs", "opacities"] + (["scales", "rotations"] if use_scale_rot else ["cov3D_precomp"])

@@ -131,15 +131,17 @@ def test_sh_dc_and_degree4_stride25():
                                             n(sc.campos), n(sc.bg), sc.width, sc.height, sc.tanfovx, sc.tanfovy,
                                             sh_degree=4, shs=n(sh), cov3D_precomp=n(sc.cov3D), **kw)
     # band 4 with zero coefficients adds exact zeros: same image as degree 3 over 16 coefficients
-    assert np.array_equal(st3.color, fwd(sh25).color)
-    # graphdeco behaviour (sh_cap = 3): coefficients 16.. are ignored whatever they hold, and get no gradient
+    assert np.array_equal(st3.color, fwd(sh25, sh_cap=4).color)
+    # graphdeco / w-depth behaviour (sh_cap = 3, the default): coefficients 16.. are ignored whatever they hold,
+    # and get no gradient
     sh25[:, 16:] = 123.0
-    st4 = fwd(sh25, sh_cap=3)
+    st4 = fwd(sh25)
+    assert np.array_equal(st4.color, fwd(sh25, sh_cap=3).color)
     assert np.array_equal(st3.color, st4.color)
     g4 = c_oracle.backward(st4, upstream_gradient(48, 40).numpy())
     assert np.all(g4["shs"][:, 16:] == 0)
-    # GGRt's fork as recollected (sh_cap = 4, the default): band 4 is evaluated and differentiated
-    st4b = fwd(sh25)
+    # on request (sh_cap = 4): band 4 is evaluated and differentiated
+    st4b = fwd(sh25, sh_cap=4)
     assert not np.array_equal(st3.color, st4b.color)
     g4b = c_oracle.backward(st4b, upstream_gradient(48, 40).numpy())
     assert np.any(g4b["shs"][:, 16:] != 0)
