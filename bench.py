@@ -317,6 +317,12 @@ def main():
                     help="debug: process-group backend (default: nccl = RCCL).  `gloo` together with `--device 0` "
                          "lets several ranks share ONE GPU to dry-run the N>1 control flow on a 1-GPU box")
     ap.add_argument("--device", type=int, default=None, help="debug: CUDA device index instead of LOCAL_RANK")
+    ap.add_argument("--exchange-chunks", type=int, default=8,
+                    help="N>1: the step's all-reduce is issued as this many asynchronous collectives over equal slices "
+                         "of the buffer (8 × 32.5 MB by default), the bucketed form a trainer overlaps with its backward")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group and run the exchange legs even with ONE rank — executes the "
+                         "RCCL code path (backend nccl, ReduceOp.AVG, device_id) on a 1-GPU box")
     args = ap.parse_args()
 
     from ggrt_official_amd import GaussianRasterizer
@@ -324,7 +330,8 @@ def main():
     from ggrt_official_amd import parallel
     import torch.distributed as dist
 
-    rank, world, local = parallel.init_from_env(args.gpus, backend=args.dist_backend)
+    rank, world, local = parallel.init_from_env(args.gpus, backend=args.dist_backend, force=args.force_dist)
+    dist_on = world > 1 or args.force_dist   # the exchange runs (a forced one-rank group reduces over itself)
     if args.device is not None:
         local = args.device
     dev = torch.device(f"cuda:{local}")
@@ -335,50 +342,42 @@ def main():
 
     # ---- the exchange (N > 1): ONE flat buffer = stand-in parameter gradients + this step's camera gradient -----
     G = max(int(args.grad_buffer_floats), 0)
-    bufs, pending = [], [None, None]
-    use_avg = world > 1 and dist.get_backend() == "nccl"   # RCCL averages in the collective; gloo: sum, then scale
-    if world > 1:
+    # Two buffers alternate; each step's exchange goes out as `--exchange-chunks` asynchronous collectives
+    # (parallel.ChunkedMeanAllReduce: RCCL averages inside the collective, gloo sums and scales on wait).
+    bufs, reducers = [], []
+    if dist_on:
         bufs = [torch.zeros(G + 35, device=dev) for _ in range(2)]
+        reducers = [parallel.ChunkedMeanAllReduce(args.exchange_chunks) for _ in range(2)]
 
     def exchange(i: int, blocking: bool):
         k = i & 1
-        if pending[k] is not None:       # the all-reduce issued two steps ago on this buffer
-            pending[k].wait()
-            pending[k] = None
+        reducers[k].wait()               # the all-reduce issued two steps ago on this buffer
         buf = bufs[k]
         torch.cat([wl.view.grad.reshape(-1), wl.proj.grad.reshape(-1), wl.campos.grad.reshape(-1)], out=buf[G:])
-        work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, async_op=True)
+        reducers[k].issue(buf)
         if blocking:
-            work.wait()
-            if not use_avg:
-                buf.div_(world)
-        else:
-            pending[k] = work
+            reducers[k].wait()
 
     def drain():
-        for k in (0, 1):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-                if not use_avg:
-                    bufs[k].div_(world)
+        for r in reducers:
+            r.wait()
 
     blocking = args.exchange_mode == "serial"
 
     def step(i: int):
         wl.step()
-        if world > 1:
+        if dist_on:
             exchange(i, blocking)
 
     log(f"scene {args.config} resident on {dev}; world {world}; warmup {args.warmup}")
     elapsed, per_step = timed_steps(step, args.steps, args.warmup, dev, barrier=parallel.barrier,
-                                    finish=drain if world > 1 else None)
+                                    finish=drain if dist_on else None)
     elapsed = parallel.max_over_ranks(elapsed, dev)
     log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.3f} ms/step")
 
     # ---- N > 1: the pieces of the step, each measured on its own (after the timed region) -------------------
     multi = None
-    if world > 1:
+    if dist_on:
         def leg(fn, fin=None):
             t, _ = timed_steps(fn, args.steps, 2, dev, barrier=parallel.barrier, finish=fin)
             return parallel.max_over_ranks(t, dev) / args.steps * 1e3
@@ -390,11 +389,13 @@ def main():
         overlap_ms = leg(lambda i: (wl.step(), exchange(i, False)), drain)
         nbytes = (G + 35) * 4
         multi = {"exchange": f"one mean all-reduce per step of {G} stand-in parameter-gradient floats + 35 camera-gradient "
-                             f"floats ({nbytes / 1e6:.1f} MB), backend {dist.get_backend()}",
+                             f"floats ({nbytes / 1e6:.1f} MB) issued as {args.exchange_chunks} asynchronous chunks, "
+                             f"backend {dist.get_backend()}",
+                 "backend": dist.get_backend(), "world": world, "chunks": args.exchange_chunks,
                  "timed_loop_mode": args.exchange_mode, "raster_ms": round(raster_ms, 4),
                  "allreduce_ms": round(allreduce_ms, 4), "serial_ms_per_step": round(serial_ms, 4),
                  "overlapped_ms_per_step": round(overlap_ms, 4),
-                 "allreduce_busbw_GBps": round(2 * (world - 1) / world * nbytes / (allreduce_ms * 1e-3) / 1e9, 1),
+                 "allreduce_busbw_GBps": round(2 * (world - 1) / world * nbytes / (max(allreduce_ms, 1e-6) * 1e-3) / 1e9, 1),
                  "raster_only_mpix_s": round(world * W * H / raster_ms / 1e3, 1)}
         log(f"multi-GPU legs: {multi}")
 
@@ -492,7 +493,7 @@ def main():
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH deg {D}, profile {cfg['profile']}, "
                                    f"fwd+bwd incl. camera gradient, 1 frame per GPU" +
                                    (f", one RCCL mean all-reduce per step of {G} stand-in parameter-gradient floats + the "
-                                    f"camera gradient ({args.exchange_mode})" if world > 1 else ""),
+                                    f"camera gradient ({args.exchange_mode}, {args.exchange_chunks} chunks)" if dist_on else ""),
                        "num_rendered": N, "parallelism": f"frames x{world}"},
             "step_ms_hip_events": percentiles(per_step),
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},

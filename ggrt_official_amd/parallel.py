@@ -16,16 +16,17 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(expected_world: int | None = None, backend: str | None = None):
+def init_from_env(expected_world: int | None = None, backend: str | None = None, force: bool = False):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run contract) and, for
-    world > 1, creates the process group (RCCL on GPU, gloo on CPU).  Returns (rank, world, local_rank)."""
+    world > 1 (or when `force`d: a one-rank group, so that the RCCL path itself can be executed on a 1-GPU box),
+    creates the process group (RCCL on GPU, gloo on CPU).  Returns (rank, world, local_rank)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if expected_world is not None and expected_world != world:
         if world == 1 and expected_world > 1:
             raise RuntimeError(f"--gpus {expected_world} needs a torch.distributed.run launch (WORLD_SIZE={world})")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -66,6 +67,36 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(dist.get_world_size())
     return flat
+
+
+class ChunkedMeanAllReduce:
+    """Mean all-reduce of a flat buffer issued as `chunks` asynchronous collectives of equal size (the last one takes
+    the remainder) — the bucketed form a trainer overlaps with its backward: chunk k can be issued as soon as the
+    gradients it covers exist, RCCL runs the chunks in order on its own stream, and the consumer waits chunk by
+    chunk.  RCCL averages inside the collective (`ReduceOp.AVG`); gloo has no AVG: sum, then scale on wait."""
+
+    def __init__(self, chunks: int = 1):
+        self.chunks = max(1, int(chunks))
+        self.pending: list = []
+
+    def issue(self, flat: torch.Tensor) -> None:
+        if not dist.is_initialized():
+            return
+        use_avg = dist.get_backend() == "nccl"
+        n = flat.numel()
+        step = (n + self.chunks - 1) // self.chunks
+        for lo in range(0, n, step):
+            part = flat[lo:lo + step]
+            work = dist.all_reduce(part, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, async_op=True)
+            self.pending.append((work, None if use_avg else part))
+
+    def wait(self) -> None:
+        world = world_size()
+        for work, part in self.pending:
+            work.wait()
+            if part is not None and world > 1:
+                part.div_(world)
+        self.pending = []
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter]) -> None:

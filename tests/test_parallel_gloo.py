@@ -45,11 +45,18 @@ def _worker(rank, world, port, out):
     if rank == 1:
         extra.grad = torch.full_like(extra, 8.0)
     parallel.allreduce_gradients([extra, pose])
+    # 3c. the bucketed exchange of bench.py: K asynchronous chunk collectives, ragged last chunk, waited chunk by chunk
+    chunked = torch.arange(1003, dtype=torch.float32) * (rank + 1)
+    red = parallel.ChunkedMeanAllReduce(chunks=8)
+    red.issue(chunked)
+    n_pending = len(red.pending)
+    red.wait()
     # 4. timing reduction used by bench.py
     t = parallel.max_over_ranks(0.5 + rank, "cpu")
     parallel.barrier()
     out[rank] = dict(frames=mine, buf=float(buf[0]), grad=float(lin.weight.grad[0, 0]), pose=float(pose.grad[3, 3]), t=t,
-                     extra=float(extra.grad[2]))
+                     extra=float(extra.grad[2]), chunked_ok=bool(torch.allclose(chunked, torch.arange(1003.0) * 1.5)),
+                     n_pending=n_pending)
     parallel.shutdown()
 
 
@@ -67,6 +74,27 @@ def test_two_rank_gloo():
         assert out[r]["grad"] == pytest.approx(15.0) and out[r]["pose"] == pytest.approx(15.0)
         assert out[r]["t"] == pytest.approx(1.5)
         assert out[r]["extra"] == pytest.approx(4.0)
+        assert out[r]["chunked_ok"] and out[r]["n_pending"] == 8
+
+
+def _forced_worker(rank, world, port, out):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_from_env(1, backend="gloo", force=True)
+    buf = torch.arange(100.0)
+    red = parallel.ChunkedMeanAllReduce(chunks=3)
+    red.issue(buf)
+    red.wait()
+    out["ok"] = bool(dist.is_initialized() and torch.equal(buf, torch.arange(100.0)))
+    parallel.shutdown()
+
+
+@pytest.mark.timeout(120)
+def test_forced_one_rank_group():
+    """`bench.py --force-dist`: a one-rank process group so that the exchange code path runs on a 1-GPU box."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_forced_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert out["ok"]
 
 
 def test_single_process_is_a_noop():
