@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libggr_raster.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -22,7 +22,7 @@ class GgrSettings(C.Structure):
         ("sh_stride", C.c_int32), ("num_points", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
         ("scale_modifier", C.c_float), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
         ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("prefiltered", C.c_int32), ("debug", C.c_int32),
-        ("tanfov_dev", C.c_void_p), ("sh_max_degree", C.c_int32),
+        ("tanfov_dev", C.c_void_p), ("sh_max_degree", C.c_int32), ("scissor", C.c_int32 * 4),
     ]
 
 

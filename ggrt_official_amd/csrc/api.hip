@@ -74,11 +74,15 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
                     "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
     if (st->sh_max_degree != 0 && st->sh_max_degree != 3 && st->sh_max_degree != 4)
         return fail(GGR_E_INVALID, "sh_max_degree must be 0 (default), 3 or 4");
+    if ((st->scissor[0] | st->scissor[1] | st->scissor[2] | st->scissor[3]) &&
+        (st->scissor[0] < 0 || st->scissor[1] < 0 || st->scissor[2] <= st->scissor[0] || st->scissor[3] <= st->scissor[1]))
+        return fail(GGR_E_INVALID, "scissor must be x0 < x1, y0 < y1, all >= 0 (or all zero for none)");
     if (in->shs && st->sh_stride < (st->sh_degree > 3 ? 16 : (st->sh_degree + 1) * (st->sh_degree + 1)))
         return fail(GGR_E_INVALID, "sh_stride %d too small for sh_degree %d", st->sh_stride, st->sh_degree);
     const int64_t tiles = (int64_t)((st->image_width + GGR_TILE - 1) / GGR_TILE) * ((st->image_height + GGR_TILE - 1) / GGR_TILE);
     if (tiles > (1 << 24)) return fail(GGR_E_LIMIT, "image has %lld tiles; at most 2^24 supported", (long long)tiles);
-    if (st->image_width > 65535 * GGR_TILE || st->image_height > 65535 * GGR_TILE) return fail(GGR_E_LIMIT, "image too large");
+    if (st->image_width > 4608 * GGR_TILE || st->image_height > 65535 * GGR_TILE)  // (a tile row must fit one count band)
+        return fail(GGR_E_LIMIT, "image too large");
     return GGR_OK;
 }
 
@@ -145,6 +149,13 @@ InputForm input_form(const GgrSettings* st, const GgrForwardIn* in) {
     f.aux_a = in->aux_a;
     f.aux_b = in->aux_b;
     f.sh_cap = st->sh_max_degree == 4 ? 4 : 3;  // default 3: INTEGRATION.md §7
+    const int gx = (st->image_width + GGR_TILE - 1) / GGR_TILE, gy = (st->image_height + GGR_TILE - 1) / GGR_TILE;
+    f.sc_x0 = 0; f.sc_y0 = 0; f.sc_x1 = gx; f.sc_y1 = gy;
+    const int32_t* sc = st->scissor;
+    if (sc[0] | sc[1] | sc[2] | sc[3]) {   // the tiles that overlap the pixel window (validate() checked its shape)
+        f.sc_x0 = min(gx, sc[0] / GGR_TILE); f.sc_y0 = min(gy, sc[1] / GGR_TILE);
+        f.sc_x1 = min(gx, (sc[2] + GGR_TILE - 1) / GGR_TILE); f.sc_y1 = min(gy, (sc[3] + GGR_TILE - 1) / GGR_TILE);
+    }
     return f;
 }
 

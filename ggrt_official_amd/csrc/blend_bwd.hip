@@ -82,6 +82,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  int segments, int views) {
     __shared__ StagedSplat stage[BATCH];
     __shared__ __attribute__((aligned(16))) uint16_t surv[4][BATCH];  // per wave: stage indices of the entries that survive its quadrant cull
+    __shared__ uint32_t wave_top[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroup = (depth segment, tile), segment-major: all tiles' segment 0 first.  (Tile-major order interleaves
@@ -128,12 +129,19 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     }
 
     const float T_final = inside ? final_T[pid] : 0.f;
-    const uint32_t last = inside ? n_contrib[pid] : 0u;
+    uint32_t last = inside ? n_contrib[pid] : 0u;
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dpz = 0.f;
     if (inside) {
         dp0 = dL_dpix[pid]; dp1 = dL_dpix[hw + pid]; dp2 = dL_dpix[2 * hw + pid];
         if (HAS_DEPTH) dpz = dL_ddepth[pid];
     }
+    // ---- zero-gradient window skip ------------------------------------------------------------------------------
+    // A pixel whose upstream gradient is exactly zero contributes exactly zero to every sum below (each term is a
+    // product with dL/dpixel): it is treated as a pixel without contributors.  The reference's fine-tune loop
+    // back-propagates, per crop cell, a gradient that is zero outside the cell through a full-frame render
+    // (finetune_ggrt_stable.py:126-142): a wave whose quadrant carries no gradient then has no survivors, and a
+    // workgroup whose 256 pixels carry none — or whose live pixels all end before this depth segment — leaves below.
+    if (dp0 == 0.f && dp1 == 0.f && dp2 == 0.f && dpz == 0.f) last = 0u;
     const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
@@ -141,6 +149,12 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     uint32_t wl = last;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, off));
+    // … and the workgroup's: nothing behind it is staged at all (the forward's tile_top is the same maximum over
+    // ALL pixels of the tile; with a dense gradient the two agree)
+    if (lane == 0) wave_top[wave] = wl;
+    __syncthreads();
+    seg_hi = min(seg_hi, (int)max(max(wave_top[0], wave_top[1]), max(wave_top[2], wave_top[3])));
+    if (seg_lo >= seg_hi) return;  // (block-uniform; no barrier is pending)
 
     float T = T_final;
     float R = T_final * bg_dot;  // everything behind the current entry, dotted with dL/dpixel (see the slot body)
@@ -148,7 +162,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     // A pixel whose list goes on behind this segment starts from the forward's checkpoint there: T as the forward
     // had it, and R = (final sums − checkpoint sums)·dL/dpixel + T_final·(bg·dL/dpixel) — the same "everything
     // behind" that the single-segment replay accumulates entry by entry.
-    if (seg_hi < top && last > (uint32_t)seg_hi) {
+    if (stride > 0 && seg_hi == seg_lo + stride && last > (uint32_t)seg_hi) {
         const float* ck = ckpt + (size_t)(seg_hi / stride) * GGR_CKPT_FLOATS * hw + pid;
         const float* fin = ckpt + pid;
         T = ck[0];

@@ -55,6 +55,8 @@
 #ifndef GGR_BIN_CHUNK
 #define GGR_BIN_CHUNK 1024
 #endif
+#define GGR_COUNT_CPG 4    // chunks per workgroup of the count kernel (their running per-tile counts stay in registers)
+#define GGR_COUNT_GROUPS 8 // groups of count workgroups: the prefix over workgroups runs per group (T·groups-way parallel)
 
 static inline size_t ggr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -216,6 +218,7 @@ struct InputForm {
     int aux_affine;            // 1: blended feature = max(aux_a + aux_b·z/s, 0) instead of z — GGRt's depth pass
     float aux_a, aux_b;        //    (:240-269: depth as a degree-0 SH coefficient) without a per-Gaussian tensor
     int sh_cap;                // highest SH band evaluated: 3 (graphdeco / w-depth family, default) or 4
+    int sc_x0, sc_y0, sc_x1, sc_y1;  // GgrSettings.scissor in TILES, half-open, inside the tile grid (whole grid = none)
 };
 
 // The cameras of one launch set: V views of the SAME P Gaussians (V = 1: the reference's call).  Per-Gaussian state of
@@ -267,8 +270,9 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
 
 // tile-list builder (tile_lists.hip)
 struct TileListPlan {
-    uint32_t nchunks, nbands, band_tiles, nsbands, sband_tiles, groups, chunks_per_group;
-    size_t table_words, gsum_words, work_bytes;
+    uint32_t nchunks, nsbands, sband_tiles;
+    uint32_t nw, groups, wpg;   // count workgroups (GGR_COUNT_CPG chunks each), groups of them, workgroups per group
+    size_t table_words, wsum_words, gsum_words, work_bytes;
 };
 TileListPlan plan_tile_lists(size_t P, size_t T);
 // K1 + K2: fills the work area, ranges[T], total_out[0] (= N, device) and total_out[1] (= N > capacity).

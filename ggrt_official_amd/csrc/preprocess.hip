@@ -251,10 +251,12 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 const int rad = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
                 px = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
                 py = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
-                const int rminx = min(gx, max(0, (int)((px - (float)rad) / (float)GGR_TILE)));
-                const int rminy = min(gy, max(0, (int)((py - (float)rad) / (float)GGR_TILE)));
-                const int rmaxx = min(gx, max(0, (int)((px + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
-                const int rmaxy = min(gy, max(0, (int)((py + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
+                // (the reference clips the rect to the tile grid [0, gx] × [0, gy]; the scissor extension to its window's
+                //  tiles — the whole grid unless GgrSettings.scissor is set)
+                const int rminx = min(inf.sc_x1, max(inf.sc_x0, (int)((px - (float)rad) / (float)GGR_TILE)));
+                const int rminy = min(inf.sc_y1, max(inf.sc_y0, (int)((py - (float)rad) / (float)GGR_TILE)));
+                const int rmaxx = min(inf.sc_x1, max(inf.sc_x0, (int)((px + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
+                const int rmaxy = min(inf.sc_y1, max(inf.sc_y0, (int)((py + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
                 const int area = (rmaxx - rminx) * (rmaxy - rminy);
                 if (area != 0) {
                     vis = true;

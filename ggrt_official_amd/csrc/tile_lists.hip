@@ -10,12 +10,14 @@
 //        tile_start[t] + #{ Gaussians before g in `order` whose rect contains t },
 // which is computed without any sort over the N = Σ tiles_touched entries:
 //
-//   K1 count    chunk c = 1024 consecutive positions of `order`; per (chunk, tile band) one workgroup
-//               histograms the chunk's rects into LDS (ds_add, order irrelevant) → table[c][t]
-//   K2a, K2b/c  exclusive prefix of table over chunks per tile (grouped: G groups of chunks so that the
-//               scan has T·G-way parallelism), exclusive scan over tiles → ranges, N (formed by every block of
-//               K2b/c for its own 256 tiles — no launch of its own);
-//               table[c][t] becomes the ABSOLUTE list position of chunk c's first entry for tile t
+//   K1 count    chunk c = 1024 consecutive positions of `order`; a workgroup takes 4 consecutive chunks of one band of
+//               tile rows: per chunk the rects' corner deltas go into an LDS grid (4 order-free ds_add per
+//               Gaussian) whose 2-D prefix sum is the per-tile count → table[c][t] = entries of the workgroup's
+//               earlier chunks, wsum[w][t] = entries of all its chunks (+ per-group and per-tile totals by atomics)
+//   K2          exclusive prefix of wsum over the workgroups per tile (grouped: 8 groups so that the scan has
+//               T·8-way parallelism), exclusive scan over tiles → ranges, N (formed by every block for its own
+//               256 tiles — no launch of its own); table[c][t] + wsum[c/4][t] is then the ABSOLUTE list
+//               position of chunk c's first entry for tile t
 //   K3 scatter  per (chunk, tile band) ONE wave walks its chunk's (Gaussian, tile) pairs in order, 64 consecutive
 //               pairs ("slots") per step; the band's cursors live in LDS (initialised from table[c][·]).  Lanes
 //               of a step that hold the same tile are matched through a per-tile lane-mask word (atomic OR,
@@ -23,9 +25,9 @@
 //               base + rank.  Program order across steps + in-order LDS ⇒ stable lists; each id is stored at
 //               point_list[pos].  One XCD owns a band (its list lines are then merged in ONE L2).
 //
-// HBM traffic: table (chunks·T·4 B, 32 MB at C3) written once, read/written once, read once; rects read
-// twice per band; N·4 B of ids written.  ≈ 0.25 GB instead of ≈ 0.9 GB for emit + 2 radix passes, and 4
-// launches instead of 12.  A tile band is ≤ 4096 tiles (16 KB of LDS) so any image size works.
+// HBM traffic: table (chunks·T·4 B, 32 MB at C3) written once, read once; wsum (8 MB) written, read + rewritten,
+// read; rects read once per count band and once per scatter band; N·4 B of ids written.  A count band is ≤ 4608
+// tiles (18 KB of LDS), a scatter band ≤ 512, so any image size works.
 #include "ggr_common.h"
 #include <stdlib.h>
 
@@ -60,112 +62,115 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
     return v;
 }
 
-// ---- K1 -----------------------------------------------------------------------------------------
+// ---- K1: per-(chunk, tile) counts from RECT CORNERS + a 2-D prefix sum -------------------------------------------
+// The number of a chunk's rects that cover tile (y, x) is the 2-D inclusive prefix sum of the corner deltas
+// +1 at (y0, x0), −1 at (y0, x1), −1 at (y1, x0), +1 at (y1, x1): 4 order-free LDS adds per Gaussian and one scan of
+// the band's tile grid per chunk, instead of visiting every (Gaussian, tile) pair (round 2: the scatter's slot walk
+// with a ds_add per pair, ≈ 17 k wave instructions per chunk; this: ≈ 1 k).  A workgroup handles GGR_COUNT_CPG
+// consecutive chunks of one band of tile ROWS and keeps, per tile, the running count over its chunks in registers:
+//   table[c][t]  = entries of the workgroup's EARLIER chunks in tile t        (exclusive prefix inside the workgroup)
+//   wsum[w][t]   = entries of all its chunks                                  (K2 turns it into the absolute base)
+//   gsum[g][t]  += the same, per group g of workgroups;  total[t] += the same (atomics, one pair per workgroup and tile)
+// which removes round 2's separate group-sum launch and two of its three sweeps over the 32 MB table.
+#define GGR_COUNT_MAXK 18  // tiles per thread: a band holds at most 256·18 = 4608 tiles
 __global__ void __launch_bounds__(256)
-bin_count_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect, uint32_t T,
-                 uint32_t band_tiles, uint32_t grid_x, uint32_t* __restrict__ table) {
-    // LDS: hist[band_tiles] shared by the block + per wave the compacted list of its 256 Gaussians that touch the
-    // band (first tile relative to the band, rect width, first slot) and mark[64] (scratch of one step)
-    extern __shared__ uint32_t lds[];
-    constexpr uint32_t PER_WAVE = GGR_BIN_CHUNK / 4;
-    uint32_t* hist = lds;
-    const uint32_t chunk = blockIdx.x, band = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t* l_xy = lds + band_tiles + wave * (3 * PER_WAVE + 64);
-    uint32_t* l_w = l_xy + PER_WAVE;
-    uint32_t* l_pre = l_w + PER_WAVE;
-    uint32_t* mark = l_pre + PER_WAVE;
-    const uint32_t lo = band * band_tiles, hi = min(T, lo + band_tiles);
-    const uint32_t band_n = hi - lo;
-    for (uint32_t i = tid; i < band_n; i += 256) hist[i] = 0;
-    const uint32_t base = chunk * GGR_BIN_CHUNK + wave * PER_WAVE;
-    // all of this wave's rects first (independent loads in flight together — the kernel is otherwise a chain
-    // of serial ≈1–2 µs round trips; PMC showed 59 % of the wave time waiting)
-    uint2 rcs[PER_WAVE / 64];
+bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, uint32_t T, uint32_t grid_x,
+                 uint32_t rows_total, uint32_t band_rows, uint32_t nchunks, uint32_t wpg, uint32_t* __restrict__ table,
+                 uint32_t* __restrict__ wsum, uint32_t* __restrict__ gsum, uint32_t* __restrict__ total) {
+    extern __shared__ uint32_t grid[];  // [band_rows][grid_x] corner deltas → counts
+    const uint32_t w = blockIdx.x, band = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t r0 = band * band_rows, r1 = min(rows_total, r0 + band_rows), nr = r1 - r0;
+    const uint32_t cells = nr * grid_x, tile0 = r0 * grid_x;
+    uint32_t run[GGR_COUNT_MAXK];
 #pragma unroll
-    for (uint32_t q = 0; q < PER_WAVE / 64; q++) {
-        const uint32_t i = base + q * 64 + lane;
-        rcs[q] = i < P ? rect[i] : make_uint2(0u, 0u);  // rect_sorted: already in depth order
-    }
-    __syncthreads();
-    // Same slot walk as bin_scatter (there with the full explanation), minus the ordering: the wave numbers the
-    // (Gaussian, tile) pairs of its quarter chunk consecutively and handles 64 of them per step with ONE
-    // order-free ds_add — every lane busy, where a thread-per-Gaussian loop over its own rect ran at the pace
-    // of the largest rect in the wave (0.051 → 0.03 ms at C3).
-    const uint32_t row_lo = lo / grid_x, row_hi = (hi - 1) / grid_x + 1;
-    uint32_t nh = 0, S = 0;
+    for (int k = 0; k < GGR_COUNT_MAXK; k++) run[k] = 0u;
+    constexpr uint32_t PER_THREAD = GGR_BIN_CHUNK / 256;
+    const uint32_t c_first = w * GGR_COUNT_CPG, c_end = min(nchunks, c_first + GGR_COUNT_CPG);
+    uint2 rc[PER_THREAD];
 #pragma unroll
-    for (uint32_t q = 0; q < PER_WAVE / 64; q++) {
-        uint32_t x0, y0, x1, y1;
-        unpack_rect(rcs[q], x0, y0, x1, y1);
-        const uint32_t ya = max(y0, row_lo), yb = min(y1, row_hi);
-        const uint32_t w = x1 > x0 ? x1 - x0 : 0, h = yb > ya ? yb - ya : 0;
-        const uint32_t n = w * h;
-        const bool hit = n > 0 && (yb - 1) * grid_x + x1 - 1 >= lo && ya * grid_x + x0 < hi;
-        const uint32_t incl = wave_scan_add(hit ? n : 0u);
-        const uint64_t mk = __ballot(hit);
-        if (hit) {
-            const uint32_t p = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-            l_xy[p] = ya * grid_x + x0 - lo;
-            l_w[p] = w;
-            l_pre[p] = S + incl - n;
-        }
-        nh += (uint32_t)__popcll(mk);
-        S += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    for (uint32_t q = 0; q < PER_THREAD; q++) {
+        const uint32_t i = c_first * GGR_BIN_CHUNK + q * 256 + tid;
+        rc[q] = i < P ? rect[i] : make_uint2(0u, 0u);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    uint32_t carry1 = 0;
-    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
-        const uint32_t s = s0 + lane;
-        mark[lane] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t kc = carry1 + lane;
-        if (kc < nh) {
-            const uint32_t pk = l_pre[kc];
-            if (pk < s0 + 64u) mark[pk - s0] = kc + 1u;
+    for (uint32_t c = c_first; c < c_end; c++) {
+        for (uint32_t i = tid; i < cells; i += 256) grid[i] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < PER_THREAD; q++) {
+            uint32_t x0, y0, x1, y1;
+            unpack_rect(rc[q], x0, y0, x1, y1);
+            const uint32_t ya = max(y0, r0), yb = min(y1, r1);
+            if (x1 > x0 && yb > ya) {  // (corners on the band's far edges would only feed cells outside it)
+                uint32_t* top = grid + (ya - r0) * grid_x;
+                atomicAdd(top + x0, 1u);
+                if (x1 < grid_x) atomicAdd(top + x1, 0xFFFFFFFFu);
+                if (yb < r1) {
+                    uint32_t* bot = grid + (yb - r0) * grid_x;
+                    atomicAdd(bot + x0, 0xFFFFFFFFu);
+                    if (x1 < grid_x) atomicAdd(bot + x1, 1u);
+                }
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t own1 = mark[lane];
-        if (lane == 0) own1 = max(own1, carry1);
-        own1 = wave_scan_max(own1);
-        carry1 = (uint32_t)__builtin_amdgcn_readlane((int)own1, 63);
-        const uint32_t k = own1 - 1u;
-        const uint32_t j = s - l_pre[k], w = l_w[k], bt = l_xy[k];
-        const uint32_t ly = (uint32_t)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)w));  // (see bin_scatter)
-        const uint32_t tr = bt + ly * grid_x + (j - ly * w);
-        if (s < S && tr < band_n) atomicAdd(&hist[tr], 1u);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // this step's mark reads before the next step's writes
-        __builtin_amdgcn_wave_barrier();
+        // the next chunk's rects travel while this one is scanned
+        if (c + 1 < c_end) {
+#pragma unroll
+            for (uint32_t q = 0; q < PER_THREAD; q++) {
+                const uint32_t i = (c + 1) * GGR_BIN_CHUNK + q * 256 + tid;
+                rc[q] = i < P ? rect[i] : make_uint2(0u, 0u);
+            }
+        }
+        __syncthreads();
+        // prefix along x: one wave per row, 64 tiles per step
+        for (uint32_t row = wave; row < nr; row += 4) {
+            uint32_t carry = 0u;
+            for (uint32_t xb = 0; xb < grid_x; xb += 64) {
+                const uint32_t x = xb + lane;
+                const uint32_t v = x < grid_x ? grid[row * grid_x + x] : 0u;
+                const uint32_t incl = wave_scan_add(v) + carry;
+                if (x < grid_x) grid[row * grid_x + x] = incl;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+        __syncthreads();
+        // prefix along y: one thread per column (consecutive lanes, consecutive words)
+        for (uint32_t x = tid; x < grid_x; x += 256) {
+            uint32_t acc = 0u;
+            for (uint32_t row = 0; row < nr; row++) {
+                acc += grid[row * grid_x + x];
+                grid[row * grid_x + x] = acc;
+            }
+        }
+        __syncthreads();
+        uint32_t* trow = table + (size_t)c * T + tile0;
+#pragma unroll
+        for (int k = 0; k < GGR_COUNT_MAXK; k++) {
+            const uint32_t i = (uint32_t)k * 256u + tid;
+            if (i < cells) {
+                trow[i] = run[k];
+                run[k] += grid[i];
+            }
+        }
+        __syncthreads();  // (the next chunk clears the grid)
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < band_n; i += 256) table[(size_t)chunk * T + lo + i] = hist[i];
+    const size_t wo = (size_t)w * T + tile0, go = (size_t)(w / wpg) * T + tile0;
+#pragma unroll
+    for (int k = 0; k < GGR_COUNT_MAXK; k++) {
+        const uint32_t i = (uint32_t)k * 256u + tid;
+        if (i < cells) {
+            wsum[wo + i] = run[k];
+            if (run[k]) { atomicAdd(&gsum[go + i], run[k]); atomicAdd(&total[tile0 + i], run[k]); }
+        }
+    }
 }
 
-// ---- K2a: per (tile, group of chunks) sum ---------------------------------------------------------
+// ---- K2: wsum[w][t] ← absolute list position of workgroup w's first entry in tile t; tile ranges; N -------------------
+// Every block forms the start of ITS 256 tiles itself: Σ totals of all tiles before them (≤ 32 KB from L2, 32 loads per
+// thread in flight) + a block scan of its own (a single-block scan launch cost ≈ 11 µs for ≈ 3 µs of work).  The blocks
+// of group 0 write the tile ranges; block (0, 0) — dispatched first — is the one that owns the LAST tiles, so N reaches
+// the host's pinned word while the rest of the launch is still running.
 __global__ void __launch_bounds__(256)
-bin_group_sum_kernel(const uint32_t* __restrict__ table, uint32_t T, uint32_t nchunks, uint32_t chunks_per_group,
-                     uint32_t* __restrict__ gsum /*[G][T]*/, uint32_t* __restrict__ total /*[T], zeroed*/) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-    if (t >= T) return;
-    const uint32_t c0 = g * chunks_per_group, c1 = min(nchunks, c0 + chunks_per_group);
-    uint32_t s = 0;
-#pragma unroll 8
-    for (uint32_t c = c0; c < c1; c++) s += table[(size_t)c * T + t];
-    gsum[(size_t)g * T + t] = s;
-    if (s) atomicAdd(&total[t], s);  // G atomics per tile at most
-}
-
-// ---- K2b/c: table[c][t] ← absolute position of chunk c's first entry in tile t's list; tile ranges; N -----------------
-// The exclusive scan of the per-tile totals used to be a launch of its own (ONE block, ≈ 11 µs for ≈ 3 µs of work, and
-// ≈ 8 µs of that is what any dependent launch costs).  Every block here now forms the start of ITS 256 tiles itself:
-// Σ totals of all tiles before them (≤ 32 KB from L2, 32 loads per thread in flight) + a block scan of its own.  The
-// blocks of group 0 write the tile ranges; block (0, 0) — dispatched first — is the one that owns the LAST tiles, so N
-// reaches the host's pinned word while the rest of the launch is still rewriting the table.
-__global__ void __launch_bounds__(256)
-bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchunks, uint32_t chunks_per_group,
-                        const uint32_t* __restrict__ gsum, const uint32_t* __restrict__ total /*[T] per-tile totals (K2a)*/,
+bin_group_prefix_kernel(uint32_t* __restrict__ wsum, uint32_t T, uint32_t nw, uint32_t wpg,
+                        const uint32_t* __restrict__ gsum, const uint32_t* __restrict__ total /*[T] per-tile totals (K1)*/,
                         uint2* __restrict__ ranges, uint32_t* __restrict__ total_out /*[0] = N, [1] = overflow | fault*/,
                         uint32_t capacity /*entries the caller's list buffer holds (sync-free mode); ~0u = exact*/,
                         uint32_t* __restrict__ host_total /*pinned host word that also receives N, or NULL*/,
@@ -212,19 +217,19 @@ bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchun
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (t >= T) return;
-    const uint32_t c0 = g * chunks_per_group, c1 = min(nchunks, c0 + chunks_per_group);
+    const uint32_t w0 = g * wpg, w1 = min(nw, w0 + wpg);
     uint32_t run = start;
 #pragma unroll 8
     for (uint32_t gg = 0; gg < g; gg++) run += gsum[(size_t)gg * T + t];  // exclusive prefix over groups
     // counts first (independent loads, 8 in flight), then the running positions
-    for (uint32_t cb = c0; cb < c1; cb += 8) {
+    for (uint32_t wb = w0; wb < w1; wb += 8) {
         uint32_t v[8];
 #pragma unroll
-        for (uint32_t u = 0; u < 8; u++) v[u] = cb + u < c1 ? table[(size_t)(cb + u) * T + t] : 0u;
+        for (uint32_t u = 0; u < 8; u++) v[u] = wb + u < w1 ? wsum[(size_t)(wb + u) * T + t] : 0u;
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++)
-            if (cb + u < c1) {
-                table[(size_t)(cb + u) * T + t] = run;
+            if (wb + u < w1) {
+                wsum[(size_t)(wb + u) * T + t] = run;
                 run += v[u];
             }
     }
@@ -234,6 +239,7 @@ bin_group_prefix_kernel(uint32_t* __restrict__ table, uint32_t T, uint32_t nchun
 __global__ void __launch_bounds__(64)
 bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect, uint32_t T,
                    uint32_t band_tiles, uint32_t grid_x, const uint32_t* __restrict__ table,
+                   const uint32_t* __restrict__ wsum /*[workgroup of K1][T]: absolute base of the chunk's count workgroup*/,
                    uint32_t* __restrict__ point_list, uint32_t capacity /*entries in point_list; ~0u = exact size*/,
                    uint32_t nbands_total) {
     // LDS: cursor[band_tiles] (next free list position per tile of the band) + the compacted list of this
@@ -272,7 +278,7 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const uint32_t i = lane + 64 * q;
-        cur0[q] = i < hi - lo ? table[(size_t)chunk * T + lo + i] : 0u;
+        cur0[q] = i < hi - lo ? table[(size_t)chunk * T + lo + i] + wsum[(size_t)(chunk / GGR_COUNT_CPG) * T + lo + i] : 0u;
     }
 #pragma unroll
     for (int q = 0; q < NB; q++) {
@@ -392,11 +398,8 @@ TileListPlan plan_tile_lists(size_t P, size_t T) {
     TileListPlan p;
     p.nchunks = (uint32_t)((P + GGR_BIN_CHUNK - 1) / GGR_BIN_CHUNK);
     if (p.nchunks == 0) p.nchunks = 1;
-    // count: wide bands (few re-reads of the rects, order-free LDS adds); scatter: narrow bands (many short,
-    // independent in-order walks instead of few long ones — every step waits for a ds_add_rtn)
-    p.band_tiles = (uint32_t)(T < 4096 ? (T ? T : 1) : 4096);
-    p.nbands = (uint32_t)((T + p.band_tiles - 1) / p.band_tiles);
-    if (p.nbands == 0) p.nbands = 1;
+    // scatter: narrow bands (many short, independent in-order walks instead of few long ones — every step waits for
+    // a ds_add_rtn); the count kernel's bands are whole tile rows, chosen at launch (it needs grid_x)
     {   // aim for ≥ ~8192 independent walks (chunks × bands); a band is 64 … 512 tiles.
         // The band COUNT is a multiple of 8: bin_scatter gives each band to one XCD (see there), so equal
         // counts per XCD keep the eight of them balanced.  (An earlier attempt at the same idea changed the
@@ -416,13 +419,15 @@ TileListPlan plan_tile_lists(size_t P, size_t T) {
         p.sband_tiles = (uint32_t)((Tn + nb - 1) / nb);
         p.nsbands = (uint32_t)nb;                                // (trailing bands may be empty: they exit at once)
     }
-    p.groups = p.nchunks < 32 ? p.nchunks : 32;
-    p.chunks_per_group = (p.nchunks + p.groups - 1) / p.groups;
-    p.groups = (p.nchunks + p.chunks_per_group - 1) / p.chunks_per_group;
+    p.nw = (p.nchunks + GGR_COUNT_CPG - 1) / GGR_COUNT_CPG;
+    p.wpg = (p.nw + GGR_COUNT_GROUPS - 1) / GGR_COUNT_GROUPS;
+    p.groups = (p.nw + p.wpg - 1) / p.wpg;
     const size_t Tp = T ? T : 1;
     p.table_words = (size_t)p.nchunks * Tp;
+    p.wsum_words = (size_t)p.nw * Tp;
     p.gsum_words = (size_t)p.groups * Tp;
-    p.work_bytes = ggr_align(p.table_words * 4) + ggr_align(p.gsum_words * 4) + ggr_align(Tp * 4) +
+    // [table | wsum | gsum, total (cleared together by the depth sort's last pass) | rect_sorted]
+    p.work_bytes = ggr_align(p.table_words * 4) + ggr_align(p.wsum_words * 4) + ggr_align((p.gsum_words + Tp) * 4) +
                    ggr_align((P ? P : 1) * sizeof(uint2));
     return p;
 }
@@ -430,16 +435,17 @@ TileListPlan plan_tile_lists(size_t P, size_t T) {
 namespace {
 struct WorkArea {
     uint32_t* table;
-    uint32_t* gsum;
-    uint32_t* tile_start;
+    uint32_t* wsum;
+    uint32_t* gsum;   // [groups][T], then …
+    uint32_t* total;  // … [T]: both accumulated with atomics by K1, so both start from zero
     uint2* rect_sorted;
 };
 WorkArea carve_work(const TileListPlan& pl, void* work, size_t T) {
     WorkArea w;
     char* p = (char*)work;
     w.table = (uint32_t*)p; p += ggr_align(pl.table_words * 4);
-    w.gsum = (uint32_t*)p; p += ggr_align(pl.gsum_words * 4);
-    w.tile_start = (uint32_t*)p; p += ggr_align((T ? T : 1) * 4);
+    w.wsum = (uint32_t*)p; p += ggr_align(pl.wsum_words * 4);
+    w.gsum = (uint32_t*)p; w.total = w.gsum + pl.gsum_words; p += ggr_align((pl.gsum_words + (T ? T : 1)) * 4);
     w.rect_sorted = (uint2*)p;
     return w;
 }
@@ -449,8 +455,8 @@ void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint
                               uint32_t** zero_area, uint32_t* zero_words) {
     const WorkArea w = carve_work(pl, work, T);
     *rect_sorted = w.rect_sorted;
-    *zero_area = w.tile_start;
-    *zero_words = (uint32_t)T;
+    *zero_area = w.gsum;
+    *zero_words = (uint32_t)(pl.gsum_words + T);
 }
 
 void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
@@ -465,15 +471,18 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     }
     if (!rects_gathered)  // (ggr_forward: the depth sort's last pass has done both jobs already)
         hipLaunchKernelGGL(gather_rect_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (uint32_t)P, order,
-                           rect, w.rect_sorted, w.tile_start, (uint32_t)T);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nchunks, pl.nbands), dim3(256),
-                       ((size_t)pl.band_tiles + 4 * (3 * (GGR_BIN_CHUNK / 4) + 64)) * 4, s, (uint32_t)P,
-                       order, w.rect_sorted, (uint32_t)T, pl.band_tiles, (uint32_t)grid_x, w.table);
+                           rect, w.rect_sorted, w.gsum, (uint32_t)(pl.gsum_words + T));
+    // count bands: whole tile rows, at most 256·GGR_COUNT_MAXK tiles each, equal sizes (1080p: two bands of 34 rows)
+    const uint32_t gx = (uint32_t)grid_x, rows = (uint32_t)(T / gx);
+    uint32_t max_rows = (256u * GGR_COUNT_MAXK) / gx;
+    if (max_rows == 0) max_rows = 1;  // (grid_x ≤ 4096 is checked by the caller: image width ≤ 65535 tiles is not enough here)
+    const uint32_t nbands = (rows + max_rows - 1) / max_rows;
+    const uint32_t band_rows = (rows + nbands - 1) / nbands;
+    hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nw, nbands), dim3(256), (size_t)band_rows * gx * 4, s, (uint32_t)P,
+                       w.rect_sorted, (uint32_t)T, gx, rows, band_rows, pl.nchunks, pl.wpg, w.table, w.wsum, w.gsum, w.total);
     const unsigned tb = (unsigned)((T + 255) / 256);
-    hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
-                       pl.chunks_per_group, w.gsum, w.tile_start);
-    hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.table, (uint32_t)T, pl.nchunks,
-                       pl.chunks_per_group, w.gsum, w.tile_start, ranges, total_out, capacity, host_total, sort_fault);
+    hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.wsum, (uint32_t)T, pl.nw,
+                       pl.wpg, w.gsum, w.total, ranges, total_out, capacity, host_total, sort_fault);
     if (after_scan) (void)hipEventRecord(after_scan, s);  // (N is in the host word long before: written by the launch's first block)
 }
 
@@ -486,7 +495,7 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
     const size_t lds = (3 * (size_t)pl.sband_tiles + 4 * (GGR_BIN_CHUNK / GGR_SCATTER_PARTS) + 64) * 4;
     const uint32_t bands8 = (pl.nsbands + 7u) / 8u;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks * bands8 * 8u), dim3(64), lds, s, (uint32_t)P, order,
-                       w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, point_list, capacity,
+                       w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, w.wsum, point_list, capacity,
                        pl.nsbands);
 }
 

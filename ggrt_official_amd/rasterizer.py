@@ -57,6 +57,9 @@ class GaussianRasterizationSettings(NamedTuple):
     sh_channel_major: bool = False              # shs given as [P,3,M] (GGRt's harmonics layout) instead of [P,M,3]
     aux_affine: Optional[tuple] = None          # (a, b): depth output = Σ max(a + b·z/s, 0)·α·T (GGRt's depth pass)
     tanfov: Optional[torch.Tensor] = None       # device [2]: overrides tanfovx / tanfovy without a read-back (camera_setup)
+    scissor: Optional[tuple] = None  # (x0, y0, x1, y1) pixels, half-open: only the tiles overlapping the window are binned
+    #                         and blended (the fine-tune loop's per-cell re-render, finetune_ggrt_stable.py:126-142); inside
+    #                         them the outputs equal the full-frame render bit for bit, other tiles come out as background
     sh_max_degree: int = 3  # highest SH band evaluated.  3 (default): graphdeco and its w-depth forks — the family the
     #                         live call site's signature belongs to (3-tuple return, no `debug`: cuda_splatting.py:101-118)
     #                         — ignore coefficients 16.. (zero gradient); 4: the nine degree-4 terms are evaluated when
@@ -141,7 +144,8 @@ def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view
         sh_stride=int(M), num_points=int(P), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
         scale_modifier=float(rs.scale_modifier), bg=_ptr(bg), viewmatrix=_ptr(view), projmatrix=_ptr(proj),
         campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfov_dev=_ptr(tf),
-        sh_max_degree=int(getattr(rs, "sh_max_degree", 3) or 3))
+        sh_max_degree=int(getattr(rs, "sh_max_degree", 3) or 3),
+        scissor=(C.c_int32 * 4)(*[int(v) for v in (getattr(rs, "scissor", None) or (0, 0, 0, 0))]))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -187,7 +191,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # (needs_input_grad mirrors tensor.requires_grad even under no_grad — the call site's means2D sink always
             #  requires grad — and inside a Function's forward the grad mode is always off: the caller's grad mode
             #  comes in as an argument)
-            infer = (not grad_mode) or not any(ctx.needs_input_grad)
+            infer = (not grad_mode) or not any(getattr(ctx, "needs_input_grad", (True,)))  # (debug_forward_state: plain ctx)
             img = torch.empty((lib.ggr_image_bytes_inference(W, H, 1) if infer else lib.ggr_image_bytes(W, H),),
                               dtype=torch.uint8, device=dev)
             holder = {}

@@ -139,7 +139,7 @@ def adapter_scale_rotation(scales: Tensor, rotations_xyzw: Tensor, c2w_rotations
 
 def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                        gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant=True,
-                       use_sh=True, gaussian_scales=None, gaussian_rotations=None):
+                       use_sh=True, gaussian_scales=None, gaussian_rotations=None, scissor=None):
     """Everything ``render_cuda`` hands to the rasterizer, batched: a list of
     (GaussianRasterizationSettings, kwargs) per view.  Split out so the golden-vector tests can
     compare it with what the reference's call site produces.
@@ -180,7 +180,8 @@ def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, backgroun
         settings = GaussianRasterizationSettings(
             image_height=h, image_width=w, tanfovx=tan_host[i][0], tanfovy=tan_host[i][1],
             bg=background_color[i], scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i],
-            sh_degree=degree, campos=extrinsics[i, :3, 3], prefiltered=False, sh_max_degree=SH_MAX_DEGREE)
+            sh_degree=degree, campos=extrinsics[i, :3, 3], prefiltered=False, sh_max_degree=SH_MAX_DEGREE,
+            **({} if scissor is None else {"scissor": tuple(scissor)}))
         kwargs = dict(means3D=gaussian_means[i], shs=shs[i] if use_sh else None,
                       colors_precomp=None if use_sh else shs[i, :, 0, :],
                       opacities=gaussian_opacities[i, ..., None])
@@ -212,12 +213,17 @@ def _rasterize_views(calls, aux=None):
 def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape, background_color: Tensor,
                 gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
                 gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True,
-                gaussian_scales: Optional[Tensor] = None, gaussian_rotations: Optional[Tensor] = None) -> Tensor:
+                gaussian_scales: Optional[Tensor] = None, gaussian_rotations: Optional[Tensor] = None,
+                scissor=None) -> Tensor:
     """[batch] views → [batch,3,h,w] (reference ``cuda_splatting.py:49-128``).  With
-    ``gaussian_covariances=None`` the ellipsoids come as scales + world quaternions (§8f-4)."""
+    ``gaussian_covariances=None`` the ellipsoids come as scales + world quaternions (§8f-4).
+
+    ``scissor=(x0, y0, x1, y1)`` (extension): render only the tiles overlapping that pixel window — for the
+    fine-tune loop's deferred back-propagation (``finetune_ggrt_stable.py:126-142``), which renders the whole frame
+    per crop cell and slices one cell out.  Inside the window the image equals the full render bit for bit."""
     calls = boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                                gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant,
-                               use_sh, gaussian_scales, gaussian_rotations)
+                               use_sh, gaussian_scales, gaussian_rotations, scissor)
     return torch.stack([o[0] for o in _rasterize_views(calls)])
 
 
@@ -282,7 +288,7 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
 def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape,
                        background_color: Tensor, gaussians: Gaussians, view_to_batch,
                        depth_mode: Optional[DepthRenderingMode] = None, scale_invariant: bool = True,
-                       device_camera: bool = True, list_capacity: int = 0, batched: bool = True):
+                       device_camera: bool = True, list_capacity: int = 0, batched: bool = True, scissor=None):
     """The call site with NO torch operation on a Gaussian-sized tensor (SURVEY.md §8 a2 "where time goes"):
 
     * ``device_camera``: view / projection matrices, camera position, tan(fov/2) and 1/near of all views come
@@ -370,7 +376,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
             image_height=h, image_width=w, tanfovx=0.0, tanfovy=0.0, bg=background_color[idx[0]], scale_modifier=1.0,
             viewmatrix=view[idx[0]], projmatrix=full[idx[0]], sh_degree=degree, campos=campos[idx[0]],
             prefiltered=False, list_capacity=list_capacity * len(idx), sh_channel_major=True, aux_affine=aux_affine,
-            sh_max_degree=SH_MAX_DEGREE)
+            sh_max_degree=SH_MAX_DEGREE, scissor=None if scissor is None else tuple(scissor))
         kw = dict(cov3D_precomp=g_cov[b]) if fused_cov else dict(scales=g_scales[b], rotations=g_rot[b])
         col, _, dep = rasterize_views(g_means[b], g_op[b][..., None], take(view), take(full), take(campos),
                                       take(background_color), tf, settings, shs=g_sh[b], aux_precomp=aux,
@@ -393,7 +399,8 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
             scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i], sh_degree=degree,
             campos=campos[i], prefiltered=False, list_capacity=list_capacity,
             input_scale=None if scale is None else scale[i:i + 1], sh_channel_major=True, aux_affine=aux_affine,
-            tanfov=None if tanfov is None else tanfov[i], sh_max_degree=SH_MAX_DEGREE)
+            tanfov=None if tanfov is None else tanfov[i], sh_max_degree=SH_MAX_DEGREE,
+            scissor=None if scissor is None else tuple(scissor))
         means = g_means[b]
         kw = dict(cov3D_precomp=g_cov[b]) if fused_cov else dict(scales=g_scales[b], rotations=g_rot[b])
         # means2D is only a gradient sink (`cuda_splatting.py:95-99`): its values are never read
@@ -440,14 +447,19 @@ class DecoderSplattingCUDA(nn.Module):
                     gaussian_rotations=cls._per_view(gaussians.rotations, v))
 
     def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
-                image_shape, depth_mode: Optional[DepthRenderingMode] = None) -> DecoderOutput:
+                image_shape, depth_mode: Optional[DepthRenderingMode] = None, scissor=None) -> DecoderOutput:
+        """``scissor=(x0, y0, x1, y1)`` (extension, fused path): render only that pixel window's tiles — the
+        deferred-backprop cell of ``finetune_ggrt_stable.py:126-142``."""
         b, v = extrinsics.shape[:2]
+        if scissor is not None and not (self.fused_inputs and self.fused_depth):
+            raise ValueError("scissor needs the fused call site (fused_inputs and fused_depth)")
         bg = self.background_color.to(far.device)[None].expand(b * v, 3)
         if self.fused_inputs and self.fused_depth:
             # no per-view copies of the Gaussians, no torch op on a Gaussian-sized tensor (render_views_fused)
             color, depth = render_views_fused(
                 extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(), image_shape, bg,
-                gaussians, [n // v for n in range(b * v)], depth_mode, list_capacity=self.list_capacity)
+                gaussians, [n // v for n in range(b * v)], depth_mode, list_capacity=self.list_capacity,
+                scissor=scissor)
             return DecoderOutput(color.reshape(b, v, *color.shape[1:]),
                                  None if depth is None else depth.reshape(b, v, *depth.shape[1:]))
         if depth_mode is not None and self.fused_depth:

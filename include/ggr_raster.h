@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 5
+#define GGR_ABI_VERSION 6
 
 enum {
     GGR_OK = 0,
@@ -70,6 +70,14 @@ typedef struct GgrSettings {
                                 cuda_splatting.py:101-118), hence the default.  4: the nine
                                 degree-4 terms are evaluated and differentiated when D >= 4 and M >= 25 — for a
                                 host whose installed rasterizer does evaluate band 4 (not verifiable in this build). */
+    int32_t scissor[4];      /* x0, y0, x1, y1 in pixels, half-open; all zero = the whole image (upstream).  Extension for
+                                the reference's deferred back-propagation loop (finetune_ggrt_stable.py:126-142), which
+                                re-renders the WHOLE frame per crop cell and keeps one cell: only the 16x16 tiles that
+                                overlap the window are binned and blended — inside them every output equals the
+                                full-frame render bit for bit; pixels of other tiles come out as background
+                                (final_T = 1, no contributors), and `radii` / visibility refer to the window (a
+                                Gaussian that touches no window tile gets radius 0 and no gradient).  The backward
+                                needs no scissor: it skips tiles and quadrants whose upstream gradient is all zero. */
 } GgrSettings;
 
 /* Inputs of GaussianRasterizer.forward (cuda_splatting.py:118-125).

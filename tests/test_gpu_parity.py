@@ -71,7 +71,7 @@ def test_forward_backward_sh_cov(P, W, H, D, profile, seed):
         check_image(color4, st4.color)
         check_grads(grads4, ref4, ["means3D", "shs"])
         assert np.any(grads4["shs"][:, 16:, :] != 0)
-        assert np.abs(color4 - color).max() > 1e-3
+        assert np.abs(color4 - color).max() > 1e-5
 
 
 def test_forward_backward_colors_precomp_scale_rot():
