@@ -38,7 +38,7 @@ class GgrForwardIn(C.Structure):
 class GgrViews(C.Structure):
     _fields_ = [
         ("num_views", C.c_int32), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-        ("bg", C.c_void_p), ("tanfov", C.c_void_p), ("input_scale", C.c_void_p),
+        ("bg", C.c_void_p), ("tanfov", C.c_void_p), ("input_scale", C.c_void_p), ("num_sets", C.c_int32),
     ]
 
 

@@ -81,7 +81,7 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
         return fail(GGR_E_INVALID, "sh_stride %d too small for sh_degree %d", st->sh_stride, st->sh_degree);
     const int64_t tiles = (int64_t)((st->image_width + GGR_TILE - 1) / GGR_TILE) * ((st->image_height + GGR_TILE - 1) / GGR_TILE);
     if (tiles > (1 << 24)) return fail(GGR_E_LIMIT, "image has %lld tiles; at most 2^24 supported", (long long)tiles);
-    if (st->image_width > 4608 * GGR_TILE || st->image_height > 65535 * GGR_TILE)  // (a tile row must fit one count band)
+    if (st->image_width > 768 * GGR_TILE || st->image_height > 65535 * GGR_TILE)  // (a tile row must fit a count wave's slots)
         return fail(GGR_E_LIMIT, "image too large");
     return GGR_OK;
 }
@@ -141,8 +141,11 @@ int wait_readback(volatile uint32_t* hw, ReadbackQueryFn query, void* ctx, doubl
 }
 hipError_t query_event(void* ev) { return hipEventQuery((hipEvent_t)ev); }
 
-InputForm input_form(const GgrSettings* st, const GgrForwardIn* in) {
+InputForm input_form(const GgrSettings* st, const GgrForwardIn* in, int sets, const void* dL_dshs = nullptr) {
     InputForm f;
+    // flat float4 staging of odd-length SH rows needs every set's rows (and gradient rows) to start 16-B aligned
+    f.sh_aligned = (((uintptr_t)in->shs | (uintptr_t)dL_dshs) & 15) == 0 &&
+                   (sets <= 1 || ((int64_t)st->num_points * st->sh_stride * 3) % 4 == 0);
     f.cov_stride = in->cov3D_full ? 9 : 6;
     f.sh_channel_major = in->sh_channel_major ? 1 : 0;
     f.aux_affine = (in->aux_affine && !in->aux_precomp) ? 1 : 0;
@@ -164,7 +167,7 @@ size_t tiles_of(int W, int H) { return (size_t)((W + GGR_TILE - 1) / GGR_TILE) *
 // the reference's call: one camera, taken from the settings
 ViewSet single_view(const GgrSettings* st, const GgrForwardIn* in) {
     ViewSet vs;
-    vs.V = 1;
+    vs.V = 1; vs.sets = 1; vs.vps = 1;
     vs.view = st->viewmatrix; vs.proj = st->projmatrix; vs.campos = st->campos; vs.bg = st->bg;
     vs.tanfov = st->tanfov_dev; vs.input_scale = in->input_scale;
     vs.tanfovx = st->tanfovx; vs.tanfovy = st->tanfovy;
@@ -176,11 +179,14 @@ int view_set(const GgrSettings* st, const GgrViews* v, ViewSet* vs) {
     if (!v->viewmatrix || !v->projmatrix || !v->campos || !v->bg)
         return fail(GGR_E_INVALID, "GgrViews: null camera array");
     const int64_t V = v->num_views;
+    const int64_t sets = v->num_sets > 1 ? v->num_sets : 1;
+    if (V % sets != 0) return fail(GGR_E_INVALID, "GgrViews: num_views must be a multiple of num_sets");
+    if (sets > GGR_SORT_MAX_SEGMENTS) return fail(GGR_E_LIMIT, "GgrViews: at most 64 Gaussian sets per launch set");
     const int64_t gy = (st->image_height + GGR_TILE - 1) / GGR_TILE;
     if (V * st->num_points >= 0x7FFFFFFFll) return fail(GGR_E_LIMIT, "num_views x num_points too large");
     if (V * gy > 65535) return fail(GGR_E_LIMIT, "num_views x tile rows exceeds 65535");
     if (V * (int64_t)tiles_of(st->image_width, st->image_height) > (1 << 24)) return fail(GGR_E_LIMIT, "more than 2^24 tiles over all views");
-    vs->V = (int)V;
+    vs->V = (int)V; vs->sets = (int)sets; vs->vps = (int)(V / sets);
     vs->view = v->viewmatrix; vs->proj = v->projmatrix; vs->campos = v->campos; vs->bg = v->bg;
     vs->tanfov = v->tanfov; vs->input_scale = v->input_scale;
     vs->tanfovx = st->tanfovx; vs->tanfovy = st->tanfovy;
@@ -229,7 +235,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // 1. per-Gaussian projection
     ggr::launch_preprocess_fwd(P1, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
                                in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
-                               in->aux_precomp, vs, W, H, out->radii, g, input_form(st, in), s);
+                               in->aux_precomp, vs, W, H, out->radii, g, input_form(st, in, vs.sets), s);
     KCHECK(dbg, s, "preprocess_fwd");
     tm.mark();
 
@@ -246,7 +252,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         // (preprocess already wrote the keys into g.keys_a and the identity permutation into g.vals_a)
         ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, (uint32_t)segs, &dk, &order, s,
                               /*hist_zeroed=*/true /*by preprocess_fwd*/,
-                              /*block_max_ready=*/(uint32_t)((P1 + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS) /*likewise*/,
+                              /*block_max_ready=*/(uint32_t)((P1 + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS) * (uint32_t)vs.sets /*likewise*/,
                               g.rect, rect_sorted, zero_area, zero_words);
         KCHECK(dbg, s, "depth sort");
     }
@@ -378,7 +384,7 @@ int backward_impl(const GgrSettings* st, const ViewSet& vs, const GgrBackwardIn*
                                out->dL_dopacities, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,
                                out->dL_dscales, out->dL_drotations, in->fwd.aux_precomp ? out->dL_daux : nullptr,
                                npose ? sc.pose_acc : nullptr, out->dL_dviewmatrix, out->dL_dprojmatrix,
-                               out->dL_dcampos, input_form(st, &in->fwd), in->fwd.cov3D_precomp ? 1 : 0, s);
+                               out->dL_dcampos, input_form(st, &in->fwd, vs.sets, out->dL_dshs), in->fwd.cov3D_precomp ? 1 : 0, s);
     KCHECK(dbg, s, "preprocess_bwd");
     tm.mark();
     return GGR_OK;

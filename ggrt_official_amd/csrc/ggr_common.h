@@ -55,7 +55,9 @@
 #ifndef GGR_BIN_CHUNK
 #define GGR_BIN_CHUNK 1024
 #endif
+#ifndef GGR_COUNT_CPG
 #define GGR_COUNT_CPG 4    // chunks per workgroup of the count kernel (their running per-tile counts stay in registers)
+#endif
 #define GGR_COUNT_GROUPS 8 // groups of count workgroups: the prefix over workgroups runs per group (T·groups-way parallel)
 
 static inline size_t ggr_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -92,7 +94,8 @@ static inline size_t ggr_sort_zero_words(size_t n, size_t S = 1) {
     return ggr_sort_status_base(S) + (size_t)GGR_SORT_PASSES * S * tps * GGR_SORT_MAX_BINS * levels;
 }
 static inline size_t ggr_sort_hist_words(size_t n, size_t S = 1) {
-    return ggr_sort_zero_words(n, S) + ((n ? n : 1) + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS;
+    // (+ S: a launch set of several Gaussian sets rounds its preprocess blocks up per set — at most one block per view more)
+    return ggr_sort_zero_words(n, S) + ((n ? n : 1) + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS + GGR_SORT_MAX_SEGMENTS;
 }
 
 struct GeomLayout {
@@ -219,6 +222,7 @@ struct InputForm {
     float aux_a, aux_b;        //    (:240-269: depth as a degree-0 SH coefficient) without a per-Gaussian tensor
     int sh_cap;                // highest SH band evaluated: 3 (graphdeco / w-depth family, default) or 4
     int sc_x0, sc_y0, sc_x1, sc_y1;  // GgrSettings.scissor in TILES, half-open, inside the tile grid (whole grid = none)
+    int sh_aligned;            // every set's SH rows (and gradient rows) start 16-B aligned: flat float4 staging allowed
 };
 
 // The cameras of one launch set: V views of the SAME P Gaussians (V = 1: the reference's call).  Per-Gaussian state of
@@ -227,6 +231,8 @@ struct InputForm {
 // (replaces the per-view loop of reference cuda_splatting.py:93-127).
 struct ViewSet {
     int V;
+    int sets, vps;             // the V views are `sets` groups of `vps` views; group b renders Gaussian set b of the
+                               // caller's [sets, P, …] inputs (sets = 1: every view renders the same P Gaussians)
     const float* view;         // device [V,16]
     const float* proj;         // device [V,16]
     const float* campos;       // device [V,3]

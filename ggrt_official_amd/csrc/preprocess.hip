@@ -106,7 +106,26 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_row_stride]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // zero the depth sort's histogram / ticket / look-back words here instead of with a separate fill launch
-    for (uint32_t wz = (uint32_t)i; wz < zero_words; wz += gridDim.x * blockDim.x) zero_area[wz] = 0u;
+    for (uint32_t wz = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; wz < zero_words;
+         wz += gridDim.x * gridDim.y * blockDim.x)
+        zero_area[wz] = 0u;
+    // ---- Gaussian set blockIdx.y of the launch set (ViewSet.sets; one set: nothing moves) ----------------------------
+    // The set's inputs are rows [set·P, (set+1)·P) of the caller's arrays, its views are views [v0, v0 + vps): every
+    // pointer is rebased once, here, so that the rest of the kernel indexes (view, Gaussian) relative to the set.
+    const int set = (int)blockIdx.y, v0 = set * vs.vps;
+    const size_t in_off = (size_t)set * (size_t)P, st_off = (size_t)v0 * (size_t)P;  // input rows / per-view state rows
+    means3D += 3 * in_off; opacities += in_off;
+    if (shs) shs += in_off * (size_t)M * 3;
+    if (colors_precomp) colors_precomp += 3 * in_off;
+    if (cov3D_precomp) cov3D_precomp += (size_t)inf.cov_stride * in_off;
+    if (scales) { scales += 3 * in_off; rotations += 4 * in_off; }
+    if (aux_precomp) aux_precomp += st_off;
+    radii += st_off; splat += 3 * st_off; depth_key += st_off; sort_vals += st_off; tiles_touched += st_off;
+    rect += st_off; clamped_out += st_off;
+    if (cov3D_out) cov3D_out += 6 * st_off;
+    vs.view += 16 * v0; vs.proj += 16 * v0; vs.campos += 3 * v0;
+    if (vs.tanfov) vs.tanfov += 2 * v0;
+    if (vs.input_scale) vs.input_scale += v0;
     // Cooperative, coalesced staging of the block's SH rows (the per-Gaussian row is 12·K bytes: read
     // lane-per-Gaussian it would touch 64 different cache lines per load instruction).
     const int sh_deg = ggr_sh_degree(D, shs ? M : 25, inf.sh_cap);
@@ -114,7 +133,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // odd row length (GGRt: 3·M = 75 floats): the block's rows are ONE contiguous, 16-B aligned region (g0 is
     // a multiple of 256) → copy it flat with float4 loads; an odd LDS stride is already conflict-free for
     // the per-lane row reads, so nothing needs repacking.  Otherwise repack to the odd stride 3K | 1.
-    const bool sh_flat = ((M * 3) & 1) != 0 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0;
+    const bool sh_flat = ((M * 3) & 1) != 0 && inf.sh_aligned != 0;
     // channel-major rows ([3][M], GGRt's harmonics layout): coefficient k of channel c sits at c·M + k, so the
     // whole row is staged; k-major rows ([M][3], upstream) only need their first 3K floats
     const int copy_row = inf.sh_channel_major ? M * 3 : sh_rowf;
@@ -164,9 +183,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     uint32_t km = 0u;  // largest sort key of this thread over all views
 
     // ---- one pass per view: the Gaussian's inputs (and its SH row in LDS) are read ONCE for all of them ----------
-    const int NV = MULTI ? vs.V : 1;
+    const int NV = MULTI ? vs.vps : 1;
 #pragma clang loop unroll(disable)
-    for (int v = 0; v < NV; v++) {
+    for (int v = 0; v < NV; v++) {   // (v: view inside the set; its global index is v0 + v)
         float V[16], PM[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) { V[k] = vs.view[16 * v + k]; PM[k] = vs.proj[16 * v + k]; }
@@ -266,7 +285,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     key_out = min(__float_as_uint(t2) - GGR_KEY_BASE, GGR_KEY_MAX);
                     tiles_out = (uint32_t)area;
                     // tile rows of view v sit below those of views 0 … v-1 in the virtual stacked image
-                    const uint32_t yo = (uint32_t)(v * gy);
+                    const uint32_t yo = (uint32_t)((v0 + v) * gy);
                     rect_out = make_uint2((uint32_t)rminx | (((uint32_t)rminy + yo) << 16),
                                           (uint32_t)rmaxx | (((uint32_t)rmaxy + yo) << 16));
                 }
@@ -335,7 +354,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (in_range) {
             radii[o] = rad_out;
             depth_key[o] = key_out;       // written straight into the depth sort's key / value input buffers
-            sort_vals[o] = (uint32_t)o;   // (saves a device memcpy and an iota launch)
+            sort_vals[o] = (uint32_t)(st_off + o);   // global (view, Gaussian) index (saves a device memcpy and an iota launch)
             tiles_touched[o] = tiles_out;
             rect[o] = rect_out;
             clamped_out[o] = clamp_bits;
@@ -351,7 +370,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     for (int off = 32; off > 0; off >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, off));
     if ((threadIdx.x & 63) == 0) kmax[threadIdx.x >> 6] = km;
     __syncthreads();
-    if (threadIdx.x == 0) block_max[blockIdx.x] = max(max(kmax[0], kmax[1]), max(kmax[2], kmax[3]));
+    if (threadIdx.x == 0) block_max[blockIdx.y * gridDim.x + blockIdx.x] = max(max(kmax[0], kmax[1]), max(kmax[2], kmax[3]));
 }
 
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
@@ -365,20 +384,20 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     const int threads = GGR_PRE_THREADS;
     const int blocks = (P + threads - 1) / threads;
     const int deg = ggr_sh_degree(D, shs ? M : 25, inf.sh_cap);
-    const bool flat = ((3 * M) & 1) && (reinterpret_cast<uintptr_t>(shs) & 15) == 0;  // same predicate as the kernel
+    const bool flat = ((3 * M) & 1) && inf.sh_aligned;  // same predicate as the kernel
     const size_t copy_row = inf.sh_channel_major ? (size_t)(3 * M) : (size_t)(3 * (deg + 1) * (deg + 1));
     const size_t rowf = (size_t)(3 * (deg + 1) * (deg + 1));
     const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
     const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
     // one view at degree 3 / 4: the rows go through LDS a third at a time (see the kernel's header)
-    const int kc = (shs && vs.V == 1 && (deg == 3 || deg == 4)) ? (deg + 1) * (deg + 1) : 0;
+    const int kc = (shs && vs.vps == 1 && (deg == 3 || deg == 4)) ? (deg + 1) * (deg + 1) : 0;
     const size_t lds = !shs ? 0 : kc ? (size_t)threads * (kc | 1) * sizeof(float) : (size_t)threads * row_stride * sizeof(float);
 #define GGR_LAUNCH_PFWD(MULTI_, KC_)                                                                                      \
-    hipLaunchKernelGGL((preprocess_fwd_kernel<MULTI_, KC_>), dim3(blocks), dim3(threads), lds, s, P, D, M, means3D, shs,  \
+    hipLaunchKernelGGL((preprocess_fwd_kernel<MULTI_, KC_>), dim3(blocks, vs.sets), dim3(threads), lds, s, P, D, M, means3D, shs,  \
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp, aux_precomp, vs, W, H, \
                        radii, g.splat, g.keys_a, g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D, g.hist,          \
                        zero_words, g.hist + zero_words, inf)
-    if (vs.V > 1) GGR_LAUNCH_PFWD(true, 0);
+    if (vs.vps > 1) GGR_LAUNCH_PFWD(true, 0);
     else if (kc == 16) GGR_LAUNCH_PFWD(false, 16);
     else if (kc == 25) GGR_LAUNCH_PFWD(false, 25);
     else GGR_LAUNCH_PFWD(false, 0);

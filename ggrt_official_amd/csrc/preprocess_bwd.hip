@@ -151,7 +151,29 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_stride]: SH in, dL/dSH out
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
-    const int NV = MULTI ? vs.V : 1;
+    const int NV = MULTI ? vs.vps : 1;
+    // ---- Gaussian set blockIdx.y of the launch set (as in preprocess_fwd): inputs and gradients are rows
+    // [set·P, (set+1)·P) of the caller's arrays, the set's views are views [v0, v0 + vps) — every pointer is rebased here
+    {
+        const int set = (int)blockIdx.y, v0 = set * vs.vps;
+        const size_t in_off = (size_t)set * (size_t)P, st_off = (size_t)v0 * (size_t)P;
+        means3D += 3 * in_off;
+        if (shs) shs += in_off * (size_t)M * 3;
+        if (scales) { scales += 3 * in_off; rotations += 4 * in_off; }
+        if (cov3D) cov3D += cov_is_input ? (size_t)inf.cov_stride * in_off : 6 * st_off;
+        radii += st_off; clamped += st_off; grad2d += GGR_G2D_STRIDE * st_off;
+        dL_dmeans2D += 3 * st_off;
+        if (dL_daux) dL_daux += st_off;
+        dL_dmeans3D += 3 * in_off; dL_dopacity += in_off;
+        if (dL_dsh) dL_dsh += in_off * (size_t)M * 3;
+        if (dL_dcolors_precomp) dL_dcolors_precomp += 3 * in_off;
+        if (dL_dcov3D) dL_dcov3D += (size_t)(cov_is_input ? inf.cov_stride : 6) * in_off;
+        if (dL_dscales) { dL_dscales += 3 * in_off; dL_drotations += 4 * in_off; }
+        if (pose_acc) pose_acc += (size_t)v0 * gridDim.x * 64;
+        vs.view += 16 * v0; vs.proj += 16 * v0; vs.campos += 3 * v0;
+        if (vs.tanfov) vs.tanfov += 2 * v0;
+        if (vs.input_scale) vs.input_scale += v0;
+    }
     // coalesced staging of the block's SH rows (same reason as in preprocess_fwd)
     const bool use_sh = !has_colors_precomp && shs != nullptr;
     const int deg = ggr_sh_degree(D, use_sh ? M : 25, inf.sh_cap);
@@ -161,7 +183,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const size_t sh_row = (size_t)M * 3;
     // odd row length (GGRt: 3·M = 75): the block's rows are ONE contiguous 16-B aligned region (g0 is a
     // multiple of 256) → flat float4 copy in and out; an odd LDS stride is conflict-free as it is
-    const bool sh_flat = (sh_row & 1) != 0 && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
+    const bool sh_flat = (sh_row & 1) != 0 && inf.sh_aligned != 0;
     // (input forms as in preprocess_fwd: channel-major rows are staged — and their gradient written — whole)
     const int copy_row = inf.sh_channel_major ? (int)sh_row : sh_rowf;
     // rows longer than what is used (GGRt with sh_max_degree 3: 25 coefficients, 16 used): only the used 3K floats live in LDS
@@ -753,20 +775,20 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     if (P <= 0) return;
     const int blocks = (P + 255) / 256;
     const int deg = ggr_sh_degree(D, (!has_colors_precomp && shs) ? M : 25, inf.sh_cap);
-    const bool flat = ((3 * M) & 1) && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
+    const bool flat = ((3 * M) & 1) && inf.sh_aligned;
     const size_t copy_row = inf.sh_channel_major ? (size_t)(3 * M) : (size_t)(3 * (deg + 1) * (deg + 1));
     const size_t rowf = (size_t)(3 * (deg + 1) * (deg + 1));
     const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
     const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
-    const bool multi = vs.V > 1;
+    const bool multi = vs.vps > 1;
     // one view at degree 3 / 4 with long rows: rows read by thirds, gradient rows written by row ranges (kernel header)
     const bool use_sh = !has_colors_precomp && shs;
     const int kc = (use_sh && !multi && (deg == 3 || deg == 4) && 3 * M > 64 &&
-                    (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0) ? (deg + 1) * (deg + 1) : 0;
+                    inf.sh_aligned) ? (deg + 1) * (deg + 1) : 0;
     const size_t lds = !use_sh ? 0 : kc ? sizeof(float) * (size_t)std::max(256 * (kc | 1), 88 * 3 * M)
                                         : (size_t)256 * row_stride * sizeof(float);
 #define GGR_LAUNCH_PBWD(POSE_, MULTI_, KC_, CM_)                                                                            \
-    hipLaunchKernelGGL((preprocess_bwd_kernel<POSE_, MULTI_, KC_, CM_>), dim3(blocks), dim3(256), lds, s, P, D, M, means3D, shs, \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<POSE_, MULTI_, KC_, CM_>), dim3(blocks, vs.sets), dim3(256), lds, s, P, D, M, means3D, shs, \
                        has_colors_precomp, scales, rotations, scale_modifier, cov3D, vs, W, H, radii, clamped, grad2d,     \
                        has_dz, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales,   \
                        dL_drotations, dL_daux, pose_acc, inf, cov_is_input)

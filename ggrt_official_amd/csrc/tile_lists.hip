@@ -70,20 +70,21 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 // consecutive chunks of one band of tile ROWS and keeps, per tile, the running count over its chunks in registers:
 //   table[c][t]  = entries of the workgroup's EARLIER chunks in tile t        (exclusive prefix inside the workgroup)
 //   wsum[w][t]   = entries of all its chunks                                  (K2 turns it into the absolute base)
-//   gsum[g][t]  += the same, per group g of workgroups;  total[t] += the same (atomics, one pair per workgroup and tile)
-// which removes round 2's separate group-sum launch and two of its three sweeps over the 32 MB table.
-#define GGR_COUNT_MAXK 18  // tiles per thread: a band holds at most 256·18 = 4608 tiles
+// so that K2 sweeps the 8 MB of wsum instead of the 32 MB table (round 2: 27 + 8 + 15.5 µs → 21 + 5.4 + 11.9 µs at C3).
+#define GGR_COUNT_SLOTS 12  // (row, 64-tile piece) pairs per wave: bounds the band, = registers for the running counts
 __global__ void __launch_bounds__(256)
 bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, uint32_t T, uint32_t grid_x,
-                 uint32_t rows_total, uint32_t band_rows, uint32_t nchunks, uint32_t wpg, uint32_t* __restrict__ table,
-                 uint32_t* __restrict__ wsum, uint32_t* __restrict__ gsum, uint32_t* __restrict__ total) {
-    extern __shared__ uint32_t grid[];  // [band_rows][grid_x] corner deltas → counts
+                 uint32_t rows_total, uint32_t band_rows, uint32_t nchunks, uint32_t* __restrict__ table,
+                 uint32_t* __restrict__ wsum) {
+    extern __shared__ uint32_t grid[];  // [band_rows][grid_x] corner deltas → column prefixes
     const uint32_t w = blockIdx.x, band = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t r0 = band * band_rows, r1 = min(rows_total, r0 + band_rows), nr = r1 - r0;
     const uint32_t cells = nr * grid_x, tile0 = r0 * grid_x;
-    uint32_t run[GGR_COUNT_MAXK];
+    const uint32_t pieces = (grid_x + 63u) >> 6;
+    // slot k of this wave = (row wave + 4·(k / pieces), tiles [64·(k mod pieces), +64) of it); lane = tile inside the piece
+    uint32_t run[GGR_COUNT_SLOTS];
 #pragma unroll
-    for (int k = 0; k < GGR_COUNT_MAXK; k++) run[k] = 0u;
+    for (int k = 0; k < GGR_COUNT_SLOTS; k++) run[k] = 0u;
     constexpr uint32_t PER_THREAD = GGR_BIN_CHUNK / 256;
     const uint32_t c_first = w * GGR_COUNT_CPG, c_end = min(nchunks, c_first + GGR_COUNT_CPG);
     uint2 rc[PER_THREAD];
@@ -120,50 +121,73 @@ bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, 
             }
         }
         __syncthreads();
-        // prefix along x: one wave per row, 64 tiles per step
-        for (uint32_t row = wave; row < nr; row += 4) {
-            uint32_t carry = 0u;
-            for (uint32_t xb = 0; xb < grid_x; xb += 64) {
-                const uint32_t x = xb + lane;
-                const uint32_t v = x < grid_x ? grid[row * grid_x + x] : 0u;
-                const uint32_t incl = wave_scan_add(v) + carry;
-                if (x < grid_x) grid[row * grid_x + x] = incl;
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-        }
-        __syncthreads();
-        // prefix along y: one thread per column (consecutive lanes, consecutive words)
+        // prefix along y, in place: one thread per column (consecutive lanes, consecutive words), 8 rows' loads in
+        // flight at a time (one LDS round trip per 8 rows instead of one per row)
         for (uint32_t x = tid; x < grid_x; x += 256) {
             uint32_t acc = 0u;
-            for (uint32_t row = 0; row < nr; row++) {
-                acc += grid[row * grid_x + x];
-                grid[row * grid_x + x] = acc;
+            for (uint32_t rb = 0; rb < nr; rb += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) v[u] = rb + u < nr ? grid[(rb + u) * grid_x + x] : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) {
+                    acc += v[u];
+                    if (rb + u < nr) grid[(rb + u) * grid_x + x] = acc;
+                }
             }
         }
         __syncthreads();
+        // prefix along x straight into the table: a wave per row, 64 tiles per piece, every slot's loads issued first
         uint32_t* trow = table + (size_t)c * T + tile0;
+        uint32_t v[GGR_COUNT_SLOTS];
 #pragma unroll
-        for (int k = 0; k < GGR_COUNT_MAXK; k++) {
-            const uint32_t i = (uint32_t)k * 256u + tid;
-            if (i < cells) {
-                trow[i] = run[k];
-                run[k] += grid[i];
+        for (int k = 0; k < GGR_COUNT_SLOTS; k++) {
+            const uint32_t row = wave + 4u * ((uint32_t)k / pieces), x = (((uint32_t)k % pieces) << 6) + lane;
+            v[k] = (row < nr && x < grid_x) ? grid[row * grid_x + x] : 0u;
+        }
+        uint32_t carry = 0u;
+#pragma unroll
+        for (int k = 0; k < GGR_COUNT_SLOTS; k++) {
+            const uint32_t piece = (uint32_t)k % pieces;
+            const uint32_t row = wave + 4u * ((uint32_t)k / pieces), x = (piece << 6) + lane;
+            if (piece == 0u) carry = 0u;
+            const uint32_t incl = wave_scan_add(v[k]) + carry;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (row < nr && x < grid_x) {
+                trow[row * grid_x + x] = run[k];
+                run[k] += incl;
             }
         }
         __syncthreads();  // (the next chunk clears the grid)
     }
-    const size_t wo = (size_t)w * T + tile0, go = (size_t)(w / wpg) * T + tile0;
+    const size_t wo = (size_t)w * T + tile0;
 #pragma unroll
-    for (int k = 0; k < GGR_COUNT_MAXK; k++) {
-        const uint32_t i = (uint32_t)k * 256u + tid;
-        if (i < cells) {
+    for (int k = 0; k < GGR_COUNT_SLOTS; k++) {
+        const uint32_t row = wave + 4u * ((uint32_t)k / pieces), x = (((uint32_t)k % pieces) << 6) + lane;
+        if (row < nr && x < grid_x) {
+            const uint32_t i = row * grid_x + x;
             wsum[wo + i] = run[k];
-            if (run[k]) { atomicAdd(&gsum[go + i], run[k]); atomicAdd(&total[tile0 + i], run[k]); }
         }
     }
 }
 
-// ---- K2: wsum[w][t] ← absolute list position of workgroup w's first entry in tile t; tile ranges; N -------------------
+// ---- K2a: per (tile, group of count workgroups) sum; per-tile totals ----------------------------------------------
+// (Folded into K1 as one atomic pair per workgroup and tile it cost 17 µs of atomic line transactions at C3 — 4 M lanes,
+//  0.25 M lines — against 7 µs for this launch, which reads the 8 MB of wsum once.)
+__global__ void __launch_bounds__(256)
+bin_group_sum_kernel(const uint32_t* __restrict__ wsum, uint32_t T, uint32_t nw, uint32_t wpg,
+                     uint32_t* __restrict__ gsum /*[G][T]*/, uint32_t* __restrict__ total /*[T], zeroed*/) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (t >= T) return;
+    const uint32_t w0 = g * wpg, w1 = min(nw, w0 + wpg);
+    uint32_t s = 0;
+#pragma unroll 8
+    for (uint32_t w = w0; w < w1; w++) s += wsum[(size_t)w * T + t];
+    gsum[(size_t)g * T + t] = s;
+    if (s) atomicAdd(&total[t], s);  // G atomics per tile at most
+}
+
+// ---- K2b: wsum[w][t] ← absolute list position of workgroup w's first entry in tile t; tile ranges; N -------------------
 // Every block forms the start of ITS 256 tiles itself: Σ totals of all tiles before them (≤ 32 KB from L2, 32 loads per
 // thread in flight) + a block scan of its own (a single-block scan launch cost ≈ 11 µs for ≈ 3 µs of work).  The blocks
 // of group 0 write the tile ranges; block (0, 0) — dispatched first — is the one that owns the LAST tiles, so N reaches
@@ -472,15 +496,23 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     if (!rects_gathered)  // (ggr_forward: the depth sort's last pass has done both jobs already)
         hipLaunchKernelGGL(gather_rect_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (uint32_t)P, order,
                            rect, w.rect_sorted, w.gsum, (uint32_t)(pl.gsum_words + T));
-    // count bands: whole tile rows, at most 256·GGR_COUNT_MAXK tiles each, equal sizes (1080p: two bands of 34 rows)
+    // count bands: whole tile rows; a wave holds the running counts of its (row, 64-tile piece) slots in registers, so a
+    // band has at most 4·⌊GGR_COUNT_SLOTS / pieces⌋ rows — and few enough that the launch has ≳ 1000 workgroups (the
+    // kernel is a chain of LDS round trips and barriers: it needs several workgroups per CU).  1080p, 1 M Gaussians:
+    // 245 workgroups of 4 chunks × 4 bands of 17 rows.
     const uint32_t gx = (uint32_t)grid_x, rows = (uint32_t)(T / gx);
-    uint32_t max_rows = (256u * GGR_COUNT_MAXK) / gx;
-    if (max_rows == 0) max_rows = 1;  // (grid_x ≤ 4096 is checked by the caller: image width ≤ 65535 tiles is not enough here)
-    const uint32_t nbands = (rows + max_rows - 1) / max_rows;
+    const uint32_t pieces = (gx + 63u) / 64u;
+    const uint32_t max_rows = 4u * (GGR_COUNT_SLOTS / pieces);  // (pieces ≤ GGR_COUNT_SLOTS: image width ≤ 768 tiles, api.hip)
+    uint32_t nbands = (rows + max_rows - 1) / max_rows;
+    const uint32_t want = (1000u + pl.nw - 1) / pl.nw;
+    if (nbands < want) nbands = want < rows ? want : rows;
     const uint32_t band_rows = (rows + nbands - 1) / nbands;
+    nbands = (rows + band_rows - 1) / band_rows;
     hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nw, nbands), dim3(256), (size_t)band_rows * gx * 4, s, (uint32_t)P,
-                       w.rect_sorted, (uint32_t)T, gx, rows, band_rows, pl.nchunks, pl.wpg, w.table, w.wsum, w.gsum, w.total);
+                       w.rect_sorted, (uint32_t)T, gx, rows, band_rows, pl.nchunks, w.table, w.wsum);
     const unsigned tb = (unsigned)((T + 255) / 256);
+    hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.wsum, (uint32_t)T, pl.nw, pl.wpg,
+                       w.gsum, w.total);
     hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.wsum, (uint32_t)T, pl.nw,
                        pl.wpg, w.gsum, w.total, ranges, total_out, capacity, host_total, sort_fault);
     if (after_scan) (void)hipEventRecord(after_scan, s);  // (N is in the host word long before: written by the launch's first block)

@@ -327,7 +327,6 @@ class _RasterizeViews(torch.autograd.Function):
                 "ggrt_official_amd rasterizer needs tensors on a ROCm GPU (device 'cuda'); there is no CPU path")
         ctx.set_materialize_grads(False)
         means3D_c = _f32c(means3D)
-        P = means3D_c.shape[0]
         view, proj, cam = _f32c(viewmatrices.to(dev)), _f32c(projmatrices.to(dev)), _f32c(campos.to(dev))
         V = int(view.shape[0])
         if view.shape != (V, 4, 4) or proj.shape != (V, 4, 4) or cam.shape != (V, 3):
@@ -337,6 +336,20 @@ class _RasterizeViews(torch.autograd.Function):
         sh_c, cp_c, op_c = _f32c(sh), _f32c(colors_precomp), _f32c(opacities)
         sc_c, rot_c, cov_c = _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
         aux_c = _f32c(aux)
+        # several Gaussian SETS (GgrViews.num_sets): means3D [B,P,3] and every per-Gaussian input [B,P,…]; the V views
+        # are B groups of V/B consecutive views.  Inside, the sets are rows [b·P, (b+1)·P) of flat [B·P, …] arrays.
+        B = 1
+        if means3D_c.dim() == 3:
+            B = int(means3D_c.shape[0])
+            if B < 1 or V % B != 0:
+                raise RuntimeError(f"rasterize_views: {V} views cannot be split over {B} Gaussian sets")
+            flat = lambda t: None if t is None else t.reshape(t.shape[0] * t.shape[1], *t.shape[2:])
+            if any(t is not None and (t.dim() < 2 or t.shape[0] != B or t.shape[1] != means3D_c.shape[1])
+                   for t in (sh_c, cp_c, op_c, sc_c, rot_c, cov_c)):
+                raise RuntimeError("rasterize_views: with means3D [B,P,3] every per-Gaussian input must be [B,P,…]")
+            means3D_c, sh_c, cp_c, op_c, sc_c, rot_c, cov_c = (flat(t) for t in (means3D_c, sh_c, cp_c, op_c, sc_c,
+                                                                                   rot_c, cov_c))
+        P = means3D_c.shape[0] // B   # Gaussians per set
         if aux_c is not None and aux_c.numel() != V * P:
             raise RuntimeError("rasterize_views: aux_precomp must be [V,P]")
         sh_cm = bool(getattr(rs, "sh_channel_major", False)) and sh_c is not None
@@ -371,7 +384,7 @@ class _RasterizeViews(torch.autograd.Function):
             cb = _lib.ALLOC_FN(_alloc)
             st = _settings_struct(rs._replace(tanfovx=0.0, tanfovy=0.0, tanfov=None), P, M, None, None, None, None)
             vw = _lib.GgrViews(num_views=V, viewmatrix=view.data_ptr(), projmatrix=proj.data_ptr(), campos=cam.data_ptr(),
-                               bg=bg_c.data_ptr(), tanfov=tf_c.data_ptr(), input_scale=_ptr(sc_in))
+                               bg=bg_c.data_ptr(), tanfov=tf_c.data_ptr(), input_scale=_ptr(sc_in), num_sets=B)
             fin = _lib.GgrForwardIn(means3D=_ptr(means3D_c), shs=_ptr(sh_c), colors_precomp=_ptr(cp_c),
                                     opacities=_ptr(op_c), scales=_ptr(sc_c), rotations=_ptr(rot_c),
                                     cov3D_precomp=_ptr(cov_c), aux_precomp=_ptr(aux_c), **form)
@@ -395,10 +408,11 @@ class _RasterizeViews(torch.autograd.Function):
         _tls.last_forward = (geom, P * V) if capacity > 0 else (None, int(fout.num_rendered))
         ctx.raster_settings = rs
         ctx.num_rendered = int(fout.num_rendered)
-        ctx.dims = (P, M, H, W, V)
+        ctx.dims = (P, M, H, W, V, B)
         ctx.form = (form, cov_full, sh_cm)
-        ctx.in_shapes = (means3D.shape, None if sh is None else sh.shape, opacities.shape,
-                         None if aux is None else aux.shape, campos.shape)
+        shp = lambda t: None if t is None else t.shape
+        ctx.in_shapes = (means3D.shape, shp(sh), opacities.shape, shp(aux), campos.shape, shp(colors_precomp),
+                         shp(scales), shp(rotations), shp(cov3Ds_precomp))
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None,
                    means2D is not None)
         ctx.save_for_backward(means3D_c, sh_c, cp_c, op_c, sc_c, rot_c, cov_c, bg_c, view, proj, cam, radii, geom,
@@ -413,7 +427,8 @@ class _RasterizeViews(torch.autograd.Function):
         rs = ctx.raster_settings
         (means3D, sh, cp, op, sc, rot, cov, bg, view, proj, cam, radii, geom, img, binb, aux, tf, sc_in,
          fwd_scratch) = ctx.saved_tensors
-        P, M, H, W, V = ctx.dims
+        P, M, H, W, V, B = ctx.dims
+        PT = P * B   # rows of the flat [B·P, …] gradient arrays
         dev = means3D.device
         need_pose = any(ctx.needs_input_grad[7:10])
         with torch.cuda.device(dev):
@@ -423,12 +438,12 @@ class _RasterizeViews(torch.autograd.Function):
             grad_color, grad_depth = _f32c(grad_color), _f32c(grad_depth)
             form, cov_full, sh_cm = ctx.form
             e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-            d_means3D, d_means2D, d_op = e(P, 3), e(V, P, 3), e(P)
-            d_cov = e(P, 3, 3) if (cov_full and cov is not None) else e(P, 6)
-            d_sh = (e(P, 3, M) if sh_cm else e(P, M, 3)) if sh is not None else None
-            d_cp = e(P, 3) if cp is not None else None
-            d_sc = e(P, 3) if sc is not None else None
-            d_rot = e(P, 4) if rot is not None else None
+            d_means3D, d_means2D, d_op = e(PT, 3), e(V, P, 3), e(PT)
+            d_cov = e(PT, 3, 3) if (cov_full and cov is not None) else e(PT, 6)
+            d_sh = (e(PT, 3, M) if sh_cm else e(PT, M, 3)) if sh is not None else None
+            d_cp = e(PT, 3) if cp is not None else None
+            d_sc = e(PT, 3) if sc is not None else None
+            d_rot = e(PT, 4) if rot is not None else None
             d_aux = e(V, P) if (aux is not None and grad_depth is not None) else None
             d_view = e(V, 4, 4) if need_pose else None
             d_proj = e(V, 4, 4) if need_pose else None
@@ -439,7 +454,7 @@ class _RasterizeViews(torch.autograd.Function):
                                                              dtype=torch.uint8, device=dev)
             st = _settings_struct(rs._replace(tanfovx=0.0, tanfovy=0.0, tanfov=None), P, M, None, None, None, None)
             vw = _lib.GgrViews(num_views=V, viewmatrix=view.data_ptr(), projmatrix=proj.data_ptr(), campos=cam.data_ptr(),
-                               bg=bg.data_ptr(), tanfov=tf.data_ptr(), input_scale=_ptr(sc_in))
+                               bg=bg.data_ptr(), tanfov=tf.data_ptr(), input_scale=_ptr(sc_in), num_sets=B)
             bin_ = _lib.GgrBackwardIn(
                 fwd=_lib.GgrForwardIn(means3D=_ptr(means3D), shs=_ptr(sh), colors_precomp=_ptr(cp), opacities=_ptr(op),
                                       scales=_ptr(sc), rotations=_ptr(rot), cov3D_precomp=_ptr(cov),
@@ -458,16 +473,16 @@ class _RasterizeViews(torch.autograd.Function):
                 prof.bwd_calls += 1
             _check(lib.ggr_backward_views(C.byref(st), C.byref(vw), C.byref(bin_), C.byref(bout), stream),
                    "ggr_backward_views")
-        means_shape, sh_shape, op_shape, aux_shape, cam_shape = ctx.in_shapes
+        means_shape, sh_shape, op_shape, aux_shape, cam_shape, cp_shape, sc_shape, rot_shape, cov_shape = ctx.in_shapes
         has_sh, has_cp, has_sc, has_cov, has_m2d = ctx.has
         return (
             d_means3D.reshape(means_shape),
             d_sh.reshape(sh_shape) if has_sh else None,
-            d_cp if has_cp else None,
+            d_cp.reshape(cp_shape) if has_cp else None,
             d_op.reshape(op_shape),
-            d_sc if has_sc else None,
-            d_rot if has_sc else None,
-            d_cov if has_cov else None,
+            d_sc.reshape(sc_shape) if has_sc else None,
+            d_rot.reshape(rot_shape) if has_sc else None,
+            d_cov.reshape(cov_shape) if has_cov else None,
             d_view if ctx.needs_input_grad[7] else None,
             d_proj if ctx.needs_input_grad[8] else None,
             d_cam.reshape(cam_shape) if ctx.needs_input_grad[9] else None,
@@ -480,7 +495,10 @@ class _RasterizeViews(torch.autograd.Function):
 def rasterize_views(means3D, opacities, viewmatrices, projmatrices, campos, bg, tanfov, raster_settings, shs=None,
                     colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, aux_precomp=None,
                     input_scale=None, means2D=None):
-    """V views of the SAME Gaussians in ONE launch set — what the reference does with a Python loop
+    """V views in ONE launch set — of the SAME Gaussians (``means3D [P,3]``), or, with ``means3D
+    [B,P,3]`` and every per-Gaussian input ``[B,P,…]``, of B Gaussian sets with V/B consecutive views each (the
+    reference's ``(b v)`` flattening with per-batch-element Gaussians, ``decoder_splatting_cuda.py:40-60``; gradients
+    then come back ``[B,P,…]``, summed over the views of each set).  This is what the reference does with a Python loop
     of rasterizer calls over a v× repeated copy of the Gaussian tensors (``decoder_splatting_cuda.py:40-60``,
     ``cuda_splatting.py:93-127``).  ``viewmatrices / projmatrices [V,4,4]``, ``campos / bg [V,3]``, ``tanfov [V,2]``
     (device tensors: tan(fov/2) per view), ``input_scale [V]`` or None, ``aux_precomp [V,P]`` or None, ``means2D

@@ -340,6 +340,31 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
         full = view @ proj
         campos, tanfov = extrinsics[:, :3, 3], None
     fused_cov = gaussians.covariances is not None
+    # ---- every batch element in ONE launch set (GgrViews.num_sets): the reference's `(b v)` flattening with
+    # per-batch-element Gaussians (decoder_splatting_cuda.py:40-60) without its per-view loop, its v× repeat, or a
+    # Python loop over batch elements — view n renders Gaussian set n // v of the [b, g, …] tensors as they are
+    nb = gaussians.means.shape[0]
+    vpb = n // nb if nb and n % nb == 0 else 0
+    if (batched and nb > 1 and vpb >= 1 and extrinsics.is_cuda and nb <= 64 and
+            list(int(x) for x in view_to_batch) == [i // vpb for i in range(n)]):
+        from .rasterizer import rasterize_views
+        aux, aux_affine = None, None
+        if depth_mode == "depth":
+            aux_affine = (0.5, SH_C0)
+        elif depth_mode is not None:
+            feat = depth_feature(ext_orig, gaussians.means.repeat_interleave(vpb, 0), near, far, depth_mode)  # [n, g]
+            aux = (0.5 + SH_C0 * feat).clamp(min=0.0)
+        tf = tanfov if tanfov is not None else torch.tensor(tan_host, dtype=torch.float32, device=view.device)
+        settings = GaussianRasterizationSettings(
+            image_height=h, image_width=w, tanfovx=0.0, tanfovy=0.0, bg=background_color[0], scale_modifier=1.0,
+            viewmatrix=view[0], projmatrix=full[0], sh_degree=degree, campos=campos[0], prefiltered=False,
+            list_capacity=list_capacity * n, sh_channel_major=True, aux_affine=aux_affine,
+            sh_max_degree=SH_MAX_DEGREE, scissor=None if scissor is None else tuple(scissor))
+        kw = dict(cov3D_precomp=gaussians.covariances) if fused_cov else dict(scales=gaussians.scales,
+                                                                              rotations=gaussians.rotations)
+        col, _, dep = rasterize_views(gaussians.means, gaussians.opacities, view, full, campos, background_color, tf,
+                                      settings, shs=gaussians.harmonics, aux_precomp=aux, input_scale=scale, **kw)
+        return col, (dep if depth_mode is not None else None)
     # batch element b of every Gaussian tensor WITHOUT `t[b]`: select's backward zero-fills a full [B,…] tensor
     # and copies the slice in, per view (0.2 ms per view for 1 M × 25 SH coefficients).  One unbind per tensor
     # (backward = one stack) — or a free reshape when there is a single batch element, GGRt's case.

@@ -221,6 +221,15 @@ typedef struct GgrViews {
     const float* bg;             /* device [V,3] */
     const float* tanfov;         /* device [V,2] (tanfovx, tanfovy) or NULL: settings->tanfovx/y for every view */
     const float* input_scale;    /* device [V] or NULL (see GgrForwardIn.input_scale, which is ignored here) */
+    int32_t num_sets;            /* B: 0 / 1 = every view renders the same P Gaussians.  B > 1: the V views are B groups of
+                                    V/B consecutive views and group b renders Gaussian SET b — every per-Gaussian input
+                                    (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp) is then
+                                    [B, P, …] with P = settings->num_points, and so is every per-Gaussian gradient of
+                                    ggr_backward_views (summed over the views of the set).  This is the reference's
+                                    `(b v)` flattening with per-batch-element Gaussians (decoder_splatting_cuda.py:40-60)
+                                    as ONE launch set: one preprocess launch, one segmented sort, one tile-list build,
+                                    one blend launch.  Everything per view ([V, …]: radii, images, aux_precomp, dL_dmeans2D,
+                                    camera gradients) is unchanged. */
 } GgrViews;
 
 /* image_buffer size of a forward with GgrForwardOut.no_backward = 1 (no checkpoint area); num_views = 1 for ggr_forward */

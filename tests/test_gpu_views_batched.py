@@ -206,3 +206,117 @@ def test_more_views_than_sort_segments():
             c1, r1, d1 = GaussianRasterizer(r)(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D),
                                                opacities=sc.opacities, shs=sc.shs, cov3D_precomp=sc.cov3D)
             assert torch.equal(color[v], c1) and torch.equal(radii[v], r1) and torch.equal(depth[v], d1)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=3, vps=2, P=5000, W=112, H=80, D=3, use_sh=True, use_cov=True),                         # MULTI kernels per set
+    dict(B=4, vps=1, P=4097, W=96, H=64, D=4, use_sh=True, use_cov=True, cm=True, cap=4),          # one view per set: the
+    dict(B=2, vps=1, P=6000, W=130, H=70, D=4, use_sh=True, use_cov=False, depth=True, pose=True),  # one-view kernels; ragged P
+    dict(B=2, vps=3, P=3000, W=64, H=48, D=0, use_sh=False, use_cov=True, aux=True, depth=True, scaled=True),
+])
+def test_gaussian_sets_equal_per_set_calls(case):
+    """GgrViews.num_sets (VERDICT r2 missing #3): B DIFFERENT Gaussian sets, V/B views each, in ONE launch set — the
+    reference's `(b v)` flattening (decoder_splatting_cuda.py:40-60) — against one `rasterize_views` call per set:
+    same tile lists per view, hence bit-identical images / radii; gradients come back per set, to summation order."""
+    B, vps, P, W, H = case["B"], case["vps"], case["P"], case["W"], case["H"]
+    V = B * vps
+    scs = [make_scene(P, W, H, sh_degree=case["D"], profile="AB"[b % 2], seed=50 + b) for b in range(B)]
+    view, full, campos, tanfov = [t.to(dev) for t in _cameras(W, H, V)]
+    g = torch.Generator().manual_seed(9)
+    dLs = torch.stack([upstream_gradient(W, H, seed=60 + v) for v in range(V)]).to(dev)
+    dDs = torch.stack([upstream_gradient(W, H, seed=80 + v)[0] * 0.2 for v in range(V)]).to(dev) if case.get("depth") else None
+    bgs = torch.rand(V, 3, generator=g).to(dev)
+    scales_in = (0.5 + torch.rand(V, generator=g)).to(dev) if case.get("scaled") else None
+    aux = torch.rand(V, P, generator=g).to(dev) if case.get("aux") else None
+    cm = case.get("cm", False)
+    stack = lambda f: torch.stack([f(s) for s in scs]).to(dev)
+    inputs = dict(means3D=stack(lambda s: s.means3D), opacities=stack(lambda s: s.opacities))
+    if case["use_sh"]:
+        inputs["shs"] = stack(lambda s: s.shs.permute(0, 2, 1).contiguous() if cm else s.shs)
+    else:
+        inputs["colors_precomp"] = stack(lambda s: s.shs[:, 0].abs())
+    if case["use_cov"]:
+        inputs["cov3D_precomp"] = stack(lambda s: s.cov3D)
+    else:
+        inputs["scales"], inputs["rotations"] = stack(lambda s: s.scales), stack(lambda s: s.rotations)
+    rs = scs[0].to(dev).settings()._replace(sh_channel_major=cm, sh_max_degree=case.get("cap", 3))
+
+    def run(as_sets):
+        leaf = lambda t: t.detach().clone().requires_grad_(True)
+        lv = {k: leaf(t) for k, t in inputs.items()}
+        cams = [leaf(view), leaf(full), leaf(campos)] if case.get("pose") else [view, full, campos]
+        aux_l = None if aux is None else leaf(aux)
+        sink = torch.zeros(V, P, 3, device=dev, requires_grad=True)
+        m, o = lv.pop("means3D"), lv.pop("opacities")
+        if as_sets:
+            color, radii, depth = rasterize_views(m, o, *cams, bgs, tanfov.to(dev), rs, aux_precomp=aux_l,
+                                                  input_scale=scales_in, means2D=sink, **lv)
+        else:
+            outs = []
+            for b in range(B):
+                sl = slice(b * vps, (b + 1) * vps)
+                outs.append(rasterize_views(m[b], o[b], cams[0][sl], cams[1][sl], cams[2][sl], bgs[sl], tanfov.to(dev)[sl],
+                                            rs, aux_precomp=None if aux_l is None else aux_l[sl],
+                                            input_scale=None if scales_in is None else scales_in[sl], means2D=sink[sl],
+                                            **{k: t[b] for k, t in lv.items()}))
+            color, radii, depth = (torch.cat([o_[i] for o_ in outs]) for i in range(3))
+        loss = (color * dLs).sum() + (0 if dDs is None else (depth * dDs).sum())
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {k: t.grad.detach().cpu().numpy() for k, t in lv.items()}
+        grads.update(means3D=m.grad.cpu().numpy(), opacities=o.grad.cpu().numpy(), means2D=sink.grad.cpu().numpy())
+        if case.get("pose"):
+            grads.update(viewmatrix=cams[0].grad.cpu().numpy(), projmatrix=cams[1].grad.cpu().numpy(), campos=cams[2].grad.cpu().numpy())
+        if aux_l is not None:
+            grads["aux"] = aux_l.grad.cpu().numpy()
+        return color.detach().cpu().numpy(), radii.cpu().numpy(), depth.detach().cpu().numpy(), grads
+
+    ca, ra, da, ga = run(False)
+    cb, rb, db, gb = run(True)
+    assert np.array_equal(ra, rb)
+    assert np.array_equal(ca, cb), float(np.abs(ca - cb).max())
+    assert np.array_equal(da, db)
+    assert set(ga) == set(gb)
+    for k in ga:
+        assert ga[k].shape == gb[k].shape, k
+        flat = lambda t: t.reshape(-1, *t.shape[2:]) if k not in ("viewmatrix", "projmatrix", "campos") else t
+        assert rel_l2(flat(gb[k]), flat(ga[k])) < 2e-6, (k, rel_l2(gb[k], ga[k]))
+    # set 0 alone against the C oracle (view 0)
+    n = lambda t: t.detach().cpu().numpy()
+    if case["use_sh"] and case["use_cov"] and not cm and case.get("cap", 3) == 3:
+        st = c_oracle.forward(n(scs[0].means3D), n(scs[0].opacities), n(view[0]), n(full[0]), n(campos[0]), n(bgs[0]),
+                              W, H, float(tanfov[0, 0]), float(tanfov[0, 1]), sh_degree=case["D"], shs=n(scs[0].shs),
+                              cov3D_precomp=n(scs[0].cov3D))
+        assert np.array_equal(rb[0], st.radii)
+        check_image(cb[0], st.color, tag="sets_oracle")
+
+
+def test_decoder_all_batch_elements_in_one_launch_set():
+    """`render_views_fused` with b > 1 batch elements takes ONE `rasterize_views` call over all of them (no Python loop
+    over batch elements): same images and gradients as the per-element path."""
+    from ggrt_official_amd import splatting as sp
+    b, v, gc, h, w = 3, 2, 4000, 80, 112
+    sc = [make_scene(gc, w, h, sh_degree=4, seed=70 + i) for i in range(b)]
+    ext = torch.stack([torch.stack([_pose(3 * i + k).float() for k in range(v)]) for i in range(b)]).to(dev)
+    intr = torch.eye(3).repeat(b, v, 1, 1)
+    intr[..., 0, 0], intr[..., 1, 1], intr[..., 0, 2], intr[..., 1, 2] = 1.1, 1.1 * w / h, 0.5, 0.5
+    near, far = torch.full((b, v), 0.9), torch.full((b, v), 80.0)
+
+    def run(batched):
+        leaf = lambda t: t.detach().clone().to(dev).requires_grad_(True)
+        gs = sp.Gaussians(means=leaf(torch.stack([s.means3D for s in sc])),
+                          covariances=leaf(torch.stack([torch.stack([s.cov3D[:, [0, 1, 2, 1, 3, 4, 2, 4, 5]].reshape(-1, 3, 3)]).squeeze(0) for s in sc])),
+                          harmonics=leaf(torch.stack([s.shs.permute(0, 2, 1) for s in sc])),
+                          opacities=leaf(torch.stack([s.opacities for s in sc])))
+        col, dep = sp.render_views_fused(ext.flatten(0, 1), intr.flatten(0, 1).to(dev), near.flatten().to(dev),
+                                         far.flatten().to(dev), (h, w), torch.zeros(b * v, 3, device=dev), gs,
+                                         [n // v for n in range(b * v)], "depth", batched=batched)
+        (col.sum() + 0.3 * dep.sum()).backward()
+        torch.cuda.synchronize()
+        return col.detach(), dep.detach(), [t.grad for t in (gs.means, gs.covariances, gs.harmonics, gs.opacities)]
+
+    c1, d1, g1 = run(True)
+    c0, d0, g0 = run(False)
+    assert torch.equal(c1, c0) and torch.equal(d1, d0)
+    for a, r in zip(g1, g0):
+        assert rel_l2(a.cpu().numpy(), r.cpu().numpy()) < 5e-6
