@@ -24,8 +24,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement) carrying extra o
                   same workload, no extrapolation (rank 0, N = 1 only); "cpu_baseline_torch" keeps the PyTorch
                   restatement's bounded-sample figure beside it
   "secondary"     the other BASELINE shapes measured the same way (N = 1 only): C5' (GGRt's per-rank training
-                  shape, fwd+bwd), C4' (GGRt's LLFF eval shape, forward only, frames/s) and C3 with the upper half
-                  of the frame empty — each with its own stage times and roofline
+                  shape, fwd+bwd), C4' (GGRt's LLFF eval shape, forward only, frames/s), C3 with the upper half
+                  of the frame empty and C6' (Waymo eval shape, 4.9 M Gaussians) — each with its own stage times
+                  and roofline
+  "binning_kernels"  depth sort and tile scatter against the bytes THIS build must move for them
+  "blend_valu_issue" the blend kernels' executed VALU instructions × the measured issue cost of their instruction mix
+                  ÷ the SIMD cycles they had (profiles/r03_valu_peak.txt, profiles/r03_valu_mix.json)
 
 Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
                  --master-port P bench.py --gpus N --steps K --warmup W
@@ -51,8 +55,14 @@ def log(msg):
 
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (≈6.3 TB/s achievable)
-# non-packed fp32 VALU issue peak: 256 CUs × 4 SIMDs, one wave64 instruction per 4 cycles at 2.4 GHz
-VALU_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4
+# fp32 VALU issue: a SIMD-32 takes 2 cycles per plain wave64 instruction (MI355X_MICROARCH.md:52-53,430; measured here:
+# profiles/r03_valu_peak.txt, tools/valu_peak_bench.hip — 126.7 TFLOP/s of v_fma_f32 = 0.81 of the 157.3 TF spec, the
+# shader clock sagging to ≈ 1.87 GHz under that load), 4 per DPP-modified or packed-fp32 instruction, 8 per v_exp /
+# v_rcp / v_permlane*_swap.  Rounds 1-2 priced every instruction at 4 cycles (614 G/s) — wrong by 2× for plain VALU.
+N_SIMD = 256 * 4
+CLOCK_NOMINAL_HZ = 2.4e9
+CLOCK_SUSTAINED_VALU_HZ = 1.867e9   # s_memtime ÷ wall clock with every SIMD issuing v_fma_f32 (profiles/r03_valu_peak.txt)
+VALU_PLAIN_WAVE_INSTS_PER_S = N_SIMD * CLOCK_NOMINAL_HZ / 2
 
 
 def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int) -> dict:
@@ -61,6 +71,11 @@ def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int) -> dict:
         # per-stage split of B_fwd = P(12+24+4+12K) + N(12+12) + N·40 + W·H·20
         "fwd_preprocess": P * (12 + 24 + 4 + 12 * K),
         "fwd_binning": N * 24,  # SURVEY's figure (12-B pair written + read once); this build writes 4 B/entry
+        # what THIS build's binning kernels must move at least (not SURVEY's figures: the 64-bit pair sort is not built):
+        # depth sort = 3 passes × (key + id read and written) + one histogram read of the keys;
+        # tile scatter = the ids written + each Gaussian's (id, rect) read once + the per-chunk start table read once
+        "depth_sort_compulsory": P * (3 * 16 + 4),
+        "tile_scatter_compulsory": N * 4 + P * 12,
         "fwd_blend": N * 40 + W * H * 20,
         # B_bwd = W·H·20 + N·40 + P(12+24+4+12K) + P(12+12+24+4+12M)
         "bwd_blend": W * H * 20 + N * 40,
@@ -143,7 +158,7 @@ class Workload:
     def rooflines(self, stages: dict, N: int) -> dict:
         D = self.cfg["sh_degree"]
         M = self.sc.shs.shape[1]
-        deg = min(D, 4)
+        deg = min(D, int(getattr(self.rs, "sh_max_degree", 3) or 3))
         while (deg + 1) ** 2 > M:
             deg -= 1
         K = (deg + 1) ** 2
@@ -162,6 +177,13 @@ class Workload:
             "render_forward": {"ms": round(t_fwd, 4), "algorithmic_bytes": b_fwd,
                                "hbm_frac": round(b_fwd / (t_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }
+        # the kernels furthest below their own roofline: compulsory bytes ÷ HIP-event stage time
+        out["binning_kernels"] = {
+            name: {"ms": round(stages[key], 4), "compulsory_bytes": ab[ck],
+                   "achieved_GBps": round(ab[ck] / (stages[key] * 1e-3) / 1e9, 1),
+                   "hbm_frac": round(ab[ck] / (stages[key] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            for name, key, ck in (("depth_sort", "fwd_depth_sort_ms", "depth_sort_compulsory"),
+                                  ("tile_scatter", "fwd_tile_scatter_ms", "tile_scatter_compulsory"))}
         if not self.fwd_only:
             t_bwd = sum(v for k, v in stages.items() if k.startswith("bwd_"))
             b_bwd = ab["bwd_blend"] + ab["bwd_preprocess"]
@@ -470,19 +492,32 @@ def main():
         rf["roofline"]["note"] = ("blend kernels are fp32-VALU-issue-bound (≈160 flop per list-entry byte), not HBM-bound; "
                                   "see blend_valu_issue and DESIGN.md §4")
         # the bound that matters for the two blend kernels: wave-level VALU instructions actually EXECUTED
-        # (SQ_INSTS_VALU, rocprofv3 PMC passes of this command at C3 — scripts/pmc_sq.sh) ÷ the non-packed fp32 issue
-        # peak (1024 SIMDs × 2.4 GHz ÷ 4 cycles per wave64 instruction) over the kernel's HIP-event time of THIS run
+        # (SQ_INSTS_VALU, rocprofv3 PMC passes of this command at C3 — scripts/pmc_sq.sh) × the average issue cost of the
+        # kernel's instruction mix (scripts/valu_mix.py over the ISA: plain 2 cycles, DPP / packed 4, exp / rcp /
+        # permlane-swap 8 — the costs measured by tools/valu_peak_bench.hip) ÷ the SIMD cycles the kernel had in its
+        # HIP-event time of THIS run, at the nominal clock and at the clock the part sustains under a dense VALU load
         valu = None
         sq_path = newest_profile("r*_pmc_sq.json") if args.config == "C3" else None
-        if sq_path:
-            valu = {"peak_wave_insts_per_s": VALU_WAVE_INSTS_PER_S,
-                    "source": f"profiles/{os.path.basename(sq_path)} (instruction counts; collected separately, not in this run)"}
+        mix_path = newest_profile("r*_valu_mix.json")
+        if sq_path and mix_path:
+            mix = json.load(open(mix_path))
+            valu = {"valu_peak_source": "profiles/r03_valu_peak.txt (tools/valu_peak_bench.hip, this part): 2 cycles per plain wave64 "
+                                        "VALU instruction (= /opt/skills/guides/MI355X_MICROARCH.md:52-53,430), 4 DPP / packed, 8 exp / rcp / "
+                                        "permlane-swap; 126.7 TFLOP/s fp32 FMA sustained = 0.81 of spec at ≈ 1.87 GHz",
+                    "peak_plain_wave_insts_per_s_nominal": VALU_PLAIN_WAVE_INSTS_PER_S,
+                    "instruction_counts_source": f"profiles/{os.path.basename(sq_path)} (SQ_INSTS_VALU; collected separately, not in this run)",
+                    "instruction_mix_source": f"profiles/{os.path.basename(mix_path)} (static mix of the hot loops, scripts/valu_mix.py)"}
             for k, v in json.load(open(sq_path)).items():
                 for short, kn, st_key in (("fwd", "blend_fwd_kernel", "fwd_blend_ms"), ("bwd", "blend_bwd_kernel", "bwd_blend_ms")):
                     if kn in k and v.get("insts_valu"):
                         t_s = stages[st_key] * 1e-3
-                        valu[short] = {"insts_valu": int(v["insts_valu"]), "kernel_ms": round(stages[st_key], 4),
-                                       "issue_frac": round(v["insts_valu"] / t_s / VALU_WAVE_INSTS_PER_S, 4),
+                        cyc = mix[kn]["avg_issue_cycles_per_valu_inst"]
+                        need = v["insts_valu"] * cyc
+                        valu[short] = {"insts_valu": int(v["insts_valu"]), "avg_issue_cycles_per_inst": cyc,
+                                       "kernel_ms": round(stages[st_key], 4),
+                                       "issue_frac_nominal_clock": round(need / (N_SIMD * CLOCK_NOMINAL_HZ * t_s), 4),
+                                       "issue_frac_sustained_clock": round(need / (N_SIMD * CLOCK_SUSTAINED_VALU_HZ * t_s), 4),
+                                       "insts_salu": v.get("insts_salu"),
                                        "valu_busy_frac_pmc": v.get("valu_busy_frac_at_2p4GHz")}
         rec = {
             "metric": "Gaussian raster fwd+bwd Mpix/s @1M Gaussians 1080p",
@@ -515,11 +550,19 @@ def main():
                 # … and four target views of the same Gaussians: per-view loop vs ONE launch set
                 rec["callsite_ggrt_views4"] = callsite_bench.measure_views(str(dev), steps=10, warmup=3, views=4)
                 log(f"four views at GGRt's shape: {rec['callsite_ggrt_views4']}")
+                # … four DIFFERENT Gaussian sets, one view each (the `(b v)` flattening): loop vs ONE launch set
+                rec["callsite_ggrt_sets4"] = callsite_bench.measure_sets(str(dev), steps=10, warmup=3, sets=4)
+                log(f"four Gaussian sets at GGRt's shape: {rec['callsite_ggrt_sets4']}")
+                # … and the fine-tune loop's deferred back-propagation cell (finetune_ggrt_stable.py:126-142): a gradient
+                # that is zero outside one cell of a 2 × 2 grid — zero-gradient skip in the backward, scissored forward
+                rec["deferred_backprop_window"] = {c: callsite_bench.measure_window(str(dev), steps=10, warmup=3, config=c)
+                                                   for c in ("C5p", "C3")}
+                log(f"windowed backward: {rec['deferred_backprop_window']}")
             except Exception as e:
                 log(f"call-site leg skipped: {type(e).__name__}: {e}")
         if world == 1 and not args.no_secondary and args.config == "C3":
             sec = {}
-            for name, fwd_only in (("C5p", False), ("C4p", True), ("C3_lower_half", False)):
+            for name, fwd_only in (("C5p", False), ("C4p", True), ("C3_lower_half", False), ("C6p", False)):
                 try:
                     sec[name] = secondary_record(name, CONFIGS[name], dev, steps=max(10, args.steps), warmup=3, fwd_only=fwd_only)
                     log(f"secondary {name}: {sec[name]['ms_per_step']} ms, fwd hbm_frac {sec[name]['render_forward']['hbm_frac']}")

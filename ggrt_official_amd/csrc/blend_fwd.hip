@@ -20,6 +20,10 @@
 namespace ggr {
 
 #define BATCH GGR_BATCH
+#ifndef SURV_GROUP
+#define SURV_GROUP 4   // survivors per trip of the blend loop (one broadcast read of their offsets; measured at C3, 2 / 4 / 8:
+                       // 189 / 187 / 218 µs — at 8 the compiler keeps all eight records live: 120 VGPRs)
+#endif
 
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
@@ -28,7 +32,8 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ out_depth, float* __restrict__ ckpt,
                  int ckpt_slots, uint32_t* __restrict__ tile_top, int views, float4* __restrict__ zero4,
                  size_t zero4_n) {
-    __shared__ StagedSplat stage[BATCH];
+    __shared__ StagedSplat stage[BATCH + 1];   // + the null record that pads a wave's survivor list
+    __shared__ __attribute__((aligned(16))) uint16_t surv[4][BATCH + SURV_GROUP];  // per wave: LDS byte offsets of its survivors
     __shared__ int wave_done[4];
     __shared__ uint32_t wave_last[4];
 
@@ -71,7 +76,11 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
     uint32_t last = 0;
-    bool done = !inside;
+    float live = inside ? 1.0f : 0.f;   // 0: the pixel is saturated (or outside the image) and takes no further entry
+    if (tid == 0) {                      // the null record: opacity 0 → α = 0 → never contributes
+        stage[BATCH].a = make_float4(0.f, 0.f, 0.f, 0.f); stage[BATCH].b = make_float4(0.f, 0.f, 0.f, 0.f);
+        stage[BATCH].c = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (lane == 0) wave_done[wave] = quad_live ? 0 : 1;
     bool wdone = !quad_live;
 
@@ -87,6 +96,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         if (tid < nb) {
             float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1], c = splat[3 * (size_t)g + 2];
             stage_scale_conic(a, b, c);  // (blend_common.h: the pixel loop works on k·q, k = log2(e)/2)
+            c.w = __uint_as_float((uint32_t)(b0 + tid + 1));  // its position in the list, + 1: what n_contrib records
             stage[tid].a = a;
             stage[tid].b = b;
             stage[tid].c = c;
@@ -97,8 +107,15 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             ck[0] = T; ck[hw] = C0; ck[2 * hw] = C1; ck[3 * hw] = C2; ck[4 * hw] = Dz;
         }
         if (!wdone) {
+            // ---- cull: this wave's survivors of the whole batch, compacted into a wave-private list of LDS byte
+            // offsets (u16: 255·48 < 2^16).  Round 2 walked the ballot mask with s_ff1 / s_and per survivor and
+            // combined its per-pixel conditions in scalar mask registers: ≈ 20 SALU per ≈ 22 VALU instructions, and a
+            // CU has ONE scalar unit for its four SIMDs — the kernel ran at the scalar unit's pace (85 M SALU against
+            // 105 M VALU per launch at C3).  Now a survivor costs no scalar instruction at all: its offset arrives in
+            // a VGPR (a broadcast LDS read), every condition is a v_cmp feeding a v_cndmask.
+            int ns = 0;
+            uint16_t* my_surv = surv[wave];
             for (int s0 = 0; s0 < nb; s0 += 64) {
-                // lane-per-entry cull against this wave's quadrant
                 const int e = s0 + lane;
                 bool keep = false;
                 if (e < nb) {
@@ -106,44 +123,38 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                     const float4 b = stage[e].b;
                     keep = staged_box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
                 }
-                uint64_t m = __ballot(keep);
-                while (m) {
-                    // two survivors per trip, straight-line: their LDS broadcast reads and the geometry
-                    // (power, exp) are independent and overlap; only the T / colour updates are sequential
-                    // (measured at C3: 1 per trip 0.205 ms, 2: 0.194, 3: 0.196, 4: 0.203, 8: 0.268)
-                    constexpr int U = 2;
-                    int e4[U];
-                    bool has[U];
+                const uint64_t mk = __ballot(keep);
+                if (keep) my_surv[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)(e * 48);
+                ns += __popcll(mk);
+            }
+            if (lane < SURV_GROUP) my_surv[ns + lane] = (uint16_t)(BATCH * 48);  // pad with the null record (opacity 0)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const char* stage_bytes = reinterpret_cast<const char*>(stage);
+            for (int k0 = 0; k0 < ns; k0 += SURV_GROUP) {
+                uint32_t pkw[SURV_GROUP / 2];   // the group's offsets, one broadcast read
+                __builtin_memcpy(pkw, my_surv + k0, sizeof pkw);
 #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        has[u] = m != 0;
-                        e4[u] = s0 + (has[u] ? __builtin_ctzll(m) : 0);
-                        m &= m - 1;  // (0 stays 0)
-                    }
-                    float alpha[U], q2[U];
-                    float4 rb[U], rc[U];
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const float4 a = stage[e4[u]].a;
-                        rb[u] = stage[e4[u]].b;
-                        rc[u] = stage[e4[u]].c;
-                        q2[u] = staged_q2(a, rb[u], a.x - pixx, a.y - pixy);  // = −power·log2(e)
-                        alpha[u] = fminf(GGR_ALPHA_MAX, rb[u].y * __builtin_amdgcn_exp2f(-q2[u]));
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        bool ok = has[u] && !done && q2[u] >= 0.0f && alpha[u] >= GGR_ALPHA_MIN;
-                        const float w = alpha[u] * T;
-                        const float test_T = T - w;  // T·(1−α)
-                        if (ok && test_T < GGR_T_MIN) { done = true; ok = false; }
-                        if (ok) {
-                            C0 += rb[u].z * w; C1 += rb[u].w * w; C2 += rc[u].x * w; Dz += rc[u].y * w;
-                            T = test_T;
-                            last = (uint32_t)(b0 + e4[u] + 1);
-                        }
-                    }
+                for (int u = 0; u < SURV_GROUP; u++) {
+                    const uint32_t off = (pkw[u >> 1] >> (16 * (u & 1))) & 0xffffu;   // (VGPR, uniform)
+                    const StagedSplat* rec = reinterpret_cast<const StagedSplat*>(stage_bytes + off);
+                    const float4 a = rec->a, rb = rec->b, rc = rec->c;
+                    const float q2 = staged_q2(a, rb, a.x - pixx, a.y - pixy);  // = −power·log2(e)
+                    float alpha = fminf(GGR_ALPHA_MAX, rb.y * __builtin_amdgcn_exp2f(-q2));
+                    alpha = q2 >= 0.0f ? alpha : 0.f;                 // power > 0: skip
+                    alpha = alpha >= GGR_ALPHA_MIN ? alpha : 0.f;    // α < 1/255: skip
+                    alpha *= live;                                    // a saturated pixel takes nothing more
+                    float w = alpha * T;
+                    const float test_T = T - w;  // T·(1−α); stays ≥ T_MIN for a skipped entry (T itself never drops below)
+                    const bool stop = test_T < GGR_T_MIN;
+                    w = stop ? 0.f : w;
+                    live = stop ? 0.f : live;
+                    C0 = fmaf(rb.z, w, C0); C1 = fmaf(rb.w, w, C1); C2 = fmaf(rc.x, w, C2); Dz = fmaf(rc.y, w, Dz);
+                    T -= w;
+                    // (list position of the entry: the staging thread left it in the record's last word)
+                    last = w > 0.f ? __float_as_uint(rc.w) : last;
                 }
-                if (__all(done)) { wdone = true; break; }
+                if (__all(live == 0.f)) { wdone = true; break; }
             }
             if (wdone && lane == 0) wave_done[wave] = 1;
         }

@@ -132,7 +132,121 @@ def measure_views(dev="cuda:0", steps=10, warmup=3, config="C5p", views=4):
     return out
 
 
+def measure_sets(dev="cuda:0", steps=10, warmup=3, config="C5p", sets=4):
+    """The reference's `(b v)` flattening with per-batch-element Gaussians (decoder_splatting_cuda.py:40-60) at GGRt's
+    shape: `sets` independent (Gaussians, camera) problems, one view each, colour + depth, forward + backward —
+      per_set_loop   one rasterizer call per problem (round 2's `render_views_fused`: a Python loop over batch elements)
+      one_launch_set ONE launch set over all of them (GgrViews.num_sets)
+    and one problem alone for scale."""
+    import math
+    from ggrt_official_amd import splatting as sp
+    from ggrt_official_amd.synthetic import CONFIGS, make_scene
+    cfg = CONFIGS[config]
+    scs = [make_scene(seed=s, **cfg).to(dev) for s in range(sets)]
+    P, H, W = scs[0].means3D.shape[0], scs[0].height, scs[0].width
+    ext = torch.eye(4, device=dev)[None].repeat(sets, 1, 1)
+    fx, fy = 0.5 / scs[0].tanfovx, 0.5 / scs[0].tanfovy
+    intr = torch.tensor([[fx, 0, 0.5], [0, fy, 0.5], [0, 0, 1]], device=dev)[None].expand(sets, 3, 3).contiguous()
+    near, far = torch.full((sets,), 1.0, device=dev), torch.full((sets,), 100.0, device=dev)
+
+    def cov33(sc):
+        cov = torch.zeros(P, 3, 3, device=dev)
+        for k, (i, j) in enumerate([(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]):
+            cov[:, i, j] = sc.cov3D[:, k]
+            cov[:, j, i] = sc.cov3D[:, k]
+        return cov
+    def make_leaves(nb):   # own leaf tensors per problem count: a slice of a bigger leaf would add its backward (a
+        return [t.clone().requires_grad_() for t in (   # zero-filled full-size tensor per slice) to the measurement
+            torch.stack([s.means3D for s in scs[:nb]]), torch.stack([cov33(s) for s in scs[:nb]]),
+            torch.stack([s.shs.permute(0, 2, 1).contiguous() for s in scs[:nb]]),
+            torch.stack([s.opacities[:, 0] for s in scs[:nb]]))]
+    leaf_sets = {1: make_leaves(1), sets: make_leaves(sets)}
+    leaves = [t for ls in leaf_sets.values() for t in ls]
+    bg = torch.zeros(sets, 3, device=dev)
+    g = torch.Generator().manual_seed(0)
+    dL = (torch.randn(sets, 3, H, W, generator=g) / (3 * H * W)).to(dev)
+    dD = (torch.randn(sets, H, W, generator=g) / (H * W)).to(dev)
+
+    def run(nb, batched):
+        lv = leaf_sets[nb]
+        gs = sp.Gaussians(means=lv[0], covariances=lv[1], harmonics=lv[2], opacities=lv[3])
+        c, d = sp.render_views_fused(ext[:nb], intr[:nb], near[:nb], far[:nb], (H, W), bg[:nb], gs, list(range(nb)), "depth",
+                                     batched=batched)
+        torch.autograd.backward([c, d], [dL[:nb], dD[:nb]])
+
+    out = {"workload": f"{config}: {sets} independent problems of {P} Gaussians, {W}x{H}, d_sh {scs[0].shs.shape[1]}, "
+                       f"colour + depth, fwd+bwd, one view each"}
+    for name, fn in (("one_problem_ms", lambda: run(1, False)), ("per_set_loop_ms", lambda: run(sets, False)),
+                     ("one_launch_set_ms", lambda: run(sets, True))):
+        for _ in range(warmup):
+            for t in leaves:
+                t.grad = None
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for t in leaves:
+                t.grad = None
+            fn()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+    out["launch_set_over_one_problem"] = round(out["one_launch_set_ms"] / out["one_problem_ms"], 2)
+    return out
+
+
+def measure_window(dev="cuda:0", steps=10, warmup=3, config="C5p", crop=2):
+    """The reference's deferred back-propagation cell (finetune_ggrt_stable.py:126-142) at GGRt's shape: a full-frame
+    render whose backward sees a gradient that is zero outside ONE cell of a crop × crop grid.  Per-stage times of the
+    rasterizer (HIP events): the dense-gradient step, the windowed gradient (the backward's zero-gradient skip), and
+    the windowed gradient with the forward scissored to the cell as well."""
+    from ggrt_official_amd import GaussianRasterizer
+    from ggrt_official_amd.rasterizer import profile_stages
+    from ggrt_official_amd.synthetic import CONFIGS, make_scene, upstream_gradient
+    cfg = CONFIGS[config]
+    sc = make_scene(**cfg).to(dev)
+    H, W = sc.height, sc.width
+    leaf = lambda t: t.clone().requires_grad_(True)
+    means, cov, op, shs = leaf(sc.means3D), leaf(sc.cov3D), leaf(sc.opacities), leaf(sc.shs)
+    sink = torch.zeros_like(means, requires_grad=True)
+    dL = upstream_gradient(W, H, seed=3, device=dev)
+    oh, ow = H // crop, W // crop
+    win = (ow * (crop - 1), oh * (crop - 1), ow * crop, oh * crop)   # the last cell
+    mask = torch.zeros(H, W, device=dev)
+    mask[win[1]:win[3], win[0]:win[2]] = 1.0
+    out = {"workload": f"{config}: one cell of a {crop}x{crop} grid ({ow}x{oh} px of {W}x{H}), fwd+bwd"}
+    for name, grad, scissor in (("dense", dL, None), ("windowed_gradient", dL * mask, None),
+                                ("windowed_gradient_scissored_forward", dL * mask, win)):
+        rast = GaussianRasterizer(sc.settings()._replace(scissor=scissor))
+
+        def step():
+            for t in (means, cov, op, shs, sink):
+                t.grad = None
+            c, _, _ = rast(means3D=means, means2D=sink, opacities=op, shs=shs, cov3D_precomp=cov)
+            c.backward(grad)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        with profile_stages() as prof:
+            for _ in range(3):
+                step()
+        torch.cuda.synchronize()
+        st = prof.as_dict()
+        out[name] = {"ms_per_step": round(ms, 3), "fwd_ms": round(sum(v for k, v in st.items() if k.startswith("fwd_")), 4),
+                     "bwd_blend_ms": round(st["bwd_blend_ms"], 4), "bwd_preprocess_ms": round(st["bwd_preprocess_ms"], 4)}
+    out["bwd_blend_windowed_over_dense"] = round(out["windowed_gradient"]["bwd_blend_ms"] / out["dense"]["bwd_blend_ms"], 3)
+    return out
+
+
 if __name__ == "__main__":
     import json
+    print(json.dumps(measure_sets(), indent=1))
+    print(json.dumps(measure_window(), indent=1))
+    print(json.dumps(measure_window(config="C3"), indent=1))
+    sys.exit(0)
     print(json.dumps(measure(), indent=1))
     print(json.dumps(measure_views(), indent=1))

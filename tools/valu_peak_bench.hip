@@ -13,7 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#define ITERS 2048
+#define ITERS 32768
 #define CHAINS 8
 
 enum { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERM32, PERM16, PK_FMA, FMA_DEP, MIX_BLEND, NMODES };
@@ -96,6 +96,16 @@ static void run(float* out, int waves_per_simd, double clk_ghz, int cus) {
     hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
+// shader clock actually sustained under a VALU load: s_memtime cycles ÷ wall time of one long launch
+__global__ void clock_probe(unsigned long long* out, float* sink) {
+    float a = threadIdx.x, b = 1.0001f;
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int i = 0; i < (1 << 20); i++) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = a;
+}
+
 int main(int argc, char** argv) {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const double clk = p.clockRate * 1e-6;  // kHz → GHz
@@ -104,6 +114,15 @@ int main(int argc, char** argv) {
            p.name, cus, clk, ITERS, CHAINS);
     printf("# peak if 2 cyc/inst: %.0f G wave-inst/s; if 4 cyc/inst: %.0f G wave-inst/s\n", cus * 4 * clk / 2, cus * 4 * clk / 4);
     float* out; hipMalloc(&out, (size_t)cus * 8 * 256 * sizeof(float));
+    {
+        unsigned long long* cw; hipMallocManaged(&cw, 16);
+        clock_probe<<<cus * 8, 256>>>(cw, out);
+        hipDeviceSynchronize();
+        int wall_khz = 0; hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+        printf("# clock probe (all SIMDs busy with v_fma_f32): %llu s_memtime ticks in %llu wall-clock ticks at %d kHz -> "
+               "s_memtime runs at %.1f MHz (a constant counter, NOT the shader clock on this part: cycles below use clockRate)\n",
+               cw[0], cw[1], wall_khz, (double)cw[0] / ((double)cw[1] / (wall_khz * 1e3)) * 1e-6);
+    }
     const int ws[] = {1, 2, 4, 8};
 #define SWEEP(M) for (int w : ws) run<M>(out, w, clk, cus);
     SWEEP(FMA) SWEEP(MUL_ADD) SWEEP(EXP) SWEEP(RCP) SWEEP(DPP_ADD) SWEEP(PERM32) SWEEP(PERM16) SWEEP(PK_FMA)
