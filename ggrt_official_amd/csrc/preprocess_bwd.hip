@@ -135,6 +135,7 @@ __device__ __forceinline__ void sh_basis25(int deg, float x, float y, float z, f
 // more than the occupancy gives: tools/sh_stage_bench.hip, 0.149 ms whole rows / 0.214 column thirds / 0.129 this).
 // CM (KC > 0 only): channel-major rows — a template parameter because with both row forms in one kernel the compiler
 // shares the basis gradients across the two branches: 199 VGPRs instead of 162 / 131.
+#define GGR_PBWD_CACHED_VIEWS 8   // views per set whose colour gradients are kept in LDS (4 KB each)
 template <bool POSE, bool MULTI, int KC, bool CM>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -147,7 +148,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_daux,
-                      float* __restrict__ pose_acc, InputForm inf, int cov_is_input) {
+                      float* __restrict__ pose_acc, InputForm inf, int cov_is_input, int dcol_off) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_stride]: SH in, dL/dSH out
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
@@ -222,10 +223,17 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
     float2 n2 = make_float2(0.f, 0.f);
     int nrad = 0;
+    uint32_t ncl = 0u;
     {
         const float4* rec = recs + (GGR_G2D_STRIDE / 4) * il;
         n0 = rec[0]; n1 = rec[1]; n2 = *reinterpret_cast<const float2*>(rec + 2); nrad = radii[il];
+        if (MULTI) ncl = clamped[il];
     }
+    // several views: every view's colour gradient (zeroed on clamped channels and for culled Gaussians) + its live flag
+    // stay in LDS behind the SH rows for the two SH phases below — they used to re-read the 64-B gradient records of
+    // every (view, Gaussian) twice more (C5', 4 views: 438 → 417 µs).  Each thread reads back only what it wrote.
+    float4* const dcol = reinterpret_cast<float4*>(sh_lds + dcol_off);
+    const bool dcol_cached = MULTI && use_sh && NV <= GGR_PBWD_CACHED_VIEWS;
 #pragma clang loop unroll(disable)
     for (int v = 0; v < NV; v++) {
         // (compiler barrier: without it the 3K SH coefficient reads from LDS below — invariant across views — are
@@ -238,9 +246,15 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float4 r1 = n1;  // mean.y, conic xx, xy, yy
         const float2 r2 = n2;  // opacity, z
         const bool live = in_range && nrad > 0;
+        if (dcol_cached) {
+            const uint32_t cl = ncl;
+            dcol[v * 256 + threadIdx.x] = make_float4(live && !(cl & 1u) ? r0.x : 0.f, live && !(cl & 2u) ? r0.y : 0.f,
+                                                      live && !(cl & 4u) ? r0.z : 0.f, live ? 1.f : 0.f);
+        }
         if (MULTI && v + 1 < NV) {
             const float4* rec = recs + (GGR_G2D_STRIDE / 4) * (o + P);
             n0 = rec[0]; n1 = rec[1]; n2 = *reinterpret_cast<const float2*>(rec + 2); nrad = radii[o + P];
+            ncl = clamped[o + P];
         }
         const float g_z = r2.y;
         if (in_range) {
@@ -559,17 +573,19 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         // LDS row then takes the gradient: the coefficients are no longer needed.
         // (1) the view-direction term of every view: dL/dmean += (∂dir/∂mean)ᵀ Σ_k ∇B_k(dir)·(sh_k · dL/dcolour)
         // (loads one view ahead, as above)
-        float4 q0 = recs[(GGR_G2D_STRIDE / 4) * il];
-        int qrad = radii[il];
-        uint32_t qcl = clamped[il];
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int qrad = 0;
+        uint32_t qcl = 0u;
+        if (!dcol_cached) { q0 = recs[(GGR_G2D_STRIDE / 4) * il]; qrad = radii[il]; qcl = clamped[il]; }
 #pragma clang loop unroll(disable)
         for (int v = 0; v < NV; v++) {
             __asm__ volatile("" ::: "memory");
             const size_t o = (size_t)v * P + il;
-            const float4 r0 = q0;  // r, g, b, –
-            const bool live = in_range && qrad > 0;
-            const uint32_t cl = qcl;
-            if (MULTI && v + 1 < NV) { q0 = recs[(GGR_G2D_STRIDE / 4) * (o + P)]; qrad = radii[o + P]; qcl = clamped[o + P]; }
+            float4 r0 = q0;  // r, g, b, –
+            bool live = in_range && qrad > 0;
+            uint32_t cl = qcl;
+            if (dcol_cached) { r0 = dcol[v * 256 + threadIdx.x]; live = r0.w != 0.f; cl = 0u; }  // (already masked)
+            else if (MULTI && v + 1 < NV) { q0 = recs[(GGR_G2D_STRIDE / 4) * (o + P)]; qrad = radii[o + P]; qcl = clamped[o + P]; }
             float dcam[3] = {0.f, 0.f, 0.f};
             if (live) {
             float dc0 = r0.x, dc1 = r0.y, dc2 = r0.z;
@@ -650,15 +666,19 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 float acc[GGR_SH_MAXK];
 #pragma unroll
                 for (int k = 0; k < GGR_SH_MAXK; k++) acc[k] = 0.f;
-                float ndc = grad2d[GGR_G2D_STRIDE * il + GGR_G2D_RGB + c];
-                int prad = radii[il];
-                uint32_t pcl = clamped[il];
+                float ndc = 0.f;
+                int prad = 0;
+                uint32_t pcl = 0u;
+                if (!dcol_cached) { ndc = grad2d[GGR_G2D_STRIDE * il + GGR_G2D_RGB + c]; prad = radii[il]; pcl = clamped[il]; }
 #pragma clang loop unroll(disable)
                 for (int v = 0; v < NV; v++) {
                     const size_t o = (size_t)v * P + il;
-                    const float dc = ndc;
-                    const bool use = in_range && prad > 0 && !((pcl >> c) & 1u);
-                    if (MULTI && v + 1 < NV) {
+                    float dc = ndc;
+                    bool use = in_range && prad > 0 && !((pcl >> c) & 1u);
+                    if (dcol_cached) {   // (a zero — culled, clamped — adds zeros: skipped)
+                        dc = reinterpret_cast<const float*>(dcol + v * 256 + threadIdx.x)[c];
+                        use = dc != 0.f;
+                    } else if (MULTI && v + 1 < NV) {
                         ndc = grad2d[GGR_G2D_STRIDE * (o + P) + GGR_G2D_RGB + c]; prad = radii[o + P]; pcl = clamped[o + P];
                     }
                     if (use) {
@@ -682,7 +702,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
         __syncthreads();
         // coalesced write-out of dL/dSH: the first 3K floats of every row from LDS, the rest zero
-        if (sh_compact) {
+        if (sh_compact) {   // (written as whole float4s in address order instead — every line complete, but (row, column)
+            // arithmetic per element — the multi-view kernel was slower: C5', 4 views, 417 → 441 µs; not kept)
             write_sh_rows_compact(dL_dsh, sh_lds, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
         } else if (sh_flat) {
             const size_t total = (size_t)nG * sh_row;
@@ -785,13 +806,16 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     const bool use_sh = !has_colors_precomp && shs;
     const int kc = (use_sh && !multi && (deg == 3 || deg == 4) && 3 * M > 64 &&
                     inf.sh_aligned) ? (deg + 1) * (deg + 1) : 0;
-    const size_t lds = !use_sh ? 0 : kc ? sizeof(float) * (size_t)std::max(256 * (kc | 1), 88 * 3 * M)
-                                        : (size_t)256 * row_stride * sizeof(float);
+    size_t lds = !use_sh ? 0 : kc ? sizeof(float) * (size_t)std::max(256 * (kc | 1), 88 * 3 * M)
+                                  : (size_t)256 * row_stride * sizeof(float);
+    // several views: room for their colour gradients behind the rows (16-B aligned)
+    const int dcol_off = (int)(((lds + 15) & ~(size_t)15) / sizeof(float));
+    if (use_sh && multi && vs.vps <= GGR_PBWD_CACHED_VIEWS) lds = (size_t)dcol_off * sizeof(float) + (size_t)vs.vps * 256 * sizeof(float4);
 #define GGR_LAUNCH_PBWD(POSE_, MULTI_, KC_, CM_)                                                                            \
     hipLaunchKernelGGL((preprocess_bwd_kernel<POSE_, MULTI_, KC_, CM_>), dim3(blocks, vs.sets), dim3(256), lds, s, P, D, M, means3D, shs, \
                        has_colors_precomp, scales, rotations, scale_modifier, cov3D, vs, W, H, radii, clamped, grad2d,     \
                        has_dz, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales,   \
-                       dL_drotations, dL_daux, pose_acc, inf, cov_is_input)
+                       dL_drotations, dL_daux, pose_acc, inf, cov_is_input, dcol_off)
 #define GGR_LAUNCH_PBWD_P(POSE_)                                                                                         \
     do {                                                                                                                  \
         if (multi) GGR_LAUNCH_PBWD(POSE_, true, 0, false);                                                                \

@@ -1,0 +1,12 @@
+#!/bin/bash
+# dev: on the GPU box, time every library variant under gpurun_variants/<name>/ with the kernel trace of the 4-view call site
+PAT=${1:-preprocess}
+R=$GRAFT_REPO_ROOT
+cp $R/ggrt_official_amd/libggr_raster.so /tmp/base.so
+for d in $R/gpurun_variants/*/; do
+  n=$(basename $d)
+  cp $d/libggr_raster.so $R/ggrt_official_amd/libggr_raster.so
+  scripts/quick_trace_views.sh var_$n measure_views > /dev/null 2>&1
+  echo "== $n"; grep -E "$PAT" $R/gpurun_out/var_$n/measure_views_kernel_stats.txt | cut -c1-110; grep batched_ms $R/gpurun_out/var_$n/views.log | tail -1
+done
+cp /tmp/base.so $R/ggrt_official_amd/libggr_raster.so
