@@ -192,6 +192,23 @@ class Workload:
         return out
 
 
+def measured_copy_bandwidth(dev, mbytes: int = 512, reps: int = 5) -> float:
+    """Device-to-device copy of `mbytes` MB (read + write counted), best of `reps`, GB/s: what a pure streaming kernel
+    reaches on THIS part — the practical ceiling next to the 8 TB/s spec (SURVEY.md §8d asks for the on-box figure)."""
+    n = mbytes * (1 << 20) // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    best = 1e9
+    for _ in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        best = min(best, e0.elapsed_time(e1))
+    return 2 * n * 4 / (best * 1e-3) / 1e9
+
+
 def timed_steps(fn, steps: int, warmup: int, dev, barrier=None, finish=None):
     """`warmup` untimed calls, then EXACTLY `steps` calls bracketed by barrier + synchronize on both sides.
     Returns (wall seconds of the bracket, per-step ms from HIP events recorded on the launch stream)."""
@@ -534,6 +551,16 @@ def main():
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
         }
         rec.update(rf)
+        # the blend's algorithmic flops, F = 20 · Σ_tiles |list| · 256 forward (× 2.5 backward), against
+        # the kernels' HIP-event times (the figures exceed the fp32 vector peak where the exact quadrant cull never
+        # evaluates most of those pairs), and the streaming ceiling measured on this part
+        rec["blend_algorithmic_tflops"] = {"fwd": round(20.0 * N * 256 / (stages["fwd_blend_ms"] * 1e-3) / 1e12, 1),
+                                           "bwd": round(50.0 * N * 256 / (stages["bwd_blend_ms"] * 1e-3) / 1e12, 1),
+                                           "fp32_vector_peak_spec": 157.3, "fp32_fma_measured": 126.7}
+        try:
+            rec["hbm_copy_GBps_measured"] = round(measured_copy_bandwidth(dev), 1)
+        except Exception as e:
+            log(f"copy bandwidth leg skipped: {type(e).__name__}: {e}")
         if valu:
             rec["blend_valu_issue"] = valu
         if multi:
