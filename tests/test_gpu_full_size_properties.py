@@ -104,3 +104,60 @@ def test_c3_centre_crop_matches_the_full_frame():
     assert float(ref.abs().mean()) > 0.05
     assert float((d > 1e-4).float().mean()) < 2e-3      # a handful of threshold pixels may flip (projection rounding)
     assert float(d.mean()) < 1e-5
+
+
+def test_window_cells_add_up_at_full_size():
+    """The deferred back-propagation pattern at C3 (round 3): the gradients of the four cells of a 2 × 2 grid — each
+    a windowed upstream gradient, three of them through a scissored forward as well — add up to the whole-frame
+    backward (linearity + exactness of the zero-gradient skip and of the scissor at the benchmark's size)."""
+    from ggrt_official_amd import GaussianRasterizer
+    sc = make_scene(**CONFIGS["C3"])
+    s = sc.to(dev)
+    W, H = sc.width, sc.height
+    dL = upstream_gradient(W, H, seed=17, device=dev)
+    _, _, whole = _fwd_bwd(s, dL)
+    total = [torch.zeros_like(g, dtype=torch.float64) for g in whole]
+    full_color = None
+    for i in range(2):
+        for j in range(2):
+            x0, y0, x1, y1 = j * W // 2, i * H // 2, (j + 1) * W // 2, (i + 1) * H // 2
+            mask = torch.zeros(H, W, device=dev)
+            mask[y0:y1, x0:x1] = 1.0
+            leaves = [t.clone().requires_grad_() for t in (s.means3D, s.shs, s.opacities, s.cov3D)]
+            m, sh, op, cov = leaves
+            rs = s.settings() if (i, j) == (0, 0) else s.settings()._replace(scissor=(x0, y0, x1, y1))
+            color, _, _ = GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros_like(m), opacities=op, shs=sh, cov3D_precomp=cov)
+            if full_color is None:
+                full_color = color.detach()
+            else:   # inside its window a scissored render IS the full render
+                assert torch.equal(color.detach()[:, y0:y1, x0:x1], full_color[:, y0:y1, x0:x1])
+            color.backward(dL * mask)
+            for t, g in zip(total, leaves):
+                t += g.grad.double()
+    for t, w in zip(total, whole):
+        assert rel_l2(t.cpu().numpy(), w.double().cpu().numpy()) < 2e-6
+
+
+def test_two_gaussian_sets_at_ggrt_shape_equal_two_calls():
+    """GgrViews.num_sets at GGRt's training shape (C5′ × 2 different scenes): bit-identical images and radii, same
+    gradients per set as two separate calls."""
+    from ggrt_official_amd import GaussianRasterizer, rasterize_views
+    cfg = CONFIGS["C5p"]
+    scs = [make_scene(seed=s, **cfg).to(dev) for s in (0, 1)]
+    W, H = scs[0].width, scs[0].height
+    dLs = torch.stack([upstream_gradient(W, H, seed=30 + k, device=dev) for k in range(2)])
+    single = []
+    for k, s in enumerate(scs):
+        c, r, g = _fwd_bwd(s, dLs[k])
+        single.append((c, r, g))
+    stack = lambda f: torch.stack([f(s) for s in scs]).clone().requires_grad_()
+    m, sh, op, cov = stack(lambda s: s.means3D), stack(lambda s: s.shs), stack(lambda s: s.opacities), stack(lambda s: s.cov3D)
+    view = torch.stack([s.viewmatrix for s in scs]); proj = torch.stack([s.projmatrix for s in scs])
+    cam = torch.stack([s.campos for s in scs]); bg = torch.stack([s.bg for s in scs])
+    tf = torch.tensor([[s.tanfovx, s.tanfovy] for s in scs], dtype=torch.float32, device=dev)
+    color, radii, _ = rasterize_views(m, op, view, proj, cam, bg, tf, scs[0].settings(), shs=sh, cov3D_precomp=cov)
+    color.backward(dLs)
+    for k in range(2):
+        assert torch.equal(color[k].detach(), single[k][0]) and torch.equal(radii[k], single[k][1])
+        for got, want in zip((m.grad[k], sh.grad[k], op.grad[k], cov.grad[k]), single[k][2]):
+            assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) < 2e-6

@@ -111,3 +111,47 @@ def test_scissor_validation():
     # a window beyond the image clips to nothing: background everywhere, no error
     c, r, d = GaussianRasterizer(sc.settings()._replace(scissor=(640, 480, 700, 500)))(**args)
     assert torch.equal(c, sc.bg[:, None, None].expand_as(c)) and not r.any()
+
+
+def test_colour_and_depth_gradients_with_different_windows():
+    """A pixel is skipped only when ALL of its upstream gradients are zero: colour gradient in one window, depth gradient
+    in another (overlapping) one."""
+    W, H = 200, 136
+    sc = make_scene(30000, W, H, sh_degree=1, profile="B", seed=23)
+    dL = upstream_gradient(W, H, seed=9)
+    dLd = upstream_gradient(W, H, seed=10)[0]
+    mc, md = torch.zeros(H, W), torch.zeros(H, W)
+    mc[20:70, 30:120] = 1.0
+    md[50:110, 90:180] = 1.0
+    _, _, _, g = _run(sc, dL * mc, dLd * md)
+    alive = (1.0 - torch.maximum(mc, md)) * 1e-30
+    _, _, _, ref = _run(sc, dL * mc + alive, dLd * md + alive)
+    for k in KEYS + ("means2D",):
+        assert rel_l2(g[k], ref[k]) < 1e-6, k
+    assert np.abs(g["means3D"]).max() > 1e-9
+
+
+def test_scissor_with_several_views_and_sets():
+    """The scissor applies to every view of a launch set (views of one set, and sets)."""
+    from ggrt_official_amd import rasterize_views
+    from ggrt_official_amd.synthetic import camera_matrices
+    W, H, P = 160, 112, 8000
+    scs = [make_scene(P, W, H, sh_degree=2, seed=40 + b) for b in range(2)]
+    cams = [camera_matrices(W, H) for _ in range(4)]
+    dev = "cuda:0"
+    view = torch.stack([c[0] for c in cams]).to(dev); proj = torch.stack([c[1] for c in cams]).to(dev)
+    cam = torch.stack([c[2] for c in cams]).to(dev)
+    tf = torch.tensor([[c[3], c[4]] for c in cams], dtype=torch.float32, device=dev)
+    bg = torch.rand(4, 3).to(dev)
+    stack = lambda f: torch.stack([f(s) for s in scs]).to(dev)
+    args = (stack(lambda s: s.means3D), stack(lambda s: s.opacities), view, proj, cam, bg, tf)
+    kw = dict(shs=stack(lambda s: s.shs), cov3D_precomp=stack(lambda s: s.cov3D))
+    rs = scs[0].to(dev).settings()
+    full, _, _ = rasterize_views(*args, rs, **kw)
+    win = (37, 20, 101, 77)
+    part, radii, _ = rasterize_views(*args, rs._replace(scissor=win), **kw)
+    tx0, ty0, tx1, ty1 = win[0] // 16 * 16, win[1] // 16 * 16, -(-win[2] // 16) * 16, -(-win[3] // 16) * 16
+    assert torch.equal(part[:, :, ty0:ty1, tx0:tx1], full[:, :, ty0:ty1, tx0:tx1])
+    out = torch.ones(H, W, dtype=torch.bool, device=dev)
+    out[ty0:ty1, tx0:tx1] = False
+    assert torch.equal(part[:, :, out], bg[:, :, None].expand(4, 3, int(out.sum())))
