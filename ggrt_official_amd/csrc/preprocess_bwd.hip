@@ -148,7 +148,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_daux,
-                      float* __restrict__ pose_acc, InputForm inf, int cov_is_input, int dcol_off) {
+                      float* __restrict__ pose_acc, InputForm inf, int cov_is_input, int dcol_off,
+                      int sh_split /*several views: dL/dSH comes from preprocess_bwd_sh_views_kernel instead*/) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_stride]: SH in, dL/dSH out
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
@@ -643,7 +644,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             }
         }
         float* dsh = sh_lds + threadIdx.x * sh_stride;
-        if (!MULTI) {
+        if (MULTI) {
+            // (several views: the gradient rows are formed and written by preprocess_bwd_sh_views_kernel — compiled out
+            //  here, the phase below cost this kernel half its occupancy)
+        } else if (!MULTI) {
             // one view: the live rows already hold their gradient; culled Gaussians get zero rows, coefficients of
             // bands that were not evaluated zero gradient
             if (in_range && !(radii[il] > 0)) {
@@ -656,7 +660,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     for (int k = sh_rowf; k < (int)sh_row; k++) dsh[k] = 0.f;
                 }
             }
-        } else {
+        } else if (false) {   // (round 2's in-kernel form, kept for reference: one colour channel at a time)
             if (in_range && !sh_compact) {
                 const int rowlen = sh_flat ? (int)sh_row : copy_row;
                 for (int k = 0; k < rowlen; k++) dsh[k] = 0.f;  // unused coefficients of a staged row: zero gradient
@@ -702,7 +706,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
         __syncthreads();
         // coalesced write-out of dL/dSH: the first 3K floats of every row from LDS, the rest zero
-        if (sh_compact) {   // (written as whole float4s in address order instead — every line complete, but (row, column)
+        if (MULTI) {
+        } else if (sh_compact) {   // (written as whole float4s in address order instead — every line complete, but (row, column)
             // arithmetic per element — the multi-view kernel was slower: C5', 4 views, 417 → 441 µs; not kept)
             write_sh_rows_compact(dL_dsh, sh_lds, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
         } else if (sh_flat) {
@@ -750,6 +755,93 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         } else {
 #pragma unroll
             for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+        }
+    }
+}
+
+// dL/dSH of a launch set with SEVERAL views per Gaussian set (round 3): dL/dSH[k][c] = Σ_views B_k(direction of the
+// view) · dL/dcolour_c(view).  Inside preprocess_bwd_kernel<·, MULTI> this phase cost the whole kernel its occupancy
+// (25 accumulators + 25 basis values on top of the geometry backward's live state: 216-223 VGPRs, 2 waves per SIMD,
+// 2.4 TB/s where the one-view kernels reach 4.9): on its own it needs 3·K accumulators, the basis and little else.
+// Reads per (view, Gaussian) the colour part of the blend's gradient record, the radius and the clamp bits; writes the
+// rows through LDS in three row ranges of the block (whole 128-B lines, as the one-view long-row path does).
+template <int KMAX>
+__global__ void __launch_bounds__(256)
+preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ means3D, ViewSet vs,
+                               const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped,
+                               const float* __restrict__ grad2d, float* __restrict__ dL_dsh, InputForm inf) {
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [88][3M]: one row range of gradient rows
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = i < P;
+    const size_t il = (size_t)min(i, P - 1);
+    {   // Gaussian set blockIdx.y (as in preprocess_bwd_kernel)
+        const int set = (int)blockIdx.y, v0 = set * vs.vps;
+        const size_t in_off = (size_t)set * (size_t)P, st_off = (size_t)v0 * (size_t)P;
+        means3D += 3 * in_off; dL_dsh += in_off * (size_t)M * 3;
+        radii += st_off; clamped += st_off; grad2d += GGR_G2D_STRIDE * st_off;
+        vs.campos += 3 * v0;
+        if (vs.input_scale) vs.input_scale += v0;
+    }
+    const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];
+    const int K = (deg + 1) * (deg + 1);
+    float acc[3][KMAX];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) acc[c][k] = 0.f;
+    const float4* recs = reinterpret_cast<const float4*>(grad2d);
+    float4 q0 = recs[(GGR_G2D_STRIDE / 4) * il];
+    int qrad = radii[il];
+    uint32_t qcl = clamped[il];
+#pragma clang loop unroll(disable)
+    for (int v = 0; v < vs.vps; v++) {
+        const size_t o = (size_t)v * P + il;
+        const float4 r0 = q0;
+        const bool live = in_range && qrad > 0;
+        const uint32_t cl = qcl;
+        if (v + 1 < vs.vps) { q0 = recs[(GGR_G2D_STRIDE / 4) * (o + P)]; qrad = radii[o + P]; qcl = clamped[o + P]; }
+        if (live) {
+            const float dc0 = (cl & 1u) ? 0.f : r0.x, dc1 = (cl & 2u) ? 0.f : r0.y, dc2 = (cl & 4u) ? 0.f : r0.z;
+            const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
+            const float vx = in_s * m0 - vs.campos[3 * v], vy = in_s * m1 - vs.campos[3 * v + 1], vz = in_s * m2 - vs.campos[3 * v + 2];
+            const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+            float B[GGR_SH_MAXK];
+            sh_basis25(deg, vx / len, vy / len, vz / len, B);
+#pragma unroll
+            for (int k = 0; k < KMAX; k++)
+                if (k < K) { acc[0][k] += B[k] * dc0; acc[1][k] += B[k] * dc1; acc[2][k] += B[k] * dc2; }
+        }
+    }
+    // rows out: three row ranges of the block through LDS, flat float4 copies (84 rows: a multiple of 4 → 16-B aligned)
+    const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+    const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
+    const int rowlen = 3 * M;
+    const bool cm = inf.sh_channel_major != 0;
+    const int pk = cm ? 1 : 3, pc = cm ? M : 1;   // coefficient k, channel c sits at k·pk + c·pc
+#pragma unroll 1
+    for (int R = 0; R < 3; R++) {
+        const int r0 = 84 * R, r1 = R == 2 ? 256 : r0 + 84;
+        if (R) __syncthreads();  // the previous range has been copied out
+        if ((int)threadIdx.x >= r0 && (int)threadIdx.x < r1 && in_range) {
+            float* rowp = sh_lds + ((int)threadIdx.x - r0) * rowlen;
+#pragma unroll
+            for (int k = 0; k < KMAX; k++)
+                if (k < K) { rowp[k * pk] = acc[0][k]; rowp[k * pk + pc] = acc[1][k]; rowp[k * pk + 2 * pc] = acc[2][k]; }
+            for (int k = K; k < M; k++) { rowp[k * pk] = 0.f; rowp[k * pk + pc] = 0.f; rowp[k * pk + 2 * pc] = 0.f; }  // bands not evaluated
+        }
+        __syncthreads();
+        const int nrow = min(r1, nG) - r0;
+        if (nrow > 0) {
+            const int total = nrow * rowlen;
+            float* dst = dL_dsh + (g0 + r0) * (size_t)rowlen;
+            if (inf.sh_aligned && ((rowlen * 4) & 3) == 0) {   // (84·rowlen·4 B is a multiple of 16)
+                const int n4 = total >> 2;
+                for (int j = threadIdx.x; j < n4; j += 256)
+                    reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(sh_lds)[j];
+                for (int j = (n4 << 2) + threadIdx.x; j < total; j += 256) dst[j] = sh_lds[j];
+            } else {
+                for (int j = threadIdx.x; j < total; j += 256) dst[j] = sh_lds[j];
+            }
         }
     }
 }
@@ -802,6 +894,7 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
     const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
     const bool multi = vs.vps > 1;
+    const int sh_split = (multi && !has_colors_precomp && shs && dL_dsh) ? 1 : 0;
     // one view at degree 3 / 4 with long rows: rows read by thirds, gradient rows written by row ranges (kernel header)
     const bool use_sh = !has_colors_precomp && shs;
     const int kc = (use_sh && !multi && (deg == 3 || deg == 4) && 3 * M > 64 &&
@@ -815,7 +908,7 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     hipLaunchKernelGGL((preprocess_bwd_kernel<POSE_, MULTI_, KC_, CM_>), dim3(blocks, vs.sets), dim3(256), lds, s, P, D, M, means3D, shs, \
                        has_colors_precomp, scales, rotations, scale_modifier, cov3D, vs, W, H, radii, clamped, grad2d,     \
                        has_dz, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales,   \
-                       dL_drotations, dL_daux, pose_acc, inf, cov_is_input, dcol_off)
+                       dL_drotations, dL_daux, pose_acc, inf, cov_is_input, dcol_off, sh_split)
 #define GGR_LAUNCH_PBWD_P(POSE_)                                                                                         \
     do {                                                                                                                  \
         if (multi) GGR_LAUNCH_PBWD(POSE_, true, 0, false);                                                                \
@@ -825,6 +918,15 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
         else if (kc == 25) GGR_LAUNCH_PBWD(POSE_, false, 25, false);                                                      \
         else GGR_LAUNCH_PBWD(POSE_, false, 0, false);                                                                     \
     } while (0)
+    if (sh_split) {   // several views: the gradient rows of the SH coefficients, on their own (see the kernel)
+        const size_t lds_sh = (size_t)88 * 3 * M * sizeof(float);
+        if (deg >= 4)
+            hipLaunchKernelGGL((preprocess_bwd_sh_views_kernel<25>), dim3(blocks, vs.sets), dim3(256), lds_sh, s, P, M, deg, means3D, vs,
+                               radii, clamped, grad2d, dL_dsh, inf);
+        else
+            hipLaunchKernelGGL((preprocess_bwd_sh_views_kernel<16>), dim3(blocks, vs.sets), dim3(256), lds_sh, s, P, M, deg, means3D, vs,
+                               radii, clamped, grad2d, dL_dsh, inf);
+    }
     if (pose_acc) {
         GGR_LAUNCH_PBWD_P(true);
         hipLaunchKernelGGL(pose_finish_kernel, dim3(35, vs.V), dim3(256), 0, s, pose_acc, blocks, dL_dview, dL_dproj,
