@@ -135,7 +135,6 @@ __device__ __forceinline__ void sh_basis25(int deg, float x, float y, float z, f
 // more than the occupancy gives: tools/sh_stage_bench.hip, 0.149 ms whole rows / 0.214 column thirds / 0.129 this).
 // CM (KC > 0 only): channel-major rows — a template parameter because with both row forms in one kernel the compiler
 // shares the basis gradients across the two branches: 199 VGPRs instead of 162 / 131.
-#define GGR_PBWD_CACHED_VIEWS 8   // views per set whose colour gradients are kept in LDS (4 KB each)
 template <bool POSE, bool MULTI, int KC, bool CM>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -148,8 +147,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors_precomp,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_daux,
-                      float* __restrict__ pose_acc, InputForm inf, int cov_is_input, int dcol_off,
-                      int sh_split /*several views: dL/dSH comes from preprocess_bwd_sh_views_kernel instead*/) {
+                      float* __restrict__ pose_acc, InputForm inf, int cov_is_input) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_stride]: SH in, dL/dSH out
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
@@ -177,7 +175,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (vs.input_scale) vs.input_scale += v0;
     }
     // coalesced staging of the block's SH rows (same reason as in preprocess_fwd)
-    const bool use_sh = !has_colors_precomp && shs != nullptr;
+    // (several views per set: the whole SH backward — direction term and gradient rows — is preprocess_bwd_sh_views_kernel's)
+    const bool use_sh = !MULTI && !has_colors_precomp && shs != nullptr;
     const int deg = ggr_sh_degree(D, use_sh ? M : 25, inf.sh_cap);
     const int sh_rowf = 3 * (deg + 1) * (deg + 1);
     const size_t g0 = (size_t)blockIdx.x * blockDim.x;
@@ -224,17 +223,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
     float2 n2 = make_float2(0.f, 0.f);
     int nrad = 0;
-    uint32_t ncl = 0u;
     {
         const float4* rec = recs + (GGR_G2D_STRIDE / 4) * il;
         n0 = rec[0]; n1 = rec[1]; n2 = *reinterpret_cast<const float2*>(rec + 2); nrad = radii[il];
-        if (MULTI) ncl = clamped[il];
     }
-    // several views: every view's colour gradient (zeroed on clamped channels and for culled Gaussians) + its live flag
-    // stay in LDS behind the SH rows for the two SH phases below — they used to re-read the 64-B gradient records of
-    // every (view, Gaussian) twice more (C5', 4 views: 438 → 417 µs).  Each thread reads back only what it wrote.
-    float4* const dcol = reinterpret_cast<float4*>(sh_lds + dcol_off);
-    const bool dcol_cached = MULTI && use_sh && NV <= GGR_PBWD_CACHED_VIEWS;
 #pragma clang loop unroll(disable)
     for (int v = 0; v < NV; v++) {
         // (compiler barrier: without it the 3K SH coefficient reads from LDS below — invariant across views — are
@@ -247,15 +239,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float4 r1 = n1;  // mean.y, conic xx, xy, yy
         const float2 r2 = n2;  // opacity, z
         const bool live = in_range && nrad > 0;
-        if (dcol_cached) {
-            const uint32_t cl = ncl;
-            dcol[v * 256 + threadIdx.x] = make_float4(live && !(cl & 1u) ? r0.x : 0.f, live && !(cl & 2u) ? r0.y : 0.f,
-                                                      live && !(cl & 4u) ? r0.z : 0.f, live ? 1.f : 0.f);
-        }
         if (MULTI && v + 1 < NV) {
             const float4* rec = recs + (GGR_G2D_STRIDE / 4) * (o + P);
             n0 = rec[0]; n1 = rec[1]; n2 = *reinterpret_cast<const float2*>(rec + 2); nrad = radii[o + P];
-            ncl = clamped[o + P];
         }
         const float g_z = r2.y;
         if (in_range) {
@@ -574,19 +560,17 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         // LDS row then takes the gradient: the coefficients are no longer needed.
         // (1) the view-direction term of every view: dL/dmean += (∂dir/∂mean)ᵀ Σ_k ∇B_k(dir)·(sh_k · dL/dcolour)
         // (loads one view ahead, as above)
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        int qrad = 0;
-        uint32_t qcl = 0u;
-        if (!dcol_cached) { q0 = recs[(GGR_G2D_STRIDE / 4) * il]; qrad = radii[il]; qcl = clamped[il]; }
+        float4 q0 = recs[(GGR_G2D_STRIDE / 4) * il];
+        int qrad = radii[il];
+        uint32_t qcl = clamped[il];
 #pragma clang loop unroll(disable)
         for (int v = 0; v < NV; v++) {
             __asm__ volatile("" ::: "memory");
             const size_t o = (size_t)v * P + il;
-            float4 r0 = q0;  // r, g, b, –
-            bool live = in_range && qrad > 0;
-            uint32_t cl = qcl;
-            if (dcol_cached) { r0 = dcol[v * 256 + threadIdx.x]; live = r0.w != 0.f; cl = 0u; }  // (already masked)
-            else if (MULTI && v + 1 < NV) { q0 = recs[(GGR_G2D_STRIDE / 4) * (o + P)]; qrad = radii[o + P]; qcl = clamped[o + P]; }
+            const float4 r0 = q0;  // r, g, b, –
+            const bool live = in_range && qrad > 0;
+            const uint32_t cl = qcl;
+            if (MULTI && v + 1 < NV) { q0 = recs[(GGR_G2D_STRIDE / 4) * (o + P)]; qrad = radii[o + P]; qcl = clamped[o + P]; }
             float dcam[3] = {0.f, 0.f, 0.f};
             if (live) {
             float dc0 = r0.x, dc1 = r0.y, dc2 = r0.z;
@@ -644,10 +628,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             }
         }
         float* dsh = sh_lds + threadIdx.x * sh_stride;
-        if (MULTI) {
-            // (several views: the gradient rows are formed and written by preprocess_bwd_sh_views_kernel — compiled out
-            //  here, the phase below cost this kernel half its occupancy)
-        } else if (!MULTI) {
+        if (!MULTI) {
             // one view: the live rows already hold their gradient; culled Gaussians get zero rows, coefficients of
             // bands that were not evaluated zero gradient
             if (in_range && !(radii[il] > 0)) {
@@ -660,54 +641,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     for (int k = sh_rowf; k < (int)sh_row; k++) dsh[k] = 0.f;
                 }
             }
-        } else if (false) {   // (round 2's in-kernel form, kept for reference: one colour channel at a time)
-            if (in_range && !sh_compact) {
-                const int rowlen = sh_flat ? (int)sh_row : copy_row;
-                for (int k = 0; k < rowlen; k++) dsh[k] = 0.f;  // unused coefficients of a staged row: zero gradient
-            }
-#pragma clang loop unroll(disable)
-            for (int c = 0; c < 3; c++) {
-                float acc[GGR_SH_MAXK];
-#pragma unroll
-                for (int k = 0; k < GGR_SH_MAXK; k++) acc[k] = 0.f;
-                float ndc = 0.f;
-                int prad = 0;
-                uint32_t pcl = 0u;
-                if (!dcol_cached) { ndc = grad2d[GGR_G2D_STRIDE * il + GGR_G2D_RGB + c]; prad = radii[il]; pcl = clamped[il]; }
-#pragma clang loop unroll(disable)
-                for (int v = 0; v < NV; v++) {
-                    const size_t o = (size_t)v * P + il;
-                    float dc = ndc;
-                    bool use = in_range && prad > 0 && !((pcl >> c) & 1u);
-                    if (dcol_cached) {   // (a zero — culled, clamped — adds zeros: skipped)
-                        dc = reinterpret_cast<const float*>(dcol + v * 256 + threadIdx.x)[c];
-                        use = dc != 0.f;
-                    } else if (MULTI && v + 1 < NV) {
-                        ndc = grad2d[GGR_G2D_STRIDE * (o + P) + GGR_G2D_RGB + c]; prad = radii[o + P]; pcl = clamped[o + P];
-                    }
-                    if (use) {
-                        const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
-                        const float vx = in_s * m0 - vs.campos[3 * v], vy = in_s * m1 - vs.campos[3 * v + 1],
-                                    vz = in_s * m2 - vs.campos[3 * v + 2];
-                        const float len = sqrtf(vx * vx + vy * vy + vz * vz);
-                        float B[GGR_SH_MAXK];
-                        sh_basis25(deg, vx / len, vy / len, vz / len, B);
-#pragma unroll
-                        for (int k = 0; k < GGR_SH_MAXK; k++)
-                            if (k < K) acc[k] += B[k] * dc;
-                    }
-                }
-                if (in_range) {
-#pragma unroll
-                    for (int k = 0; k < GGR_SH_MAXK; k++)
-                        if (k < K) dsh[k * sh_ks + c * sh_cs] = acc[k];
-                }
-            }
         }
         __syncthreads();
         // coalesced write-out of dL/dSH: the first 3K floats of every row from LDS, the rest zero
-        if (MULTI) {
-        } else if (sh_compact) {   // (written as whole float4s in address order instead — every line complete, but (row, column)
+        if (sh_compact) {   // (written as whole float4s in address order instead — every line complete, but (row, column)
             // arithmetic per element — the multi-view kernel was slower: C5', 4 views, 417 → 441 µs; not kept)
             write_sh_rows_compact(dL_dsh, sh_lds, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
         } else if (sh_flat) {
@@ -759,69 +696,143 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     }
 }
 
-// dL/dSH of a launch set with SEVERAL views per Gaussian set (round 3): dL/dSH[k][c] = Σ_views B_k(direction of the
-// view) · dL/dcolour_c(view).  Inside preprocess_bwd_kernel<·, MULTI> this phase cost the whole kernel its occupancy
-// (25 accumulators + 25 basis values on top of the geometry backward's live state: 216-223 VGPRs, 2 waves per SIMD,
-// 2.4 TB/s where the one-view kernels reach 4.9): on its own it needs 3·K accumulators, the basis and little else.
-// Reads per (view, Gaussian) the colour part of the blend's gradient record, the radius and the clamp bits; writes the
-// rows through LDS in three row ranges of the block (whole 128-B lines, as the one-view long-row path does).
-template <int KMAX>
-__global__ void __launch_bounds__(256)
-preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ means3D, ViewSet vs,
-                               const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped,
-                               const float* __restrict__ grad2d, float* __restrict__ dL_dsh, InputForm inf) {
-    extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [88][3M]: one row range of gradient rows
+// The SH backward of a launch set with SEVERAL views per Gaussian set (round 3), in a kernel of its own:
+//   dL/dSH[k][c]  = Σ_views B_k(direction of the view) · dL/dcolour_c(view)                       (gradient rows)
+//   dL/dmean     += Σ_views (∂dir/∂mean)ᵀ Σ_k ∇B_k(dir) · (sh_k · dL/dcolour(view))               (direction term)
+//   dL/dcampos(view) −= the same term, summed over the Gaussians                                   (POSE)
+// Inside preprocess_bwd_kernel<·, MULTI> these phases cost that kernel its occupancy (the SH rows in LDS, 25 accumulators
+// + 25 basis values on top of the geometry backward's live state: 216-223 VGPRs, 2 waves per SIMD, 2.4 TB/s where the
+// one-view kernels reach 4.9; C5', 4 views: 438 µs → main kernel without them + this kernel).  Runs BEHIND
+// the main kernel on the same stream: it adds to the dL/dmeans3D and to the camera rows that kernel wrote.
+// Reads per (view, Gaussian) the colour part of the blend's gradient record, the radius and the clamp bits; the SH rows
+// once, through LDS; writes the gradient rows through the same LDS in three row ranges of the block (whole 128-B lines).
+#ifndef GGR_SHV_WAVES
+#define GGR_SHV_WAVES 1
+#endif
+template <int KMAX, bool POSE>
+__global__ void __launch_bounds__(256, GGR_SHV_WAVES)
+preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ means3D, const float* __restrict__ shs,
+                               ViewSet vs, const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped,
+                               const float* __restrict__ grad2d, float* __restrict__ dL_dmeans3D,
+                               float* __restrict__ dL_dsh, float* __restrict__ pose_acc, InputForm inf) {
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // the block's SH rows, then [88][3M] gradient rows
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < P;
     const size_t il = (size_t)min(i, P - 1);
     {   // Gaussian set blockIdx.y (as in preprocess_bwd_kernel)
         const int set = (int)blockIdx.y, v0 = set * vs.vps;
         const size_t in_off = (size_t)set * (size_t)P, st_off = (size_t)v0 * (size_t)P;
-        means3D += 3 * in_off; dL_dsh += in_off * (size_t)M * 3;
+        means3D += 3 * in_off; shs += in_off * (size_t)M * 3;
+        dL_dmeans3D += 3 * in_off; dL_dsh += in_off * (size_t)M * 3;
         radii += st_off; clamped += st_off; grad2d += GGR_G2D_STRIDE * st_off;
+        if (POSE) pose_acc += (size_t)v0 * gridDim.x * 64;
         vs.campos += 3 * v0;
         if (vs.input_scale) vs.input_scale += v0;
     }
     const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];
     const int K = (deg + 1) * (deg + 1);
+    // staging of the block's rows: the forms of preprocess_bwd_kernel (flat / compact / repacked)
+    const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+    const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
+    const size_t sh_row = (size_t)M * 3;
+    const int sh_rowf = 3 * K;
+    const bool sh_flat = (sh_row & 1) != 0 && inf.sh_aligned != 0;
+    const int copy_row = inf.sh_channel_major ? (int)sh_row : sh_rowf;
+    const bool sh_compact = (int)sh_row > sh_rowf && sh_row <= 128 && (sh_flat || inf.sh_channel_major);
+    const int sh_stride = sh_compact ? (sh_rowf | 1) : sh_flat ? (int)sh_row : (copy_row | 1);
+    const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? (sh_compact ? sh_rowf / 3 : M) : 1;
+    if (sh_compact) stage_sh_rows_compact(sh_lds, shs, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
+    else stage_sh_rows(sh_lds, shs, g0, nG, sh_row, copy_row, sh_stride, sh_flat);
+    __syncthreads();
+    const float* sh = sh_lds + threadIdx.x * sh_stride;
+
     float acc[3][KMAX];
 #pragma unroll
     for (int c = 0; c < 3; c++)
 #pragma unroll
         for (int k = 0; k < KMAX; k++) acc[c][k] = 0.f;
+    float dmean[3] = {0.f, 0.f, 0.f};
     const float4* recs = reinterpret_cast<const float4*>(grad2d);
     float4 q0 = recs[(GGR_G2D_STRIDE / 4) * il];
     int qrad = radii[il];
     uint32_t qcl = clamped[il];
 #pragma clang loop unroll(disable)
     for (int v = 0; v < vs.vps; v++) {
+        // (compiler barrier: without it the 3K coefficient reads from LDS — invariant across views — are hoisted out of
+        // the loop into as many registers)
+        __asm__ volatile("" ::: "memory");
         const size_t o = (size_t)v * P + il;
         const float4 r0 = q0;
         const bool live = in_range && qrad > 0;
         const uint32_t cl = qcl;
         if (v + 1 < vs.vps) { q0 = recs[(GGR_G2D_STRIDE / 4) * (o + P)]; qrad = radii[o + P]; qcl = clamped[o + P]; }
+        float dcam[3] = {0.f, 0.f, 0.f};
         if (live) {
             const float dc0 = (cl & 1u) ? 0.f : r0.x, dc1 = (cl & 2u) ? 0.f : r0.y, dc2 = (cl & 4u) ? 0.f : r0.z;
             const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
             const float vx = in_s * m0 - vs.campos[3 * v], vy = in_s * m1 - vs.campos[3 * v + 1], vz = in_s * m2 - vs.campos[3 * v + 2];
             const float len = sqrtf(vx * vx + vy * vy + vz * vz);
-            float B[GGR_SH_MAXK];
-            sh_basis25(deg, vx / len, vy / len, vz / len, B);
+            float x = vx / len, y = vy / len, z = vz / len;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            // two passes over the basis instead of one (its polynomials are cheap): (a) the rows' accumulators from the
+            // basis VALUES, (b) the direction term from the basis GRADIENTS and the coefficients in LDS, band by band
+            // behind compiler fences — formed together, every band's values, gradients and coefficient reads were live
+            // next to the 3·K accumulators: 196 VGPRs (K = 16) / 286 (K = 25)
+            {
+                float B[GGR_SH_MAXK];
+                sh_basis25(deg, x, y, z, B);
 #pragma unroll
-            for (int k = 0; k < KMAX; k++)
-                if (k < K) { acc[0][k] += B[k] * dc0; acc[1][k] += B[k] * dc1; acc[2][k] += B[k] * dc2; }
+                for (int k = 0; k < KMAX; k++)
+                    if (k < K) { acc[0][k] += B[k] * dc0; acc[1][k] += B[k] * dc1; acc[2][k] += B[k] * dc2; }
+            }
+            __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z) :: "memory");
+#define SH_TERM(k, Bk, bx, by, bz)                                                                     \
+{                                                                                                  \
+    if ((k) < KMAX) {                                                                              \
+        const int o0 = (k) * sh_ks, o1 = o0 + sh_cs, o2 = o1 + sh_cs;                              \
+        const float sd = sh[o0] * dc0 + sh[o1] * dc1 + sh[o2] * dc2;                               \
+        ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                      \
+    }                                                                                              \
+}
+#define SH_FENCE __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(xx), "+v"(yy), "+v"(zz), "+v"(xy), "+v"(yz), "+v"(xz), "+v"(ddx), "+v"(ddy), "+v"(ddz) :: "memory");
+            GGR_SH_TERMS(SH_TERM, deg, SH_FENCE)
+#undef SH_FENCE
+#undef SH_TERM
+            const float sum2 = vx * vx + vy * vy + vz * vz;
+            const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            const float gx_ = ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
+            const float gy_ = (-vx * vy * ddx + (sum2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
+            const float gz_ = (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * inv32;
+            dmean[0] += in_s * gx_; dmean[1] += in_s * gy_; dmean[2] += in_s * gz_;
+            if (POSE) { dcam[0] = -gx_; dcam[1] = -gy_; dcam[2] = -gz_; }
+        }
+        if (POSE) {  // this view's dL/dcampos partial joins the row the main kernel wrote (entries 32..34)
+            __shared__ float cred[4][4];
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float scm = wave_sum_lane63(dcam[k]);
+                if (lane == 63) cred[wave][k] = scm;
+            }
+            __syncthreads();
+            if (threadIdx.x >= 32 && threadIdx.x < 35) {
+                const int k = threadIdx.x - 32;
+                pose_acc[((size_t)v * gridDim.x + blockIdx.x) * 64 + threadIdx.x] += cred[0][k] + cred[1][k] + cred[2][k] + cred[3][k];
+            }
+            __syncthreads();
         }
     }
+    if (in_range) {   // (the main kernel's geometry part of dL/dmean is already there)
+        dL_dmeans3D[3 * i] += dmean[0]; dL_dmeans3D[3 * i + 1] += dmean[1]; dL_dmeans3D[3 * i + 2] += dmean[2];
+    }
     // rows out: three row ranges of the block through LDS, flat float4 copies (84 rows: a multiple of 4 → 16-B aligned)
-    const size_t g0 = (size_t)blockIdx.x * blockDim.x;
-    const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
     const int rowlen = 3 * M;
     const bool cm = inf.sh_channel_major != 0;
     const int pk = cm ? 1 : 3, pc = cm ? M : 1;   // coefficient k, channel c sits at k·pk + c·pc
 #pragma unroll 1
     for (int R = 0; R < 3; R++) {
         const int r0 = 84 * R, r1 = R == 2 ? 256 : r0 + 84;
-        if (R) __syncthreads();  // the previous range has been copied out
+        __syncthreads();  // the coefficients / the previous range have been read
         if ((int)threadIdx.x >= r0 && (int)threadIdx.x < r1 && in_range) {
             float* rowp = sh_lds + ((int)threadIdx.x - r0) * rowlen;
 #pragma unroll
@@ -834,7 +845,7 @@ preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ 
         if (nrow > 0) {
             const int total = nrow * rowlen;
             float* dst = dL_dsh + (g0 + r0) * (size_t)rowlen;
-            if (inf.sh_aligned && ((rowlen * 4) & 3) == 0) {   // (84·rowlen·4 B is a multiple of 16)
+            if (inf.sh_aligned) {   // (g0 + r0 is a multiple of 4 rows: every range starts 16-B aligned)
                 const int n4 = total >> 2;
                 for (int j = threadIdx.x; j < n4; j += 256)
                     reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(sh_lds)[j];
@@ -894,21 +905,18 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
     const bool compact = (size_t)(3 * M) > rowf && 3 * M <= 128 && (flat || inf.sh_channel_major);
     const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
     const bool multi = vs.vps > 1;
-    const int sh_split = (multi && !has_colors_precomp && shs && dL_dsh) ? 1 : 0;
+    const bool sh_split = multi && !has_colors_precomp && shs && dL_dsh;   // several views: the SH backward has its own kernel
     // one view at degree 3 / 4 with long rows: rows read by thirds, gradient rows written by row ranges (kernel header)
-    const bool use_sh = !has_colors_precomp && shs;
-    const int kc = (use_sh && !multi && (deg == 3 || deg == 4) && 3 * M > 64 &&
+    const bool use_sh = !has_colors_precomp && shs && !multi;   // (what the MAIN kernel stages)
+    const int kc = (use_sh && (deg == 3 || deg == 4) && 3 * M > 64 &&
                     inf.sh_aligned) ? (deg + 1) * (deg + 1) : 0;
-    size_t lds = !use_sh ? 0 : kc ? sizeof(float) * (size_t)std::max(256 * (kc | 1), 88 * 3 * M)
-                                  : (size_t)256 * row_stride * sizeof(float);
-    // several views: room for their colour gradients behind the rows (16-B aligned)
-    const int dcol_off = (int)(((lds + 15) & ~(size_t)15) / sizeof(float));
-    if (use_sh && multi && vs.vps <= GGR_PBWD_CACHED_VIEWS) lds = (size_t)dcol_off * sizeof(float) + (size_t)vs.vps * 256 * sizeof(float4);
+    const size_t lds = !use_sh ? 0 : kc ? sizeof(float) * (size_t)std::max(256 * (kc | 1), 88 * 3 * M)
+                                        : (size_t)256 * row_stride * sizeof(float);
 #define GGR_LAUNCH_PBWD(POSE_, MULTI_, KC_, CM_)                                                                            \
     hipLaunchKernelGGL((preprocess_bwd_kernel<POSE_, MULTI_, KC_, CM_>), dim3(blocks, vs.sets), dim3(256), lds, s, P, D, M, means3D, shs, \
                        has_colors_precomp, scales, rotations, scale_modifier, cov3D, vs, W, H, radii, clamped, grad2d,     \
                        has_dz, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales,   \
-                       dL_drotations, dL_daux, pose_acc, inf, cov_is_input, dcol_off, sh_split)
+                       dL_drotations, dL_daux, pose_acc, inf, cov_is_input)
 #define GGR_LAUNCH_PBWD_P(POSE_)                                                                                         \
     do {                                                                                                                  \
         if (multi) GGR_LAUNCH_PBWD(POSE_, true, 0, false);                                                                \
@@ -918,21 +926,23 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
         else if (kc == 25) GGR_LAUNCH_PBWD(POSE_, false, 25, false);                                                      \
         else GGR_LAUNCH_PBWD(POSE_, false, 0, false);                                                                     \
     } while (0)
-    if (sh_split) {   // several views: the gradient rows of the SH coefficients, on their own (see the kernel)
-        const size_t lds_sh = (size_t)88 * 3 * M * sizeof(float);
-        if (deg >= 4)
-            hipLaunchKernelGGL((preprocess_bwd_sh_views_kernel<25>), dim3(blocks, vs.sets), dim3(256), lds_sh, s, P, M, deg, means3D, vs,
-                               radii, clamped, grad2d, dL_dsh, inf);
-        else
-            hipLaunchKernelGGL((preprocess_bwd_sh_views_kernel<16>), dim3(blocks, vs.sets), dim3(256), lds_sh, s, P, M, deg, means3D, vs,
-                               radii, clamped, grad2d, dL_dsh, inf);
-    }
+    auto launch_sh_views = [&](bool pose) {   // several views: the SH backward, behind the main kernel (see the kernel)
+        const size_t lds_sh = sizeof(float) * std::max((size_t)256 * row_stride, (size_t)88 * 3 * M);
+#define GGR_LAUNCH_SHV(K_, POSE_)                                                                                          \
+    hipLaunchKernelGGL((preprocess_bwd_sh_views_kernel<K_, POSE_>), dim3(blocks, vs.sets), dim3(256), lds_sh, s, P, M, deg,  \
+                       means3D, shs, vs, radii, clamped, grad2d, dL_dmeans3D, dL_dsh, pose_acc, inf)
+        if (deg >= 4) { if (pose) GGR_LAUNCH_SHV(25, true); else GGR_LAUNCH_SHV(25, false); }
+        else { if (pose) GGR_LAUNCH_SHV(16, true); else GGR_LAUNCH_SHV(16, false); }
+#undef GGR_LAUNCH_SHV
+    };
     if (pose_acc) {
         GGR_LAUNCH_PBWD_P(true);
+        if (sh_split) launch_sh_views(true);
         hipLaunchKernelGGL(pose_finish_kernel, dim3(35, vs.V), dim3(256), 0, s, pose_acc, blocks, dL_dview, dL_dproj,
                            dL_dcampos);
     } else {
         GGR_LAUNCH_PBWD_P(false);
+        if (sh_split) launch_sh_views(false);
     }
 #undef GGR_LAUNCH_PBWD_P
 #undef GGR_LAUNCH_PBWD

@@ -39,7 +39,7 @@ def _cameras(W, H, V):
     return view, full, campos, tanfov
 
 
-def _run(sc, cams, dLs, dDs, mode, use_sh, use_cov, bgs, scales, aux, batched, pose=False):
+def _run(sc, cams, dLs, dDs, mode, use_sh, use_cov, bgs, scales, aux, batched, pose=False, cap=3):
     view, full, campos, tanfov = [t.to(dev) for t in cams]
     V = view.shape[0]
     leaf = lambda t: t.detach().clone().to(dev).requires_grad_(True)
@@ -61,7 +61,7 @@ def _run(sc, cams, dLs, dDs, mode, use_sh, use_cov, bgs, scales, aux, batched, p
     aux_l = None if aux is None else leaf(aux)
     if aux_l is not None:
         leaves["aux"] = aux_l
-    rs = sc.to(dev).settings()._replace(aux_affine=mode)
+    rs = sc.to(dev).settings()._replace(aux_affine=mode, sh_max_degree=cap)
     sink = torch.zeros(V, sc.means3D.shape[0], 3, device=dev, requires_grad=True)
     leaves["means2D"] = sink
     if batched:
@@ -91,6 +91,7 @@ def _run(sc, cams, dLs, dDs, mode, use_sh, use_cov, bgs, scales, aux, batched, p
     dict(P=9000, W=130, H=70, D=4, V=4, use_sh=True, use_cov=False, scaled=True, depth=True),   # ragged size, M = 25
     dict(P=3000, W=64, H=48, D=0, V=2, use_sh=False, use_cov=True, aux=True, depth=True),
     dict(P=20000, W=160, H=112, D=4, V=5, use_sh=True, use_cov=True, profile="B", affine=True, depth=True, pose=True),
+    dict(P=7000, W=112, H=80, D=4, V=3, use_sh=True, use_cov=True, pose=True, cap=4),   # band 4 evaluated: K = 25 in the views' SH kernel
 ])
 def test_views_equal_per_view_calls(case):
     P, W, H, V = case["P"], case["W"], case["H"], case["V"]
@@ -104,8 +105,8 @@ def test_views_equal_per_view_calls(case):
     aux = torch.rand(V, P, generator=g) if case.get("aux") else None
     mode = (0.5, 0.28209479177387814) if case.get("affine") else None
     args = (sc, cams, dLs, dDs, mode, case["use_sh"], case["use_cov"], bgs, scales, aux)
-    ca, ra, da, ga = _run(*args, batched=False, pose=case.get("pose", False))
-    cb, rb, db, gb = _run(*args, batched=True, pose=case.get("pose", False))
+    ca, ra, da, ga = _run(*args, batched=False, pose=case.get("pose", False), cap=case.get("cap", 3))
+    cb, rb, db, gb = _run(*args, batched=True, pose=case.get("pose", False), cap=case.get("cap", 3))
     assert np.array_equal(ra, rb)
     assert np.array_equal(ca, cb), float(np.abs(ca - cb).max())      # same lists, same blend: bit-identical
     assert np.array_equal(da, db)
