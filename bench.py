@@ -580,6 +580,9 @@ def main():
                 # … four DIFFERENT Gaussian sets, one view each (the `(b v)` flattening): loop vs ONE launch set
                 rec["callsite_ggrt_sets4"] = callsite_bench.measure_sets(str(dev), steps=10, warmup=3, sets=4)
                 log(f"four Gaussian sets at GGRt's shape: {rec['callsite_ggrt_sets4']}")
+                # … GGRt's eval loop (forward only) at its LLFF shape: one frame per call vs four frames per launch set
+                rec["callsite_ggrt_eval_sets4"] = callsite_bench.measure_eval_sets(str(dev), steps=10, warmup=3, sets=4)
+                log(f"eval frames/s: {rec['callsite_ggrt_eval_sets4']}")
                 # … and the fine-tune loop's deferred back-propagation cell (finetune_ggrt_stable.py:126-142): a gradient
                 # that is zero outside one cell of a 2 × 2 grid — zero-gradient skip in the backward, scissored forward
                 rec["deferred_backprop_window"] = {c: callsite_bench.measure_window(str(dev), steps=10, warmup=3, config=c)

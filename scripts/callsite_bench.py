@@ -194,6 +194,50 @@ def measure_sets(dev="cuda:0", steps=10, warmup=3, config="C5p", sets=4):
     return out
 
 
+def measure_eval_sets(dev="cuda:0", steps=10, warmup=3, config="C4p", sets=4):
+    """GGRt's evaluation loop (eval/eval_ggrt.py:317: forward only under `torch.no_grad()`) at its LLFF shape, `sets`
+    independent frames per launch set against one frame per call: frames per second."""
+    from ggrt_official_amd import splatting as sp
+    from ggrt_official_amd.synthetic import CONFIGS, make_scene
+    cfg = CONFIGS[config]
+    scs = [make_scene(seed=s, **cfg).to(dev) for s in range(sets)]
+    P, H, W = scs[0].means3D.shape[0], scs[0].height, scs[0].width
+    ext = torch.eye(4, device=dev)[None].repeat(sets, 1, 1)
+    fx, fy = 0.5 / scs[0].tanfovx, 0.5 / scs[0].tanfovy
+    intr = torch.tensor([[fx, 0, 0.5], [0, fy, 0.5], [0, 0, 1]], device=dev)[None].expand(sets, 3, 3).contiguous()
+    near, far = torch.full((sets,), 1.0, device=dev), torch.full((sets,), 100.0, device=dev)
+
+    def cov33(sc):
+        cov = torch.zeros(P, 3, 3, device=dev)
+        for k, (i, j) in enumerate([(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]):
+            cov[:, i, j] = sc.cov3D[:, k]
+            cov[:, j, i] = sc.cov3D[:, k]
+        return cov
+    gs_all = sp.Gaussians(means=torch.stack([s.means3D for s in scs]), covariances=torch.stack([cov33(s) for s in scs]),
+                          harmonics=torch.stack([s.shs.permute(0, 2, 1).contiguous() for s in scs]),
+                          opacities=torch.stack([s.opacities[:, 0] for s in scs]))
+    gs_one = sp.Gaussians(means=gs_all.means[:1].clone(), covariances=gs_all.covariances[:1].clone(),
+                          harmonics=gs_all.harmonics[:1].clone(), opacities=gs_all.opacities[:1].clone())
+    bg = torch.zeros(sets, 3, device=dev)
+
+    def run(gs, nb):
+        with torch.no_grad():
+            sp.render_views_fused(ext[:nb], intr[:nb], near[:nb], far[:nb], (H, W), bg[:nb], gs, list(range(nb)), None)
+
+    out = {"workload": f"{config}: {P} Gaussians per frame, {W}x{H}, d_sh {scs[0].shs.shape[1]}, colour, forward only (no_grad)"}
+    for name, fn, frames in (("one_frame_per_call", lambda: run(gs_one, 1), 1), (f"{sets}_frames_per_launch_set", lambda: run(gs_all, sets), sets)):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[name] = {"ms_per_call": round(ms, 3), "frames_per_s": round(frames * 1e3 / ms, 1)}
+    return out
+
+
 def measure_window(dev="cuda:0", steps=10, warmup=3, config="C5p", crop=2):
     """The reference's deferred back-propagation cell (finetune_ggrt_stable.py:126-142) at GGRt's shape: a full-frame
     render whose backward sees a gradient that is zero outside ONE cell of a crop × crop grid.  Per-stage times of the
@@ -244,6 +288,7 @@ def measure_window(dev="cuda:0", steps=10, warmup=3, config="C5p", crop=2):
 
 if __name__ == "__main__":
     import json
+    print(json.dumps(measure_eval_sets(), indent=1))
     print(json.dumps(measure_sets(), indent=1))
     print(json.dumps(measure_window(), indent=1))
     print(json.dumps(measure_window(config="C3"), indent=1))
