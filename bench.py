@@ -247,7 +247,7 @@ def cpu_baseline_c_oracle(sc, dL_cpu, reps: int = 2) -> dict:
     best = None
     for r in range(reps + 1):  # the first repetition warms the page cache / thread pool
         t0 = time.perf_counter()
-        st = oracle_forward(sc)
+        st = oracle_forward(sc, tight=False)   # the reference's algorithm, its own tile rects
         t_f = time.perf_counter() - t0
         t0 = time.perf_counter()
         c_oracle.backward(st, dL_cpu)

@@ -22,7 +22,7 @@ class GgrSettings(C.Structure):
         ("sh_stride", C.c_int32), ("num_points", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
         ("scale_modifier", C.c_float), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
         ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("prefiltered", C.c_int32), ("debug", C.c_int32),
-        ("tanfov_dev", C.c_void_p), ("sh_max_degree", C.c_int32), ("scissor", C.c_int32 * 4),
+        ("tanfov_dev", C.c_void_p), ("sh_max_degree", C.c_int32), ("scissor", C.c_int32 * 4), ("reference_rects", C.c_int32),
     ]
 
 

@@ -152,6 +152,7 @@ InputForm input_form(const GgrSettings* st, const GgrForwardIn* in, int sets, co
     f.aux_a = in->aux_a;
     f.aux_b = in->aux_b;
     f.sh_cap = st->sh_max_degree == 4 ? 4 : 3;  // default 3: INTEGRATION.md §7
+    f.tight_rects = st->reference_rects ? 0 : 1;
     const int gx = (st->image_width + GGR_TILE - 1) / GGR_TILE, gy = (st->image_height + GGR_TILE - 1) / GGR_TILE;
     f.sc_x0 = 0; f.sc_y0 = 0; f.sc_x1 = gx; f.sc_y1 = gy;
     const int32_t* sc = st->scissor;

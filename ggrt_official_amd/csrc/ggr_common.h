@@ -223,7 +223,29 @@ struct InputForm {
     int sh_cap;                // highest SH band evaluated: 3 (graphdeco / w-depth family, default) or 4
     int sc_x0, sc_y0, sc_x1, sc_y1;  // GgrSettings.scissor in TILES, half-open, inside the tile grid (whole grid = none)
     int sh_aligned;            // every set's SH rows (and gradient rows) start 16-B aligned: flat float4 staging allowed
+    int tight_rects;           // 1 (default): tile rects clipped to the α ≥ 1/255 ellipse's bounding box (ggr_tighten_rect)
 };
+
+// ---- TIGHT tile rects (round 3; restated in oracle/ggr_oracle.c `tighten_rect`, same operations in the same order) ----
+// The reference lists a Gaussian in every tile of the square of radius ceil(3·sqrt(λmax)) around its mean.  A pixel can
+// only take it if α = opacity·exp(−q/2) ≥ 1/255, i.e. inside the ellipse q ≤ qmax = 2·ln(255·opacity), whose bounding box
+// has the half widths sqrt(qmax·cov_xx), sqrt(qmax·cov_yy): tiles outside that box (half a pixel and 1 % to spare) hold
+// only pixels that `continue` past the Gaussian.  Dropping them changes no output — images, final_T, radii, every gradient
+// are bit-identical (oracle-checked) — only the lists get shorter (C3: 10.76 M → 8.0 M entries).  The bound on ln comes from
+// the float's exponent and a cubic in its mantissa (≥ ln on [1, 2)): exact-order fp32 operations, so host oracle and
+// kernel agree on every rect to the bit, which libm's logf and the device's would not.
+__host__ __device__ static inline float ggr_qmax_upper(float opacity) {   // ≥ 2·ln(255·opacity); negative: α < 1/255 everywhere
+#pragma clang fp contract(off)   // (no FMA contraction: the oracle's plain fp32 operations, bit for bit)
+    const float u = 255.0f * opacity;
+    if (!(u >= 1.0f)) return -1.0f;
+    union { float f; uint32_t b; } cv;
+    cv.f = u;
+    const int e = (int)(cv.b >> 23) - 127;
+    cv.b = (cv.b & 0x007FFFFFu) | 0x3F800000u;
+    const float x = cv.f - 1.0f, t = x * x;
+    const float lnm = (x - 0.5f * t) + 0.33333334f * (t * x);
+    return 2.0f * ((float)e * 0.69314718f + lnm) + 0.02f;
+}
 
 // The cameras of one launch set: V views of the SAME P Gaussians (V = 1: the reference's call).  Per-Gaussian state of
 // view v lives at index v·P + g; its tiles are tiles [v·T, (v+1)·T) of a virtual image of V frames stacked vertically

@@ -277,17 +277,32 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 const int rmaxx = min(inf.sc_x1, max(inf.sc_x0, (int)((px + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
                 const int rmaxy = min(inf.sc_y1, max(inf.sc_y0, (int)((py + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
                 const int area = (rmaxx - rminx) * (rmaxy - rminy);
-                if (area != 0) {
+                if (area != 0) {   // (visibility — radii, colours — follows the REFERENCE's rect whatever the lists hold)
                     vis = true;
                     rad_out = rad;
+                    int tx0 = rminx, ty0 = rminy, tx1 = rmaxx, ty1 = rmaxy;
+                    if (inf.tight_rects) {   // ggr_common.h ggr_qmax_upper: tiles the α ≥ 1/255 ellipse cannot reach are dropped
+                        const float qmax = ggr_qmax_upper(opac);
+                        if (qmax < 0.f) { tx1 = tx0; ty1 = ty0; }
+                        else {
+                            const float hx = sqrtf(qmax * a) * 1.01f + 0.5f, hy = sqrtf(qmax * c) * 1.01f + 0.5f;
+                            tx0 = max(tx0, (int)floorf((px - hx) / (float)GGR_TILE));
+                            ty0 = max(ty0, (int)floorf((py - hy) / (float)GGR_TILE));
+                            tx1 = min(tx1, (int)floorf((px + hx) / (float)GGR_TILE) + 1);
+                            ty1 = min(ty1, (int)floorf((py + hy) / (float)GGR_TILE) + 1);
+                            if (tx1 < tx0) tx1 = tx0;
+                            if (ty1 < ty0) ty1 = ty0;
+                        }
+                    }
+                    const int area_t = (tx1 - tx0) * (ty1 - ty0);
                     // > 0: t2 > 0.2f.  The three-pass sort takes 30-bit keys: depths ≥ 6.8e37 (incl. +inf) share the last key
                     // and keep ascending id among themselves instead of voiding the frame (ggr_raster.h "depth order")
                     key_out = min(__float_as_uint(t2) - GGR_KEY_BASE, GGR_KEY_MAX);
-                    tiles_out = (uint32_t)area;
+                    tiles_out = (uint32_t)area_t;
                     // tile rows of view v sit below those of views 0 … v-1 in the virtual stacked image
                     const uint32_t yo = (uint32_t)((v0 + v) * gy);
-                    rect_out = make_uint2((uint32_t)rminx | (((uint32_t)rminy + yo) << 16),
-                                          (uint32_t)rmaxx | (((uint32_t)rmaxy + yo) << 16));
+                    if (area_t) rect_out = make_uint2((uint32_t)tx0 | (((uint32_t)ty0 + yo) << 16),
+                                                      (uint32_t)tx1 | (((uint32_t)ty1 + yo) << 16));
                 }
             }
         }

@@ -60,6 +60,9 @@ class GaussianRasterizationSettings(NamedTuple):
     scissor: Optional[tuple] = None  # (x0, y0, x1, y1) pixels, half-open: only the tiles overlapping the window are binned
     #                         and blended (the fine-tune loop's per-cell re-render, finetune_ggrt_stable.py:126-142); inside
     #                         them the outputs equal the full-frame render bit for bit, other tiles come out as background
+    reference_rects: bool = False    # False: tight tile rects (a Gaussian is listed only where its α ≥ 1/255 ellipse can reach:
+    #                         same outputs bit for bit, shorter internal lists); True: the reference's rects — lists identical
+    #                         to the reference's, entry for entry
     sh_max_degree: int = 3  # highest SH band evaluated.  3 (default): graphdeco and its w-depth forks — the family the
     #                         live call site's signature belongs to (3-tuple return, no `debug`: cuda_splatting.py:101-118)
     #                         — ignore coefficients 16.. (zero gradient); 4: the nine degree-4 terms are evaluated when
@@ -145,7 +148,8 @@ def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view
         scale_modifier=float(rs.scale_modifier), bg=_ptr(bg), viewmatrix=_ptr(view), projmatrix=_ptr(proj),
         campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfov_dev=_ptr(tf),
         sh_max_degree=int(getattr(rs, "sh_max_degree", 3) or 3),
-        scissor=(C.c_int32 * 4)(*[int(v) for v in (getattr(rs, "scissor", None) or (0, 0, 0, 0))]))
+        scissor=(C.c_int32 * 4)(*[int(v) for v in (getattr(rs, "scissor", None) or (0, 0, 0, 0))]),
+        reference_rects=int(bool(getattr(rs, "reference_rects", False))))
 
 
 class _RasterizeGaussians(torch.autograd.Function):

@@ -78,6 +78,12 @@ typedef struct GgrSettings {
                                 (final_T = 1, no contributors), and `radii` / visibility refer to the window (a
                                 Gaussian that touches no window tile gets radius 0 and no gradient).  The backward
                                 needs no scissor: it skips tiles and quadrants whose upstream gradient is all zero. */
+    int32_t reference_rects; /* 0 (default): TIGHT tile rects — a Gaussian is listed only in the tiles that the bounding box of
+                                its alpha >= 1/255 ellipse reaches (inside the reference's 3-sigma square).  Every output
+                                (images, radii, all gradients) is bit-identical to the reference-rect build — the dropped
+                                (Gaussian, tile) pairs are exactly pairs every pixel would `continue` past — only the
+                                internal lists are shorter (num_rendered, n_contrib positions).  1: the reference's rects,
+                                i.e. lists identical to the reference's 64-bit sort, entry for entry. */
 } GgrSettings;
 
 /* Inputs of GaussianRasterizer.forward (cuda_splatting.py:118-125).

@@ -74,9 +74,10 @@ class OracleState:
 
 def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy,
             sh_degree=0, shs=None, colors_precomp=None, cov3D_precomp=None, scales=None,
-            rotations=None, scale_modifier=1.0, sh_cap=3) -> OracleState:
+            rotations=None, scale_modifier=1.0, sh_cap=3, tight_rects=False) -> OracleState:
     """``sh_cap``: highest SH band evaluated (3 = graphdeco / w-depth family, the default; 4 = band 4 as well; see
-    the header of ggr_oracle.c)."""
+    the header of ggr_oracle.c).  ``tight_rects``: False = the reference's tile rects (the restatement proper); True =
+    the build's tight rects (ggr_oracle.c `tighten_rect`): sub-lists of the reference's, every output unchanged."""
     L = lib()
     means3D = _f32(means3D)
     P = means3D.shape[0]
@@ -101,17 +102,18 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfov
     clamped = np.zeros((P, 3), np.uint8)
     tiles = np.zeros(P, np.int32)
     cov_used = np.zeros((P, 6), np.float32)
+    rect = np.zeros((P, 4), np.int32)
     N = L.ggo_preprocess(
         C.c_int(P), C.c_int(sh_degree), C.c_int(M), _p(means3D), _p(shs), _p(colors_precomp), _p(opac),
         _p(scales), _p(rotations), C.c_float(scale_modifier), _p(cov3D_precomp), _p(V), _p(PM), _p(cam),
         C.c_int(W), C.c_int(H), C.c_float(tanfovx), C.c_float(tanfovy), _p(depth), _p(radii), _p(xy),
-        _p(co), _p(rgb), _p(clamped), _p(tiles), _p(cov_used), C.c_int(sh_cap))
+        _p(co), _p(rgb), _p(clamped), _p(tiles), _p(cov_used), C.c_int(sh_cap), _p(rect), C.c_int(int(bool(tight_rects))))
     gx, gy = (W + 15) // 16, (H + 15) // 16
     point_list = np.zeros(max(N, 1), np.uint32)
     keys = np.zeros(max(N, 1), np.uint64)
     ranges = np.zeros((gx * gy, 2), np.int32)
     L.ggo_bin(C.c_int(P), C.c_int(W), C.c_int(H), _p(depth), _p(radii), _p(xy), C.c_int64(N),
-              _p(point_list), _p(keys), _p(ranges))
+              _p(point_list), _p(keys), _p(ranges), _p(rect))
     color = np.zeros((3, H, W), np.float32)
     final_T = np.zeros((H, W), np.float32)
     n_contrib = np.zeros((H, W), np.int32)

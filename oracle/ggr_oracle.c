@@ -270,6 +270,42 @@ static void kv_merge_sort(KV* a, KV* tmp, int64_t n) {
 }
 
 /*
+ * TIGHT tile rects (an option of the BUILD, not of the reference; ggo_preprocess `tight_rects`).  The reference lists a
+ * Gaussian in every tile of the square of radius ceil(3·sqrt(λmax)) around its mean; a pixel can only take it if
+ * α = opacity·exp(−q/2) ≥ 1/255, i.e. inside the ellipse q ≤ 2·ln(255·opacity), whose axis-aligned bounding box has the
+ * half widths sqrt(qmax·cov_xx), sqrt(qmax·cov_yy).  Intersecting the reference's rect with the tiles of that box (with
+ * half a pixel and 1 % to spare) drops only (Gaussian, tile) pairs that every pixel of the tile would `continue` past:
+ * images, final_T, radii and all gradients are unchanged bit for bit (tests/test_oracle.py), the lists are sub-lists of
+ * the reference's in the same order.  The bound on ln is formed from the float's exponent and a cubic in its mantissa —
+ * exact-order fp32 operations only, so that the C and the HIP side agree to the bit on every rect (libm's logf and the
+ * device's differ in the last place).
+ */
+static float qmax_upper(float opacity) {   /* ≥ 2·ln(255·opacity); negative: below 1/255 everywhere */
+    const float u = 255.0f * opacity;
+    if (!(u >= 1.0f)) return -1.0f;
+    uint32_t bits;
+    memcpy(&bits, &u, 4);
+    const int e = (int)(bits >> 23) - 127;
+    const uint32_t mb = (bits & 0x007FFFFFu) | 0x3F800000u;
+    float m;
+    memcpy(&m, &mb, 4);
+    const float x = m - 1.0f, t = x * x;
+    const float lnm = (x - 0.5f * t) + 0.33333334f * (t * x);   /* ≥ ln(1 + x) on [0, 1): alternating series */
+    return 2.0f * ((float)e * 0.69314718f + lnm) + 0.02f;
+}
+static void tighten_rect(float px, float py, float cov_xx, float cov_yy, float opacity, int* rmin, int* rmax) {
+    const float qmax = qmax_upper(opacity);
+    if (qmax < 0.f) { rmax[0] = rmin[0]; rmax[1] = rmin[1]; return; }
+    const float hx = sqrtf(qmax * cov_xx) * 1.01f + 0.5f, hy = sqrtf(qmax * cov_yy) * 1.01f + 0.5f;
+    rmin[0] = imax(rmin[0], (int)floorf((px - hx) / (float)GGO_TILE));
+    rmin[1] = imax(rmin[1], (int)floorf((py - hy) / (float)GGO_TILE));
+    rmax[0] = imin(rmax[0], (int)floorf((px + hx) / (float)GGO_TILE) + 1);
+    rmax[1] = imin(rmax[1], (int)floorf((py + hy) / (float)GGO_TILE) + 1);
+    if (rmax[0] < rmin[0]) rmax[0] = rmin[0];
+    if (rmax[1] < rmin[1]) rmax[1] = rmin[1];
+}
+
+/*
  * Preprocess (A.1).  Any output pointer except radii/tiles_touched may be NULL.
  * cov3D_precomp XOR (scales, rotations); shs XOR colors_precomp.
  * cov3D_out[P,6] receives the covariance actually used.
@@ -281,7 +317,8 @@ int64_t ggo_preprocess(int P, int D, int M, const float* means3D, const float* s
                        const float* viewmatrix, const float* projmatrix, const float* campos, int W,
                        int H, float tanfovx, float tanfovy, float* depth, int32_t* radii, float* xy,
                        float* conic_opacity, float* rgb, uint8_t* clamped, int32_t* tiles_touched,
-                       float* cov3D_out, int sh_cap) {
+                       float* cov3D_out, int sh_cap, int32_t* rect_out /*[P,4] (x0,y0,x1,y1) or NULL*/,
+                       int tight_rects /*0: the reference's rects*/) {
     const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
     const int gx = (W + GGO_TILE - 1) / GGO_TILE, gy = (H + GGO_TILE - 1) / GGO_TILE;
     const int deg = sh_eff_degree(D, shs ? M : 25, sh_cap);
@@ -291,6 +328,7 @@ int64_t ggo_preprocess(int P, int D, int M, const float* means3D, const float* s
     for (int i = 0; i < P; i++) {
         radii[i] = 0;
         tiles_touched[i] = 0;
+        if (rect_out) rect_out[4 * i] = rect_out[4 * i + 1] = rect_out[4 * i + 2] = rect_out[4 * i + 3] = 0;
         if (depth) depth[i] = 0.f;
         if (xy) xy[2 * i] = xy[2 * i + 1] = 0.f;
         if (conic_opacity) for (int k = 0; k < 4; k++) conic_opacity[4 * i + k] = 0.f;
@@ -321,8 +359,13 @@ int64_t ggo_preprocess(int P, int D, int M, const float* means3D, const float* s
         const float px = ndc2pix(ppx, W), py = ndc2pix(ppy, H);
         int rmin[2], rmax[2];
         get_rect(px, py, rad, gx, gy, rmin, rmax);
-        const int area = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
-        if (area == 0) continue;
+        int area = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
+        if (area == 0) continue;   /* visibility (radii, colours) follows the REFERENCE's rect in both modes */
+        if (tight_rects) {
+            tighten_rect(px, py, e.a, e.c, opacities[i], rmin, rmax);
+            area = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
+        }
+        if (rect_out) { rect_out[4 * i] = rmin[0]; rect_out[4 * i + 1] = rmin[1]; rect_out[4 * i + 2] = rmax[0]; rect_out[4 * i + 3] = rmax[1]; }
         if (rgb) {
             if (colors_precomp) {
                 for (int k = 0; k < 3; k++) rgb[3 * i + k] = colors_precomp[3 * i + k];
@@ -361,7 +404,8 @@ int64_t ggo_preprocess(int P, int D, int M, const float* means3D, const float* s
  * point_list[N], ranges[tiles*2], optional keys_sorted[N].
  */
 void ggo_bin(int P, int W, int H, const float* depth, const int32_t* radii, const float* xy,
-             int64_t N, uint32_t* point_list, uint64_t* keys_sorted, int32_t* ranges) {
+             int64_t N, uint32_t* point_list, uint64_t* keys_sorted, int32_t* ranges,
+             const int32_t* rect /*[P,4] from ggo_preprocess, or NULL: the reference's rects, recomputed*/) {
     const int gx = (W + GGO_TILE - 1) / GGO_TILE, gy = (H + GGO_TILE - 1) / GGO_TILE;
     KV* kv = (KV*)malloc(sizeof(KV) * (size_t)(N > 0 ? N : 1));
     KV* tmp = (KV*)malloc(sizeof(KV) * (size_t)(N > 0 ? N : 1));
@@ -369,7 +413,8 @@ void ggo_bin(int P, int W, int H, const float* depth, const int32_t* radii, cons
     for (int i = 0; i < P; i++) {
         if (radii[i] <= 0) continue;
         int rmin[2], rmax[2];
-        get_rect(xy[2 * i], xy[2 * i + 1], radii[i], gx, gy, rmin, rmax);
+        if (rect) { rmin[0] = rect[4 * i]; rmin[1] = rect[4 * i + 1]; rmax[0] = rect[4 * i + 2]; rmax[1] = rect[4 * i + 3]; }
+        else get_rect(xy[2 * i], xy[2 * i + 1], radii[i], gx, gy, rmin, rmax);
         uint32_t dbits;
         memcpy(&dbits, &depth[i], 4);
         for (int y = rmin[1]; y < rmax[1]; y++)

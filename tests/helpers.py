@@ -75,7 +75,11 @@ def check_grads(grads, ref, keys, tag="", rtol=None):
         assert r <= (GRAD_RTOL if rtol is None else rtol), f"grad {k}: rel-L2 {r:.3e} ({drop} rows set aside; all rows {r_all:.3e})"
 
 
-def oracle_forward(sc: Scene, use_sh=True, use_cov=True, colors=None, sh_cap=3):
+def oracle_forward(sc: Scene, use_sh=True, use_cov=True, colors=None, sh_cap=3, tight=True):
+    """``tight=True``: the oracle with the BUILD's tight tile rects — what the product builds by default, so that lists,
+    ranges, num_rendered and n_contrib can be compared entry for entry; ``tight=False``: the reference's rects (the
+    restatement proper; the product's ``reference_rects=True``).  Images, final_T, radii and gradients are the same in
+    both (tests/test_oracle.py::test_tight_rects_change_no_output)."""
     n = lambda t: t.detach().cpu().numpy()
     kw = {}
     if use_sh:
@@ -89,7 +93,7 @@ def oracle_forward(sc: Scene, use_sh=True, use_cov=True, colors=None, sh_cap=3):
         kw["rotations"] = n(sc.rotations)
     return c_oracle.forward(n(sc.means3D), n(sc.opacities), n(sc.viewmatrix), n(sc.projmatrix), n(sc.campos),
                             n(sc.bg), sc.width, sc.height, sc.tanfovx, sc.tanfovy, sh_degree=sc.sh_degree,
-                            sh_cap=sh_cap, **kw)
+                            sh_cap=sh_cap, tight_rects=tight, **kw)
 
 
 def rel_l2(a, b) -> float:
@@ -104,7 +108,7 @@ def psnr(a, b) -> float:
 
 
 def hip_forward_backward(sc: Scene, dL_dcolor: torch.Tensor, use_sh=True, use_cov=True, colors=None,
-                         dL_ddepth=None, pose=False, sh_max_degree=3):
+                         dL_ddepth=None, pose=False, sh_max_degree=3, reference_rects=False):
     """Runs the product path (GaussianRasterizer on cuda:0).  Returns (color, radii, depth, grads)."""
     from ggrt_official_amd import GaussianRasterizer
     dev = torch.device("cuda:0")
@@ -122,7 +126,7 @@ def hip_forward_backward(sc: Scene, dL_dcolor: torch.Tensor, use_sh=True, use_co
     else:
         leaves["scales"] = kw["scales"] = leaf(s.scales)
         leaves["rotations"] = kw["rotations"] = leaf(s.rotations)
-    rs = s.settings()._replace(sh_max_degree=sh_max_degree)
+    rs = s.settings()._replace(sh_max_degree=sh_max_degree, reference_rects=reference_rects)
     if pose:
         view, proj, cam = leaf(s.viewmatrix), leaf(s.projmatrix), leaf(s.campos)
         rs = rs._replace(viewmatrix=view, projmatrix=proj, campos=cam)

@@ -47,7 +47,7 @@ def test_size_queries_are_consistent():
 
 def test_struct_layouts_match_header_sizes():
     # 64-bit ABI: sizes follow from the field lists in include/ggr_raster.h
-    assert ctypes.sizeof(_lib.GgrSettings) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4 + 8 + 4 + 4 * 4 + 4  # + sh_max_degree, scissor, padded
+    assert ctypes.sizeof(_lib.GgrSettings) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4 + 8 + 4 + 4 * 4 + 4  # + sh_max_degree, scissor, reference_rects
     assert ctypes.sizeof(_lib.GgrForwardIn) == 9 * 8 + 3 * 4 + 2 * 4 + 4
     assert ctypes.sizeof(_lib.GgrForwardOut) == 9 * 8 + 8 + 8  # + no_backward (padded) + backward_scratch
     assert ctypes.sizeof(_lib.GgrBackwardIn) == (9 * 8 + 3 * 4 + 2 * 4 + 4) + 8 * 8 + 8  # + scratch_zeroed, padded

@@ -30,7 +30,7 @@ def test_lists_partition_and_are_depth_sorted(name):
     N = st["num_rendered"]
     ranges = st["ranges"].long()
     tiles_touched = st["tiles_touched"].long()
-    assert N == int(tiles_touched.sum()) and N > 3 * sc.means3D.shape[0]
+    assert N == int(tiles_touched.sum()) and N > 2 * sc.means3D.shape[0]   # (tight rects: C5′ 3.62 M → 2.80 M entries)
     lens = ranges[:, 1] - ranges[:, 0]
     nz = lens > 0
     starts = ranges[nz, 0]

@@ -198,3 +198,28 @@ def test_channel_major_rows_equal_k_major(P, D, cap, pose):
     check_grads(outs[1][2], outs[0][2], list(outs[0][2].keys()), tag="channel-major")
     K = (min(D, cap) + 1) ** 2
     assert np.all(outs[1][2]["shs"][:, K:, :] == 0) and np.any(outs[1][2]["shs"][:, :K, :] != 0)
+
+
+@pytest.mark.parametrize("P,W,H,D,profile,seed", [(20000, 208, 144, 3, "A", 11), (30000, 160, 112, 1, "B", 12)])
+def test_reference_rects_reproduce_the_reference_lists(P, W, H, D, profile, seed):
+    """`reference_rects=True`: the per-tile lists of the reference's 64-bit sort, entry for entry (oracle with the
+    reference's rects); the default tight rects: the tight oracle's lists, entry for entry — and the same image, radii and
+    gradients either way (bit-identical images: the dropped entries are ones every pixel `continue`s past)."""
+    from ggrt_official_amd.rasterizer import debug_forward_state
+    sc = make_scene(P, W, H, sh_degree=D, profile=profile, seed=seed)
+    s = sc.to("cuda:0")
+    dL = upstream_gradient(W, H, seed=seed)
+    out = {}
+    for ref_mode in (True, False):
+        st = oracle_forward(sc, tight=not ref_mode)
+        state = debug_forward_state(s.means3D, s.opacities, s.settings()._replace(reference_rects=ref_mode), shs=s.shs,
+                                    cov3D_precomp=s.cov3D)
+        assert state["num_rendered"] == st.num_rendered
+        assert np.array_equal(state["point_list"].cpu().numpy().astype(np.uint32), st.point_list)
+        assert np.array_equal(state["ranges"].cpu().numpy(), st.ranges)
+        assert np.array_equal(state["tiles_touched"].cpu().numpy(), st.tiles_touched)
+        out[ref_mode] = hip_forward_backward(sc, dL, reference_rects=ref_mode)
+    (c1, r1, d1, g1), (c0, r0, d0, g0) = out[True], out[False]
+    assert np.array_equal(c1, c0) and np.array_equal(r1, r0) and np.array_equal(d1, d0)
+    for k in ("means3D", "means2D", "shs", "opacities", "cov3D_precomp"):
+        assert rel_l2(g0[k], g1[k]) < 1e-5, k   # (the order of the float atomics differs with the lists)
