@@ -65,7 +65,7 @@ CLOCK_SUSTAINED_VALU_HZ = 1.867e9   # s_memtime ÷ wall clock with every SIMD is
 VALU_PLAIN_WAVE_INSTS_PER_S = N_SIMD * CLOCK_NOMINAL_HZ / 2
 
 
-def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int) -> dict:
+def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int, N_built: int = None) -> dict:
     """SURVEY.md §8(d) per-unit figures × the units one launch processes."""
     return {
         # per-stage split of B_fwd = P(12+24+4+12K) + N(12+12) + N·40 + W·H·20
@@ -75,7 +75,7 @@ def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int) -> dict:
         # depth sort = 3 passes × (key + id read and written) + one histogram read of the keys;
         # tile scatter = the ids written + each Gaussian's (id, rect) read once + the per-chunk start table read once
         "depth_sort_compulsory": P * (3 * 16 + 4),
-        "tile_scatter_compulsory": N * 4 + P * 12,
+        "tile_scatter_compulsory": (N if N_built is None else N_built) * 4 + P * 12,   # (the ids this build writes)
         "fwd_blend": N * 40 + W * H * 20,
         # B_bwd = W·H·20 + N·40 + P(12+24+4+12K) + P(12+12+24+4+12M)
         "bwd_blend": W * H * 20 + N * 40,
@@ -137,10 +137,14 @@ class Workload:
         color.backward(self.dL)  # the upstream gradient dL/dcolor goes straight into the rasterizer's backward
         return color
 
-    def num_rendered(self) -> int:
+    def num_rendered(self, reference: bool = True) -> int:
+        """List entries of this frame.  `reference=True`: N_dup of the REFERENCE's emit rule (every tile of the 3σ square,
+        SURVEY.md §8d) — the figure the algorithmic bytes are defined with, and what `reference_rects=True` builds;
+        False: what the default build lists (tight rects: only tiles the α ≥ 1/255 ellipse reaches)."""
         from ggrt_official_amd.rasterizer import debug_forward_state
         sc = self.sc
-        return debug_forward_state(sc.means3D, sc.opacities, sc.settings(), shs=sc.shs, cov3D_precomp=sc.cov3D)["num_rendered"]
+        rs = sc.settings()._replace(reference_rects=reference)
+        return debug_forward_state(sc.means3D, sc.opacities, rs, shs=sc.shs, cov3D_precomp=sc.cov3D)["num_rendered"]
 
     def stage_times(self, n: int) -> dict:
         """per-stage HIP-event timing on the launch stream (the library brackets its stages with hipEvents on the
@@ -155,14 +159,14 @@ class Workload:
             d = {k: v for k, v in d.items() if k.startswith("fwd_")}
         return d
 
-    def rooflines(self, stages: dict, N: int) -> dict:
+    def rooflines(self, stages: dict, N: int, N_built: int = None) -> dict:
         D = self.cfg["sh_degree"]
         M = self.sc.shs.shape[1]
         deg = min(D, int(getattr(self.rs, "sh_max_degree", 3) or 3))
         while (deg + 1) ** 2 > M:
             deg -= 1
         K = (deg + 1) ** 2
-        ab = algorithmic_bytes(self.P, N, self.W, self.H, K, M)
+        ab = algorithmic_bytes(self.P, N, self.W, self.H, K, M, N_built)
         kernel_ms = {"fwd_preprocess": stages["fwd_preprocess_ms"], "fwd_blend": stages["fwd_blend_ms"]}
         if not self.fwd_only:
             kernel_ms.update({"bwd_blend": stages["bwd_blend_ms"], "bwd_preprocess": stages["bwd_preprocess_ms"]})
@@ -321,13 +325,14 @@ def secondary_record(name: str, cfg: dict, dev, steps: int, warmup: int, fwd_onl
     _, per_step = timed_steps(lambda i: wl.step(), steps, warmup, dev)
     stages = wl.stage_times(3)
     N = wl.num_rendered()
+    N_built = wl.num_rendered(reference=False)
     pc = percentiles(per_step)
     rec = {"workload": (f"{name}: {wl.P} Gaussians, {wl.W}x{wl.H}, SH deg {cfg['sh_degree']} (M={wl.sc.shs.shape[1]}), "
                         f"profile {cfg['profile']}" + (f", layout {cfg['layout']}" if cfg.get("layout") else "") +
                         (", forward only (torch.no_grad)" if fwd_only else ", fwd+bwd incl. camera gradient")),
-           "num_rendered": N, "ms_per_step": pc, "mpix_s": round(wl.W * wl.H / pc["median"] / 1e3, 1),
+           "num_rendered": N, "num_rendered_built": N_built, "ms_per_step": pc, "mpix_s": round(wl.W * wl.H / pc["median"] / 1e3, 1),
            "frames_per_s": round(1e3 / pc["median"], 1), "stages_ms": {k: round(v, 4) for k, v in stages.items()}}
-    rec.update(wl.rooflines(stages, N))
+    rec.update(wl.rooflines(stages, N, N_built))
     del wl
     torch.cuda.empty_cache()
     return rec
@@ -440,7 +445,8 @@ def main():
 
     stages = wl.stage_times(args.profile_steps)
     log("stages: " + ", ".join(f"{k}={v:.3f}" for k, v in stages.items()))
-    N = wl.num_rendered()  # num_rendered of this rank's frame
+    N = wl.num_rendered()  # num_rendered of this rank's frame by the reference's emit rule (algorithmic bytes)
+    N_built = wl.num_rendered(reference=False)
 
     # informational: the same step with the sync-free forward (list buffer sized 1.25·N up front) captured in ONE
     # HIP graph and replayed — no host sync, no per-kernel launch cost.  Not the headline value: the default,
@@ -492,7 +498,7 @@ def main():
     if rank == 0:
         D = cfg["sh_degree"]
         ms_per_step = elapsed / args.steps * 1e3
-        rf = wl.rooflines(stages, N)
+        rf = wl.rooflines(stages, N, N_built)
         dom = rf["roofline"]["kernel"]
         kname = {"bwd_blend": "blend_bwd_kernel", "fwd_blend": "blend_fwd_kernel",
                  "fwd_preprocess": "preprocess_fwd_kernel", "bwd_preprocess": "preprocess_bwd_kernel"}[dom]
@@ -546,7 +552,11 @@ def main():
                                    f"fwd+bwd incl. camera gradient, 1 frame per GPU" +
                                    (f", one RCCL mean all-reduce per step of {G} stand-in parameter-gradient floats + the "
                                     f"camera gradient ({args.exchange_mode}, {args.exchange_chunks} chunks)" if dist_on else ""),
-                       "num_rendered": N, "parallelism": f"frames x{world}"},
+                       "num_rendered": N, "num_rendered_built": N_built,
+                       "num_rendered_note": "num_rendered = N_dup by the reference's emit rule (3-sigma square), which SURVEY §8(d)'s "
+                                            "algorithmic bytes are defined with; num_rendered_built = what the default build "
+                                            "lists (tight tile rects, same outputs bit for bit)",
+                       "parallelism": f"frames x{world}"},
             "step_ms_hip_events": percentiles(per_step),
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
         }
