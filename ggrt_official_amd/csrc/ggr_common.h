@@ -88,6 +88,7 @@ __host__ __device__ static inline size_t ggr_sort_status_base(size_t S) { return
 #define GGR_SORT_LEVELS 3
 #define GGR_SORT_TREE_MAX_TILES 512   // (tiles of 4096 keys) up to here all tiles of a sort are resident at once — as one
                                       // tile of up to 8192 keys per CU, or two per CU — and look back through the tree
+                                      // (the tree's three levels span 8·8·8 tiles: do not raise without a fourth)
 static inline size_t ggr_sort_zero_words(size_t n, size_t S = 1) {
     const size_t tps = ggr_sort_blocks((n ? n : 1) / S ? (n ? n : 1) / S : 1);
     const size_t levels = tps * S <= GGR_SORT_TREE_MAX_TILES ? GGR_SORT_LEVELS : 1;

@@ -22,7 +22,7 @@ def _state(s):
     return debug_forward_state(s.means3D, s.opacities, s.settings(), shs=s.shs, cov3D_precomp=s.cov3D)
 
 
-@pytest.mark.parametrize("name", ["C3", "C5p"])
+@pytest.mark.parametrize("name", ["C3", "C5p", "C6p"])   # C6p: 4.9 M keys = 1200 sort tiles (beyond one resident wave of tiles)
 def test_lists_partition_and_are_depth_sorted(name):
     sc = make_scene(**CONFIGS[name])
     s = sc.to(dev)
