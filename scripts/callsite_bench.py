@@ -70,7 +70,7 @@ def measure(dev="cuda:0", steps=10, warmup=3, config="C5p"):
     return out
 
 
-def measure_views(dev="cuda:0", steps=10, warmup=3, config="C5p", views=4):
+def measure_views(dev="cuda:0", steps=10, warmup=3, config="C5p", views=4, only=None):
     """SURVEY.md §8f-2 at GGRt's shape: `views` target views of the SAME Gaussians (pixelSplat-style samples render
     several target views; reference decoder_splatting_cuda.py:40-60), colour + depth, forward + backward:
 
@@ -116,6 +116,8 @@ def measure_views(dev="cuda:0", steps=10, warmup=3, config="C5p", views=4):
                        f"of the same Gaussians"}
     for name, fn in (("one_view_ms", lambda: run(1, False)), ("per_view_loop_ms", lambda: run(views, False)),
                      ("batched_ms", lambda: run(views, True))):
+        if only and name != only:   # (kernel traces of one leg alone)
+            continue
         for _ in range(warmup):
             for t in leaves:
                 t.grad = None
@@ -128,8 +130,13 @@ def measure_views(dev="cuda:0", steps=10, warmup=3, config="C5p", views=4):
             fn()
         torch.cuda.synchronize()
         out[name] = round((time.perf_counter() - t0) / steps * 1e3, 3)
-    out["batched_over_one_view"] = round(out["batched_ms"] / out["one_view_ms"], 2)
+    if not only:
+        out["batched_over_one_view"] = round(out["batched_ms"] / out["one_view_ms"], 2)
     return out
+
+
+def measure_views_batched_only(steps=10, warmup=3):
+    return measure_views(steps=steps, warmup=warmup, only="batched_ms")
 
 
 def measure_sets(dev="cuda:0", steps=10, warmup=3, config="C5p", sets=4):

@@ -3,15 +3,16 @@
 #   kernel trace + stats of the C3 bench command, the two HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE, separate: TCC
 #   has 4 counter slots), four SQ counter passes, and the kernel stats of the 4-view batched call site at GGRt's shape.
 # Counter passes carry --kernel-trace only (never sys/runtime trace together with --pmc).
-# usage: scripts/profile_round.sh <tag>      → gpurun_out/prof_<tag>/…  (summaries: *.txt / *.json, copy to profiles/)
+# usage: scripts/profile_round.sh <tag> [config, default C3]   → gpurun_out/prof_<tag>/…  (summaries: *.txt / *.json, copy to profiles/)
 set -u
 TAG=$1
+CFG=${2:-C3}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-callsite --no-graph"
+BENCH="python $R/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-callsite --no-graph"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o fetch -- $BENCH > $OUT/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write -- $BENCH > $OUT/write.log 2>&1
