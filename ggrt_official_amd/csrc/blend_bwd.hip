@@ -91,7 +91,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     // (`views` frames stacked vertically, as in blend_fwd: tile vt of the launch = tile (vt mod T) of view vt / T)
     const int tiles1 = grid_x * ((H + GGR_TILE - 1) / GGR_TILE), ntiles = tiles1 * views;
     const int seg = segments > 1 ? (int)blockIdx.x / xcd_grid(ntiles) : 0;
-    const int vtile = xcd_tile((int)blockIdx.x - seg * xcd_grid(ntiles), ntiles);
+    const int vtile = xcd_tile((int)blockIdx.x - seg * xcd_grid(ntiles), ntiles, true);
     if (vtile < 0) return;  // padding workgroup (before any barrier)
     const int view = vtile / tiles1, tile = vtile - view * tiles1;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;

@@ -6,23 +6,27 @@ namespace ggr {
 
 #define GGR_BATCH 256
 
-// Workgroup b runs on XCD b mod 8 and every XCD has its own L2.  Neighbouring tiles share most of their
-// Gaussians' 48-B records, so an XCD gets contiguous ranges of the row-major tile sequence instead of every 8th
-// tile: `split` ranges each (range r of XCD x = range x + 8·r of the 8·split equal ranges), split = 1 below 4000
-// tiles, up to 4 from 8000 tiles on (≥ 250 tiles ≈ two tile rows of a 1080p frame per range).  Measured, C3 with
-// the upper half of the frame empty (a frame with sky), blend forward / backward: one range per XCD 0.192 / 0.409
-// ms, four 0.160 / 0.349 ms; the uniform C3 frame pays 1-2 % for it (0.189 / 0.402 → 0.191 / 0.409), the 660-tile
-// GGRt frames would pay 4 % and keep one range.  Returns -1 for the padding workgroups.
-__host__ __device__ static inline int xcd_split(int tiles) { return tiles >= 8000 ? 4 : tiles >= 6000 ? 3 : tiles >= 4000 ? 2 : 1; }
-__host__ __device__ static inline int xcd_range_len(int tiles) { return (tiles + 8 * xcd_split(tiles) - 1) / (8 * xcd_split(tiles)); }
-__device__ __forceinline__ int xcd_tile(int block, int tiles) {
-    const int len = xcd_range_len(tiles);
-    const int i = block >> 3;                       // index inside the XCD
-    const int r = i / len, j = i - r * len;         // which of the XCD's ranges, position inside it
-    const int t = ((block & 7) + 8 * r) * len + j;
+// Workgroup b runs on XCD b mod 8 and every XCD has its own L2.  Two tile ↔ workgroup mappings:
+//   interleaved  tile = b: every 8th tile of the row-major sequence per XCD.  Any compact region of the frame — the one
+//                live cell of the fine-tune loop's deferred back-propagation, the ground under a sky — is spread over
+//                all eight XCDs;
+//   ranged       XCD x owns the contiguous tile range [x·len, (x+1)·len): neighbouring tiles share most of their
+//                Gaussians' 48-B records, which then meet in one L2.
+// Measured (round 3, blend forward / backward, ranged → interleaved): C3 0.174 / 0.394 → 0.173 / 0.389 ms; C3 with the
+// upper half of the frame empty 0.145 / 0.330 → 0.118 / 0.246 (rounds 1-2 split the ranges in up to four per XCD for this
+// frame: 0.160 / 0.349 at the time); C5′ 0.186 / 0.246 → 0.192-0.195 / 0.246-0.248; C4′ 0.199 / 0.230 → 0.205 / 0.231;
+// C6′ 0.433 / 0.841 → 0.440 / 0.825; C5′ with the gradient confined to one cell of 2 × 2: backward 0.155 → 0.103, the
+// scissored forward 0.436 → 0.397.  Hence: the backward is always interleaved; the forward is ranged only for a frame of
+// fewer than 4096 tiles without a scissor (its one regression, 3-5 %).  Both return -1 for the padding workgroups of a
+// grid of xcd_grid(tiles).
+__host__ __device__ static inline int xcd_grid(int tiles) { return ((tiles + 7) / 8) * 8; }
+__device__ __forceinline__ int xcd_tile(int block, int tiles, bool interleaved) {
+    if (interleaved) return block < tiles ? block : -1;
+    const int len = (tiles + 7) / 8;
+    const int t = (block & 7) * len + (block >> 3);
     return t < tiles ? t : -1;
 }
-__host__ __device__ static inline int xcd_grid(int tiles) { return xcd_range_len(tiles) * xcd_split(tiles) * 8; }
+__host__ static inline bool xcd_forward_interleaved(int tiles, bool scissored) { return tiles >= 4096 || scissored; }
 
 // Checkpoints (ggr_common.h, ImageLayout): list positions between two checkpoints of a tile whose list has `len`
 // entries — a multiple of the staging batch, large enough that slots 1 … slots−1 cover the whole list.

@@ -30,7 +30,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
                  const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ out_depth, float* __restrict__ ckpt,
-                 int ckpt_slots, uint32_t* __restrict__ tile_top, int views, float4* __restrict__ zero4,
+                 int ckpt_slots, uint32_t* __restrict__ tile_top, int views, int interleaved, float4* __restrict__ zero4,
                  size_t zero4_n) {
     __shared__ StagedSplat stage[BATCH + 1];   // + the null record that pads a wave's survivor list
     __shared__ __attribute__((aligned(16))) uint16_t surv[4][BATCH + SURV_GROUP];  // per wave: LDS byte offsets of its survivors
@@ -46,7 +46,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     // `views` frames stacked vertically (ggr_common.h ViewSet): tile vt of the launch = tile (vt mod T) of view vt / T;
     // per-view outputs and per-pixel state follow each other in the caller's [V, …] arrays
     const int tiles1 = grid_x * ((H + GGR_TILE - 1) / GGR_TILE), ntiles = tiles1 * views;
-    const int vtile = xcd_tile((int)blockIdx.x, ntiles);
+    const int vtile = xcd_tile((int)blockIdx.x, ntiles, interleaved != 0);
     if (vtile < 0) return;  // padding workgroup (before any barrier)
     const int view = vtile / tiles1, tile = vtile - view * tiles1;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -182,12 +182,13 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
-                      float* out_depth, float* ckpt, int ckpt_slots, uint32_t* tile_top, int views, void* zero_area,
-                      size_t zero_bytes, hipStream_t s) {
+                      float* out_depth, float* ckpt, int ckpt_slots, uint32_t* tile_top, int views, int scissored,
+                      void* zero_area, size_t zero_bytes, hipStream_t s) {
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
     if (gx * gy * views == 0) return;
     hipLaunchKernelGGL(blend_fwd_kernel, dim3(xcd_grid(gx * gy * views)), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg,
-                       out_color, final_T, n_contrib, out_depth, ckpt, ckpt_slots, tile_top, views, (float4*)zero_area,
+                       out_color, final_T, n_contrib, out_depth, ckpt, ckpt_slots, tile_top, views,
+                       xcd_forward_interleaved(gx * gy * views, scissored != 0) ? 1 : 0, (float4*)zero_area,
                        zero_area ? zero_bytes / 16 : 0);
 }
 

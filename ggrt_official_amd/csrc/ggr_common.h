@@ -327,6 +327,7 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
                       float* out_depth, float* ckpt /*or null*/, int ckpt_slots, uint32_t* tile_top, int views,
+                      int scissored /*the lists are confined to a window of the frame (GgrSettings.scissor)*/,
                       void* zero_area /*or null: also cleared, on the side*/, size_t zero_bytes /*multiple of 16*/,
                       hipStream_t s);
 
