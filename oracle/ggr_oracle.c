@@ -255,18 +255,25 @@ typedef struct {
     uint32_t val;
 } KV;
 
-/* Stable merge sort on the 64-bit key (A.2): ties keep emission order. */
+/* Stable merge sort on the 64-bit key (A.2): ties keep emission order.  The merges of one width are independent of
+ * each other: OpenMP over them (the result does not depend on the thread count; the last widths have fewer merges than
+ * threads and run on one or two cores).  The two arrays alternate as source and destination. */
 static void kv_merge_sort(KV* a, KV* tmp, int64_t n) {
+    KV *src = a, *dst = tmp;
     for (int64_t w = 1; w < n; w *= 2) {
-        for (int64_t lo = 0; lo < n; lo += 2 * w) {
+        const int64_t merges = (n + 2 * w - 1) / (2 * w);
+#pragma omp parallel for schedule(static) if (n > 65536 && merges >= 2)
+        for (int64_t m = 0; m < merges; m++) {
+            const int64_t lo = m * 2 * w;
             int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
             int64_t i = lo, j = mid, k = lo;
-            while (i < mid && j < hi) tmp[k++] = (a[j].key < a[i].key) ? a[j++] : a[i++];
-            while (i < mid) tmp[k++] = a[i++];
-            while (j < hi) tmp[k++] = a[j++];
+            while (i < mid && j < hi) dst[k++] = (src[j].key < src[i].key) ? src[j++] : src[i++];
+            while (i < mid) dst[k++] = src[i++];
+            while (j < hi) dst[k++] = src[j++];
         }
-        memcpy(a, tmp, (size_t)n * sizeof(KV));
+        KV* t = src; src = dst; dst = t;
     }
+    if (src != a) memcpy(a, src, (size_t)n * sizeof(KV));
 }
 
 /*
