@@ -244,7 +244,7 @@ def timed_steps(fn, steps: int, warmup: int, dev, barrier=None, finish=None):
 # ---------------------------------------------------------------------------------------------------------
 def cpu_baseline_c_oracle(sc, dL_cpu, reps: int = 2) -> dict:
     """oracle/ggr_oracle.c on the WHOLE frame: preprocess + 64-bit key sort + blend forward + blend backward +
-    per-Gaussian backward, OpenMP over Gaussians / pixel rows / tiles (the key sort is sequential)."""
+    per-Gaussian backward, OpenMP over Gaussians / pixel rows / tiles / the merges of the key sort."""
     from oracle import c_oracle
     from tests.helpers import oracle_forward
     cores = int(c_oracle.lib().ggo_num_threads())
