@@ -76,7 +76,13 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
     uint32_t last = 0;
-    float live = inside ? 1.0f : 0.f;   // 0: the pixel is saturated (or outside the image) and takes no further entry
+    // false: the pixel is saturated (or outside the image) and takes no further entry.  A lane MASK in scalar
+    // registers, like every per-pixel condition below: a vector compare costs 4.6 cycles, a select 2.4, a literal operand
+    // 2 more (tools/valu_peak_bench.hip, round 3) — the conditions are combined with scalar ANDs and applied by ONE select
+    // on the weight and one on the position (as float factors and per-condition selects: 57 instead of 42 issue cycles)
+    bool live = inside;
+    float amax = GGR_ALPHA_MAX;
+    __asm__ volatile("" : "+s"(amax));   // (a scalar register operand instead of a 32-bit literal in every v_min)
     if (tid == 0) {                      // the null record: opacity 0 → α = 0 → never contributes
         stage[BATCH].a = make_float4(0.f, 0.f, 0.f, 0.f); stage[BATCH].b = make_float4(0.f, 0.f, 0.f, 0.f);
         stage[BATCH].c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -96,7 +102,6 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         if (tid < nb) {
             float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1], c = splat[3 * (size_t)g + 2];
             stage_scale_conic(a, b, c);  // (blend_common.h: the pixel loop works on k·q, k = log2(e)/2)
-            c.w = __uint_as_float((uint32_t)(b0 + tid + 1));  // its position in the list, + 1: what n_contrib records
             stage[tid].a = a;
             stage[tid].b = b;
             stage[tid].c = c;
@@ -131,6 +136,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const char* stage_bytes = reinterpret_cast<const char*>(stage);
+            uint32_t hit_off = 0xFFFFFFFFu;   // LDS offset of the pixel's latest contributor in this batch (none yet)
             for (int k0 = 0; k0 < ns; k0 += SURV_GROUP) {
                 uint32_t pkw[SURV_GROUP / 2];   // the group's offsets, one broadcast read
                 __builtin_memcpy(pkw, my_surv + k0, sizeof pkw);
@@ -138,24 +144,28 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 for (int u = 0; u < SURV_GROUP; u++) {
                     const uint32_t off = (pkw[u >> 1] >> (16 * (u & 1))) & 0xffffu;   // (VGPR, uniform)
                     const StagedSplat* rec = reinterpret_cast<const StagedSplat*>(stage_bytes + off);
-                    const float4 a = rec->a, rb = rec->b, rc = rec->c;
+                    const float4 a = rec->a, rb = rec->b;
+                    const float2 rc = *reinterpret_cast<const float2*>(&rec->c);   // (blue, z)
                     const float q2 = staged_q2(a, rb, a.x - pixx, a.y - pixy);  // = −power·log2(e)
-                    float alpha = fminf(GGR_ALPHA_MAX, rb.y * __builtin_amdgcn_exp2f(-q2));
-                    alpha = q2 >= 0.0f ? alpha : 0.f;                 // power > 0: skip
-                    alpha = alpha >= GGR_ALPHA_MIN ? alpha : 0.f;    // α < 1/255: skip
-                    alpha *= live;                                    // a saturated pixel takes nothing more
-                    float w = alpha * T;
-                    const float test_T = T - w;  // T·(1−α); stays ≥ T_MIN for a skipped entry (T itself never drops below)
-                    const bool stop = test_T < GGR_T_MIN;
-                    w = stop ? 0.f : w;
-                    live = stop ? 0.f : live;
+                    const float alpha = fminf(amax, rb.y * __builtin_amdgcn_exp2f(-q2));
+                    // skip: power > 0, α < 1/255, or the pixel is saturated
+                    const bool cand = live & (q2 >= 0.0f) & (alpha >= GGR_ALPHA_MIN);
+                    const float wr = alpha * T;
+                    const float test_T = T - wr;               // T·(1−α)
+                    const bool stop = cand & (test_T < GGR_T_MIN);
+                    const bool take = cand & !stop;
+                    live = live & !stop;
+                    const float w = take ? wr : 0.f;
                     C0 = fmaf(rb.z, w, C0); C1 = fmaf(rb.w, w, C1); C2 = fmaf(rc.x, w, C2); Dz = fmaf(rc.y, w, Dz);
                     T -= w;
-                    // (list position of the entry: the staging thread left it in the record's last word)
-                    last = w > 0.f ? __float_as_uint(rc.w) : last;
+                    // (which entry: its LDS offset, already in a register — the list position follows from it after the
+                    //  batch; reading it from the record was a fourth LDS read per survivor, 2 of 12 LDS cycles)
+                    hit_off = take ? off : hit_off;
                 }
-                if (__all(live == 0.f)) { wdone = true; break; }
+                if (!__any(live)) { wdone = true; break; }
             }
+            // list position + 1 of entry e = offset / 48 of this batch: what n_contrib records
+            if (hit_off != 0xFFFFFFFFu) last = (uint32_t)b0 + 1u + (((hit_off >> 4) * 0xAAABu) >> 17);
             if (wdone && lane == 0) wave_done[wave] = 1;
         }
     }

@@ -16,13 +16,15 @@
 #define ITERS 32768
 #define CHAINS 8
 
-enum { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERM32, PERM16, PK_FMA, FMA_DEP, MIX_BLEND, NMODES };
+enum { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERM32, PERM16, PK_FMA, FMA_DEP, MIX_BLEND, CMP_VCC, CNDMASK_VCC, CMP_CND, CMP_SGPR_CND, MIN_LIT, MOV, NMODES };
 static const char* kNames[NMODES] = {"v_fma_f32 (8 indep chains)", "v_mul_f32 + v_add_f32", "v_exp_f32",
                                      "v_rcp_f32", "v_add_f32_dpp quad_perm", "v_permlane32_swap",
                                      "v_permlane16_swap", "v_pk_fma_f32 (2 flop-pairs/inst)",
-                                     "v_fma_f32 (ONE dependent chain)", "blend-like mix: 6 fma + exp + rcp"};
+                                     "v_fma_f32 (ONE dependent chain)", "blend-like mix: 6 fma + exp + rcp",
+                                     "v_cmp_lt_f32 -> vcc", "v_cndmask_b32 (vcc)", "v_cmp (vcc) + v_cndmask (vcc)",
+                                     "v_cmp_e64 -> sgpr pair + v_cndmask_e64", "v_min_f32 with a literal", "v_mov_b32"};
 // VALU instructions issued per chain per iteration
-static const int kInstPerChainIter[NMODES] = {1, 2, 1, 1, 1, 1, 1, 1, 1, 8};
+static const int kInstPerChainIter[NMODES] = {1, 2, 1, 1, 1, 1, 1, 1, 1, 8, 1, 1, 2, 2, 1, 1};
 
 template <int MODE>
 __global__ void __launch_bounds__(256) k(float* out, int iters) {
@@ -47,6 +49,19 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
             if (MODE == PERM32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(v[c]), "+v"(w[c]));
             if (MODE == PERM16) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(v[c]), "+v"(w[c]));
             if (MODE == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(pv[c]));
+            if (MODE == CMP_VCC) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(v[c]), "v"(w[c]) : "vcc");
+            if (MODE == CNDMASK_VCC) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[c]) : "v"(w[c]) : );
+            if (MODE == CMP_CND) {
+                asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(v[c]), "v"(w[c]) : "vcc");
+                asm volatile("s_nop 1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[c]) : "v"(w[c]) : "vcc");
+            }
+            if (MODE == CMP_SGPR_CND) {
+                unsigned long long m;
+                asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(v[c]), "v"(w[c]));
+                asm volatile("s_nop 1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[c]) : "v"(w[c]), "s"(m));
+            }
+            if (MODE == MIN_LIT) asm volatile("v_min_f32 %0, 0x3f7d70a4, %0" : "+v"(v[c]));
+            if (MODE == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(v[c]) : "v"(w[c]));
             if (MODE == MIX_BLEND) {  // the shape of one (entry, pixel) evaluation: geometry fmas, exp, rcp, recurrences
                 float t;
                 asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(t) : "v"(v[c]), "v"(w[c]));
@@ -126,6 +141,6 @@ int main(int argc, char** argv) {
     const int ws[] = {1, 2, 4, 8};
 #define SWEEP(M) for (int w : ws) run<M>(out, w, clk, cus);
     SWEEP(FMA) SWEEP(MUL_ADD) SWEEP(EXP) SWEEP(RCP) SWEEP(DPP_ADD) SWEEP(PERM32) SWEEP(PERM16) SWEEP(PK_FMA)
-    SWEEP(FMA_DEP) SWEEP(MIX_BLEND)
+    SWEEP(FMA_DEP) SWEEP(MIX_BLEND) SWEEP(CMP_VCC) SWEEP(CNDMASK_VCC) SWEEP(CMP_CND) SWEEP(CMP_SGPR_CND) SWEEP(MIN_LIT) SWEEP(MOV)
     return 0;
 }
