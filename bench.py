@@ -526,9 +526,10 @@ def main():
         mix_path = newest_profile("r*_valu_mix.json")
         if sq_path and mix_path:
             mix = json.load(open(mix_path))
-            valu = {"valu_peak_source": "profiles/r03_valu_peak.txt (tools/valu_peak_bench.hip, this part): 2 cycles per plain wave64 "
-                                        "VALU instruction (= /opt/skills/guides/MI355X_MICROARCH.md:52-53,430), 4 DPP / packed, 8 exp / rcp / "
-                                        "permlane-swap; 126.7 TFLOP/s fp32 FMA sustained = 0.81 of spec at ≈ 1.87 GHz",
+            valu = {"valu_peak_source": "profiles/r03_valu_peak.txt, r03_valu_peak2.txt (tools/valu_peak_bench.hip, this part): 2 cycles per "
+                                        "plain wave64 VALU instruction (= /opt/skills/guides/MI355X_MICROARCH.md:52-53,430), 4 DPP / packed / "
+                                        "vector compare / any instruction with a 32-bit literal, 8 exp / rcp / permlane-swap; 126.7 TFLOP/s "
+                                        "fp32 FMA sustained = 0.81 of spec at ≈ 1.87 GHz",
                     "peak_plain_wave_insts_per_s_nominal": VALU_PLAIN_WAVE_INSTS_PER_S,
                     "instruction_counts_source": f"profiles/{os.path.basename(sq_path)} (SQ_INSTS_VALU; collected separately, not in this run)",
                     "instruction_mix_source": f"profiles/{os.path.basename(mix_path)} (static mix of the hot loops, scripts/valu_mix.py)"}

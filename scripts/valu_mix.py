@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Static VALU instruction mix of the blend kernels' hot loops, from the gfx950 ISA hipcc emits for them, weighted with
-the per-class issue costs measured by tools/valu_peak_bench.hip (profiles/r03_valu_peak.txt): plain VALU 2 cycles per
-wave64 instruction, DPP-modified VALU 4, v_exp / v_rcp / v_permlane*_swap 8, packed fp32 4.
+the per-class issue costs measured by tools/valu_peak_bench.hip (profiles/r03_valu_peak.txt, r03_valu_peak2.txt): plain
+VALU 2 cycles per wave64 instruction, DPP-modified VALU 4, v_exp / v_rcp / v_permlane*_swap 8, packed fp32 4, vector
+compares 4 (4.6 at the nominal clock; a select is a plain instruction), a 32-bit literal operand 2 more.
 
 usage: scripts/valu_mix.py            (needs hipcc; cross-compiles, no GPU)  → JSON on stdout
 The mix is taken over the innermost loops only (the survivor / reduction-batch bodies, where > 90 % of the dynamic
@@ -14,7 +15,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COST = {"plain": 2.0, "dpp": 4.0, "trans": 8.0, "permlane_swap": 8.0, "packed": 4.0}
+COST = {"plain": 2.0, "dpp": 4.0, "trans": 8.0, "permlane_swap": 8.0, "packed": 4.0, "cmp": 4.0, "plain_literal": 4.0}
 
 
 def classify(line: str):
@@ -30,6 +31,10 @@ def classify(line: str):
         return "dpp"
     if op.startswith("v_pk_"):
         return "packed"
+    if op.startswith("v_cmp"):
+        return "cmp"
+    if re.search(r"[ ,]0x[0-9a-f]{5,8}\b", line):   # a 32-bit literal (inline constants print as decimals)
+        return "plain_literal"
     return "plain"
 
 
@@ -41,7 +46,7 @@ def kernel_mix(src: str, symbol_re: str):
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
     start = next(i for i, l in enumerate(text) if re.match(symbol_re, l))
-    end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
+    end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))   # (an early return is an s_endpgm too)
     body = text[start:end]
     # loop depth of every line from LLVM's block comments ("Depth=N"); keep the deepest loops
     depth, cur, in_label = [], 0, False
@@ -70,7 +75,7 @@ def kernel_mix(src: str, symbol_re: str):
 
 
 if __name__ == "__main__":
-    res = {"costs_cycles_per_wave64_inst": COST, "cost_source": "profiles/r03_valu_peak.txt (tools/valu_peak_bench.hip)",
+    res = {"costs_cycles_per_wave64_inst": COST, "cost_source": "profiles/r03_valu_peak.txt, profiles/r03_valu_peak2.txt (tools/valu_peak_bench.hip)",
            "blend_fwd_kernel": kernel_mix("blend_fwd.hip", r"^_ZN3ggr16blend_fwd_kernel"),
            "blend_bwd_kernel": kernel_mix("blend_bwd.hip", r"^_ZN3ggr16blend_bwd_kernelILb0")}
     json.dump(res, sys.stdout, indent=1)
