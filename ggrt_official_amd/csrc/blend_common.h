@@ -44,21 +44,25 @@ struct __attribute__((aligned(16))) StagedSplat {
 };
 
 // Exact minimum of q(d) = cxx·dx² + 2·cxy·dx·dy + cyy·dy² (d = mean − pixel) over the pixel box
-// [x0,x1]×[y0,y1].  q is convex (the conic is positive definite), so the minimum is 0 if the mean
-// lies in the box and otherwise sits on one of the four edges, where it is a clamped 1-D quadratic.
+// [x0,x1]×[y0,y1], i.e. over d ∈ [dxl,dxh]×[dyl,dyh].  q is convex (the conic is positive definite) with its free
+// minimum at the mean (d = 0): the minimum over the box is 0 if the mean lies in it and otherwise sits on a face of the
+// box that the mean SEES (moving from any other boundary point towards the mean stays inside the box and lowers q) —
+// at most one vertical and one horizontal face, where q is a clamped 1-D quadratic.  With f = the box point nearest to
+// the mean (v_med3 per coordinate; 0 where the mean is inside the range) the two candidates are the lines dx = f.x and
+// dy = f.y restricted to the box: the faces the mean sees, or — where it sees none — a line through box points, whose
+// values cannot undercut the minimum.  No compare, no branch (round 3: four edges, an inside test of four compares at
+// 4.6 cycles each and a branch cost ≈ 60 instructions per test; this form ≈ 27 — tools/valu_peak_bench.hip).
 __device__ __forceinline__ float box_min_q(float mx, float my, float cxx, float cxy, float cyy, float x0,
                                            float y0, float x1, float y1) {
     const float dxl = mx - x1, dxh = mx - x0, dyl = my - y1, dyh = my - y0;
-    if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return 0.f;
+    const float fx = __builtin_amdgcn_fmed3f(0.f, dxl, dxh), fy = __builtin_amdgcn_fmed3f(0.f, dyl, dyh);
     // v_rcp_f32 (1 ulp) instead of two IEEE divisions: an edge minimiser that is off by 1e-7 relative changes q
     // only to second order, far inside the caller's 1e-3 margin
     const float ry = -cxy * __builtin_amdgcn_rcpf(cyy), rx = -cxy * __builtin_amdgcn_rcpf(cxx);
     auto qf = [&](float dx, float dy) { return cxx * dx * dx + 2.f * cxy * dx * dy + cyy * dy * dy; };
-    const float q1 = qf(dxl, fminf(fmaxf(ry * dxl, dyl), dyh));
-    const float q2 = qf(dxh, fminf(fmaxf(ry * dxh, dyl), dyh));
-    const float q3 = qf(fminf(fmaxf(rx * dyl, dxl), dxh), dyl);
-    const float q4 = qf(fminf(fmaxf(rx * dyh, dxl), dxh), dyh);
-    return fminf(fminf(q1, q2), fminf(q3, q4));
+    const float qa = qf(fx, __builtin_amdgcn_fmed3f(ry * fx, dyl, dyh));
+    const float qb = qf(__builtin_amdgcn_fmed3f(rx * fy, dxl, dxh), fy);
+    return fminf(qa, qb);
 }
 
 // Can this entry reach α ≥ 1/255 on any pixel of the box?  α = opacity·exp(−q/2) ≥ 1/255 ⇔
