@@ -116,8 +116,10 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             // offsets (u16: 255·48 < 2^16).  Round 2 walked the ballot mask with s_ff1 / s_and per survivor and
             // combined its per-pixel conditions in scalar mask registers: ≈ 20 SALU per ≈ 22 VALU instructions, and a
             // CU has ONE scalar unit for its four SIMDs — the kernel ran at the scalar unit's pace (85 M SALU against
-            // 105 M VALU per launch at C3).  Now a survivor costs no scalar instruction at all: its offset arrives in
-            // a VGPR (a broadcast LDS read), every condition is a v_cmp feeding a v_cndmask.
+            // 105 M VALU per launch at C3).  Now the WALK costs no scalar instruction: a survivor's offset arrives in a
+            // VGPR (a broadcast LDS read).  The per-pixel conditions are lane masks in scalar registers again (three
+            // scalar ANDs per survivor, 38 M SALU per launch): as float factors and one select per condition they cost
+            // more vector issue cycles than they saved scalar ones (see `live` above).
             int ns = 0;
             uint16_t* my_surv = surv[wave];
             for (int s0 = 0; s0 < nb; s0 += 64) {
