@@ -71,6 +71,30 @@ __device__ __forceinline__ float sum_cols8(float s) {
     return s;
 }
 
+// Transposing reduction of o[0..7] over the 8 lanes of a group (the 8 pixel columns): lane c of the group gets the
+// group's sum of ONE of the values, o[π(c)] with π(c) = c for c < 4 and 11 − c for c ≥ 4 (the third level pairs lane c
+// with lane 7 − c: row_half_mirror is the only DPP move that crosses the two quads of a group) — 7 DPP adds and 14
+// selects for 8 sums; as 8 butterflies (sum_cols8: every lane gets every total) they are 24 DPP adds at twice a select's
+// issue cost (tools/valu_peak_bench.hip).  A lane keeps the values whose index bits match its own (mirrored in the
+// upper quad), sends the others to its partner and adds what the partner sends.
+__device__ __forceinline__ float transpose_cols8(const float (&o)[8], int lane) {
+    const bool up = (lane & 4) != 0;
+    const bool e0 = (((lane ^ (lane >> 2)) & 1) != 0), e1 = ((((lane >> 1) ^ (lane >> 2)) & 1) != 0);
+    float k1[4], k2[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float keep = e0 ? o[2 * i + 1] : o[2 * i], send = e0 ? o[2 * i] : o[2 * i + 1];
+        k1[i] = keep + dpp_mov<0xB1>(send);   // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const float keep = e1 ? k1[2 * j + 1] : k1[2 * j], send = e1 ? k1[2 * j] : k1[2 * j + 1];
+        k2[j] = keep + dpp_mov<0x4E>(send);   // quad_perm [2,3,0,1]
+    }
+    const float keep = up ? k2[1] : k2[0], send = up ? k2[0] : k2[1];
+    return keep + dpp_mov<0x141>(send);       // row_half_mirror
+}
+
 template <bool HAS_DEPTH>
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
@@ -173,6 +197,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     // which of the 9 (10) values this lane commits: value index vi = lane & 7 for the first atomic
     // instruction; lanes with (lane & 7) == 0 also commit value 8 (opacity) and 9 (depth) afterwards
     const int vi = lane & 7;
+    const int vix = vi < 4 ? vi : 11 - vi;   // the value transpose_cols8 leaves in this lane
     const int my_slot = lane >> 3;
 
     // the list ids of a batch are requested one batch ahead (id → record is a chain of two global round trips)
@@ -276,22 +301,21 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 // ---- reductions.  lane = 8·y + x, so the three transposing levels (32, 16, 8) sum over the pixel
                 // ROWS and leave, in lane (slot, x), column x's partial sums of that slot: six arrays go through
                 // them (Σw·dp_{r,g,b}, Σm, Σm·y', Σm·y'²) instead of nine — the moments in x are products of the
-                // column sums with the lane's x' (once per batch, not per entry) — then the three butterflies over
-                // the 8 columns finish all nine values (≈ 300 of ≈ 2480 cycles per batch less, plus 3 multiplies
-                // per (entry, pixel))
+                // column sums with the lane's x' (once per batch, not per entry) — then ONE transposing reduction over
+                // the 8 columns finishes the eight committed values (see the commit below; two butterflies give the
+                // opacity / depth pair to every lane)
                 const float Cm = transpose_rows8(g_m, lane), Cy = transpose_rows8(g_my, lane);
-                const float t_r = sum_cols8(transpose_rows8(g_r, lane));
-                const float t_g = sum_cols8(transpose_rows8(g_g, lane));
-                const float t_b = sum_cols8(transpose_rows8(g_b, lane));
-                const float S0 = sum_cols8(Cm);
-                const float Mx = sum_cols8(pxc * Cm);
-                const float Mxx = sum_cols8(pxc * pxc * Cm);
-                const float My = sum_cols8(Cy);
-                const float Mxy = sum_cols8(pxc * Cy);
-                const float Myy = sum_cols8(transpose_rows8(g_myy, lane));
+                const float Cyy = transpose_rows8(g_myy, lane);
+                float o[8];
+                o[0] = transpose_rows8(g_r, lane); o[1] = transpose_rows8(g_g, lane); o[2] = transpose_rows8(g_b, lane);
+                const float S0 = sum_cols8(Cm);   // (every lane: the pair value of the commit)
                 float t_z = 0.f;
                 if (HAS_DEPTH) t_z = sum_cols8(transpose_rows8(g_z, lane));
-                // ---- commit: lane (slot, vi) finishes value vi of its slot ---------------------------------
+                // ---- commit: lane (slot, c) finishes value π(c) of its slot (transpose_cols8) -------------------
+                // The five geometric values are LINEAR in the six moment sums, with coefficients of the slot's entry:
+                // every lane forms them on its column's partial sums, and one transposing reduction over the columns
+                // finishes all eight values (the three colour sums ride along) — instead of nine butterflies that leave
+                // all nine totals in every lane and a select of the lane's own.
                 // A slot has 9 (10) values but only 8 lanes.  Sending values 8, 9 in a second instruction of their
                 // own made two 64-B line transactions per slot; instead the 8-lane groups of an even and an odd
                 // slot (the two halves of a 16-lane row) help each other: instruction A carries the even slots'
@@ -309,18 +333,15 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                     // shift the moments from the quadrant centre to the Gaussian's mean: d = mean − pixel = o − p',
                     // o = mean − quadrant centre, p' the centred pixel coordinates
                     const float ox = a.x - qcx, oy = a.y - qcy;
-                    const float Sx = ox * S0 - Mx, Sy = oy * S0 - My;
-                    switch (vi) {
-                        case 0: val = t_r; break;
-                        case 1: val = t_g; break;
-                        case 2: val = t_b; break;
-                        // (the staged conic is k·cxx, 2k·cxy, k·cyy: back to the plain one with 1/k)
-                        case 3: val = -op * GGR_INV_KQ * (a.z * Sx + 0.5f * a.w * Sy) * ddelx_dx; break;
-                        case 4: val = -op * GGR_INV_KQ * (b.x * Sy + 0.5f * a.w * Sx) * ddely_dy; break;
-                        case 5: val = -0.5f * op * (ox * (Sx - Mx) + Mxx); break;
-                        case 6: val = -0.5f * op * (ox * Sy - oy * Mx + Mxy); break;
-                        default: val = -0.5f * op * (oy * (Sy - My) + Myy); break;
-                    }
+                    const float Mx = pxc * Cm, Mxx = pxc * Mx, Mxy = pxc * Cy;   // (this column's share of the moments in x)
+                    const float Sx = ox * Cm - Mx, Sy = oy * Cm - Cy;
+                    // (the staged conic is k·cxx, 2k·cxy, k·cyy: back to the plain one with 1/k)
+                    o[3] = -op * GGR_INV_KQ * (a.z * Sx + 0.5f * a.w * Sy) * ddelx_dx;
+                    o[4] = -op * GGR_INV_KQ * (b.x * Sy + 0.5f * a.w * Sx) * ddely_dy;
+                    o[5] = -0.5f * op * (ox * (Sx - Mx) + Mxx);
+                    o[6] = -0.5f * op * (ox * Sy - oy * Mx + Mxy);
+                    o[7] = -0.5f * op * (oy * (Sy - Cy) + Cyy);
+                    val = transpose_cols8(o, lane);
                 }
                 if (my_e < 0) val = 0.f;
                 // (a third atomic instruction — a third line transaction per slot — once cost the depth variant 45 %:
@@ -336,12 +357,12 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 float* const rec_nb = grad2d + GGR_G2D_STRIDE * (size_t)gid_nb;
                 const bool help = vi < NPAIR && pair_nb != 0.f;  // (an empty neighbour slot has pair value 0)
                 {   // instruction A: the even slots' records
-                    float* const p = odd ? rec_nb + GGR_G2D_OPACITY + vi : rec_own + vi;
+                    float* const p = odd ? rec_nb + GGR_G2D_OPACITY + vi : rec_own + vix;
                     const float v = odd ? pair_nb : val;
                     if (odd ? help : v != 0.f) atomicAdd(p, v);
                 }
                 {   // instruction B: the odd slots' records
-                    float* const p = odd ? rec_own + vi : rec_nb + GGR_G2D_OPACITY + vi;
+                    float* const p = odd ? rec_own + vix : rec_nb + GGR_G2D_OPACITY + vi;
                     const float v = odd ? val : pair_nb;
                     if (odd ? v != 0.f : help) atomicAdd(p, v);
                 }
