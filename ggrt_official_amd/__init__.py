@@ -7,8 +7,8 @@ Scope: the rasterizer (forward + backward) behind a C ABI, the c
 synthetic-scene generator for the benchmark.  Everything else of GGRt is out of scope.
 """
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, last_forward_status,
-                         rasterize_gaussians, rasterize_views)
+                         rasterize_gaussians, rasterize_views, set_list_hint)
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_views",
-           "last_forward_status"]
+           "last_forward_status", "set_list_hint"]
 __version__ = "0.1.0"

@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libggr_raster.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -47,7 +47,7 @@ class GgrForwardOut(C.Structure):
         ("out_color", C.c_void_p), ("radii", C.c_void_p), ("out_depth", C.c_void_p), ("geom_buffer", C.c_void_p),
         ("image_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("num_rendered", C.c_int64),
         ("stage_ms", C.c_void_p), ("binning_capacity", C.c_int64), ("no_backward", C.c_int32),
-        ("backward_scratch", C.c_void_p),
+        ("backward_scratch", C.c_void_p), ("capacity_is_hint", C.c_int32),
     ]
 
 

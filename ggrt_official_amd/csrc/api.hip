@@ -263,13 +263,14 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // sync-free mode: the caller brought a list buffer of `binning_capacity` entries → no read-back, no host
     // sync, no second allocator call; the whole forward (and backward) is then hipGraph-capturable
     const bool sync_free = out->binning_capacity > 0 && out->binning_buffer != nullptr;
+    const bool hinted = sync_free && out->capacity_is_hint != 0;   // exact mode with a guessed buffer: N is awaited at the END
     if (out->binning_capacity >= 0x7FFFFFFF) return fail(GGR_E_LIMIT, "binning_capacity too large");
     const uint32_t capacity = sync_free ? (uint32_t)out->binning_capacity : 0xFFFFFFFFu;
     // exact mode: num_rendered travels to the host through a pinned word written by the scan kernel, with an
     // event right behind that kernel — the host wakes up while the last scan kernel still runs and has the list
     // buffer allocated and the scatter queued by the time the GPU gets there (a device→host memcpy into pageable
     // memory + stream sync left the GPU idle for that long)
-    ReadbackSlot* rb = (!sync_free && P > 0) ? readback_slot() : nullptr;
+    ReadbackSlot* rb = ((!sync_free || hinted) && P > 0) ? readback_slot() : nullptr;
     if (rb) *(volatile uint32_t*)rb->host = GGR_READBACK_ARMED;
     if (P > 0) {
         ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, capacity, s,
@@ -332,6 +333,19 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
                           ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s);
     KCHECK(dbg, s, "blend_fwd");
     tm.mark();
+    if (hinted) {   // num_rendered, while the device works on scatter and blend; the guess must have held
+        out->num_rendered = 0;
+        if (rb) {
+            const int rc = wait_readback((volatile uint32_t*)rb->host, query_event, (void*)rb->ev, GGR_READBACK_TIMEOUT_S, &num_rendered);
+            if (rc != GGR_OK) return rc;
+            if (num_rendered == GGR_HOST_FAULT_SPIN) return fail(GGR_E_HIP, "%s", kSpinFault);
+            if (num_rendered == GGR_HOST_FAULT_RANGE) return fail(GGR_E_LIMIT, "%s", kRangeFault);
+            if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
+            out->num_rendered = (int64_t)num_rendered;
+            if (num_rendered > capacity)
+                return fail(GGR_E_CAPACITY, "num_rendered %u exceeds the hinted capacity %u", num_rendered, capacity);
+        }
+    }
     tm.finish();
     return GGR_OK;
 }

@@ -138,6 +138,79 @@ def _check(rc: int, what: str):
         raise RuntimeError(f"{what} failed (code {rc}): {_lib.last_error()}")
 
 
+# ---- the default mode's list buffer, sized from what the same shape needed before --------------------------------
+# Upstream's forward reads num_rendered back in the middle, allocates the list buffer to that size and only then
+# launches the rest — the device idles for as long as the host takes (a slow or busy host: 0.96 instead of 0.88 ms per
+# 1080p frame on one box of the pool).  With a guess of the size — 1.25 × the largest num_rendered of the last calls of
+# the same (device, P, W, H, views) — everything is enqueued at once (GgrForwardOut.capacity_is_hint), the call still
+# returns the exact num_rendered, and a guess that was too small costs a repeat in upstream's order.  The guess is a
+# HINT: no result depends on it; `GGR_LIST_HINT=0` in the environment turns it off.
+_GGR_E_CAPACITY = 5
+_hint_lock = threading.Lock()
+_hints: dict = {}
+_HINTS_ON = __import__("os").environ.get("GGR_LIST_HINT", "1") != "0"
+
+
+def set_list_hint(enabled: bool) -> bool:
+    """Turns the list-size guess of the default mode on or off (process-wide); returns the previous setting.  Off, every
+    forward runs in upstream's order: read num_rendered back, allocate, launch the rest."""
+    global _HINTS_ON
+    with _hint_lock:
+        prev, _HINTS_ON = _HINTS_ON, bool(enabled)
+        if not enabled:
+            _hints.clear()
+    return prev
+
+
+def _capacity_guess(key) -> int:
+    if not _HINTS_ON:
+        return 0
+    with _hint_lock:
+        h = _hints.get(key)
+        return (int(1.25 * max(h)) + 4096) if h else 0
+
+
+def _note_rendered(key, n: int):
+    with _hint_lock:
+        if len(_hints) > 256 and key not in _hints:   # (shapes that keep changing: start over rather than grow)
+            _hints.clear()
+        h = _hints.setdefault(key, [])
+        h.append(int(n))
+        del h[:-8]
+
+
+def _forward_with_guess(call, fout, holder, lib, dev, W, H, key, user_capacity, profiling):
+    """Runs `call()` (the ggr_forward / ggr_forward_views invocation over `fout`): sync-free with the caller's
+    `list_capacity`, or exact — with a guessed list buffer when this shape has been seen, upstream's order otherwise and
+    after a guess that did not hold.  Returns what `last_forward_status` needs to know."""
+    if user_capacity > 0:  # sync-free mode: bring the list buffer, no read-back inside the call
+        holder["bin"] = torch.empty((lib.ggr_binning_bytes(user_capacity, W, H),), dtype=torch.uint8, device=dev)
+        fout.binning_buffer = holder["bin"].data_ptr()
+        fout.binning_capacity = user_capacity
+        _check(call(), "ggr_forward")
+        return
+    guess = 0 if profiling else _capacity_guess(key)   # (stage timing keeps upstream's order: the read-back is a stage)
+    if guess > 0:
+        holder["bin"] = torch.empty((lib.ggr_binning_bytes(guess, W, H),), dtype=torch.uint8, device=dev)
+        fout.binning_buffer = holder["bin"].data_ptr()
+        fout.binning_capacity = guess
+        fout.capacity_is_hint = 1
+        rc = call()
+        if rc != _GGR_E_CAPACITY:
+            _check(rc, "ggr_forward")
+            _note_rendered(key, int(fout.num_rendered))
+            return
+        # the guess did not hold: once more, in upstream's order (the buffers of the first attempt are released to the
+        # stream-ordered allocator: what is still running on them was enqueued before what follows)
+        _note_rendered(key, int(fout.num_rendered))
+        holder.clear()
+        fout.binning_buffer = None
+        fout.binning_capacity = 0
+        fout.capacity_is_hint = 0
+    _check(call(), "ggr_forward")
+    _note_rendered(key, int(fout.num_rendered))
+
+
 def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view, proj, campos) -> _lib.GgrSettings:
     tf = getattr(rs, "tanfov", None)
     if tf is not None and (tf.dtype != torch.float32 or not tf.is_contiguous() or (bg is not None and tf.device != bg.device)):
@@ -221,15 +294,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0,
                                       no_backward=int(infer), backward_scratch=_ptr(scratch))
             capacity = int(getattr(rs, "list_capacity", 0) or 0)
-            if capacity > 0:  # sync-free mode: bring the list buffer, no read-back inside ggr_forward
-                holder["bin"] = torch.empty((lib.ggr_binning_bytes(capacity, W, H),), dtype=torch.uint8, device=dev)
-                fout.binning_buffer = holder["bin"].data_ptr()
-                fout.binning_capacity = capacity
             prof = _current_profile()
             if prof is not None:
                 fout.stage_ms = C.cast(prof.fwd, C.c_void_p)
                 prof.fwd_calls += 1
-            _check(lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream), "ggr_forward")
+            _forward_with_guess(lambda: lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream),
+                                fout, holder, lib, dev, W, H, (dev.index, P, W, H, 1, getattr(rs, "scissor", None)),
+                                capacity, prof is not None)
 
         # exact mode: count known, nothing to keep.  Sync-free mode: count + flags live in the geometry buffer on the
         # device, so that (≈100 MB at P = 1 M) buffer stays referenced until this thread's next forward
@@ -398,17 +469,15 @@ class _RasterizeViews(torch.autograd.Function):
                                       geom_buffer=geom.data_ptr(), image_buffer=img.data_ptr(),
                                       binning_buffer=None, num_rendered=0, stage_ms=None, binning_capacity=0,
                                       no_backward=int(infer), backward_scratch=_ptr(scratch))
-            capacity = int(getattr(rs, "list_capacity", 0) or 0)
-            if capacity > 0:  # sync-free mode: the capacity covers the lists of ALL views
-                holder["bin"] = torch.empty((lib.ggr_binning_bytes(capacity, W, H),), dtype=torch.uint8, device=dev)
-                fout.binning_buffer = holder["bin"].data_ptr()
-                fout.binning_capacity = capacity
+            capacity = int(getattr(rs, "list_capacity", 0) or 0)   # (sync-free mode: the capacity covers the lists of ALL views)
             prof = _current_profile()
             if prof is not None:
                 fout.stage_ms = C.cast(prof.fwd, C.c_void_p)
                 prof.fwd_calls += 1
-            _check(lib.ggr_forward_views(C.byref(st), C.byref(vw), C.byref(fin), C.byref(fout), cb, None, stream),
-                   "ggr_forward_views")
+            _forward_with_guess(lambda: lib.ggr_forward_views(C.byref(st), C.byref(vw), C.byref(fin), C.byref(fout), cb,
+                                                              None, stream),
+                                fout, holder, lib, dev, W, H, (dev.index, P, W, H, V, getattr(rs, "scissor", None)),
+                                capacity, prof is not None)
         _tls.last_forward = (geom, P * V) if capacity > 0 else (None, int(fout.num_rendered))
         ctx.raster_settings = rs
         ctx.num_rendered = int(fout.num_rendered)

@@ -35,14 +35,16 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 6
+#define GGR_ABI_VERSION 7
 
 enum {
     GGR_OK = 0,
     GGR_E_INVALID = 1,   /* bad argument combination (e.g. both/neither of shs & colors_precomp) */
     GGR_E_HIP = 2,       /* a HIP runtime call or kernel launch failed */
     GGR_E_ALLOC = 3,     /* the allocator callback returned NULL */
-    GGR_E_LIMIT = 4      /* size beyond what the kernels index (P, N ≥ 2^31, > 2^24 tiles) */
+    GGR_E_LIMIT = 4,     /* size beyond what the kernels index (P, N ≥ 2^31, > 2^24 tiles) */
+    GGR_E_CAPACITY = 5   /* GgrForwardOut.capacity_is_hint: num_rendered exceeds the buffer that was brought along — the
+                            outputs of this call are void, repeat it in exact mode (or with a larger buffer) */
 };
 
 /* Mirrors the NamedTuple built at cuda_splatting.py:101-113 (field meaning identical). */
@@ -142,6 +144,13 @@ typedef struct GgrForwardOut {
                               ggr_backward: the forward clears it on the side (inside the forward blend kernel, whose
                               memory pipe is idle) and the backward, told so by GgrBackwardIn.scratch_zeroed, skips its own
                               64-byte-per-Gaussian memset.  NULL: the backward clears it itself. */
+    int32_t capacity_is_hint; /* IN, with binning_capacity > 0.  0: sync-free mode as described above.  1: EXACT mode with a
+                              guess — the caller expects num_rendered ≤ binning_capacity (e.g. 1.25 × the previous frame's) and
+                              brought a list buffer of that size: scatter and blend are enqueued behind the count WITHOUT
+                              waiting for it, then the call waits for num_rendered alone (the exact mode's early read-back;
+                              the device is busy with scatter and blend meanwhile) and returns it.  Fits: every output is what
+                              the exact mode gives, and the host's latency after the read-back — alloc, two launches — is off
+                              the device's critical path.  Does not fit: GGR_E_CAPACITY, outputs void. */
 } GgrForwardOut;
 
 /* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */

@@ -19,7 +19,7 @@ def test_library_builds_and_loads():
     path = _build.build_library()
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.ggr_abi_version() == 6
+    assert lib.ggr_abi_version() == 7
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -49,7 +49,7 @@ def test_struct_layouts_match_header_sizes():
     # 64-bit ABI: sizes follow from the field lists in include/ggr_raster.h
     assert ctypes.sizeof(_lib.GgrSettings) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4 + 8 + 4 + 4 * 4 + 4  # + sh_max_degree, scissor, reference_rects
     assert ctypes.sizeof(_lib.GgrForwardIn) == 9 * 8 + 3 * 4 + 2 * 4 + 4
-    assert ctypes.sizeof(_lib.GgrForwardOut) == 9 * 8 + 8 + 8  # + no_backward (padded) + backward_scratch
+    assert ctypes.sizeof(_lib.GgrForwardOut) == 9 * 8 + 8 + 8 + 8  # + no_backward (padded) + backward_scratch + capacity_is_hint (padded)
     assert ctypes.sizeof(_lib.GgrBackwardIn) == (9 * 8 + 3 * 4 + 2 * 4 + 4) + 8 * 8 + 8  # + scratch_zeroed, padded
     assert ctypes.sizeof(_lib.GgrBackwardOut) == 13 * 8
 

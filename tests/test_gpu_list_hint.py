@@ -1,0 +1,68 @@
+"""The default mode's list-size guess (rasterizer._forward_with_guess, GgrForwardOut.capacity_is_hint): a forward whose
+list buffer was sized from the previous call of the same shape returns what upstream's order returns — also when the
+guess was too small and the call is repeated — and the same num_rendered."""
+import pytest
+import torch
+
+import ggrt_official_amd
+from ggrt_official_amd import rasterizer as R
+from ggrt_official_amd.synthetic import make_scene, upstream_gradient
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+dev = "cuda:0"
+
+
+def _run(sc, dL, scale_modifier=1.0):
+    s = sc.to(dev)
+    leaves = [t.clone().requires_grad_() for t in (s.means3D, s.shs, s.opacities, s.cov3D)]
+    m, sh, op, cov = leaves
+    rs = s.settings()._replace(scale_modifier=scale_modifier)
+    color, radii, depth = ggrt_official_amd.GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros_like(m), opacities=op,
+                                                                   shs=sh, cov3D_precomp=cov)
+    n, _ = ggrt_official_amd.last_forward_status()
+    color.backward(dL.to(dev))
+    return color.detach().cpu(), radii.cpu(), depth.detach().cpu(), [t.grad.cpu() for t in leaves], n
+
+
+def _same(a, b):
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[4] == b[4]
+    for x, y in zip(a[3], b[3]):
+        assert rel_l2(x.numpy(), y.numpy()) < 2e-5
+
+
+def test_guessed_buffer_gives_the_exact_modes_results():
+    P, W, H = 60_000, 400, 304
+    sc = make_scene(P, W, H, sh_degree=2, profile="A", seed=4)
+    dL = upstream_gradient(W, H, seed=9)
+    prev = ggrt_official_amd.set_list_hint(False)
+    try:
+        want = _run(sc, dL)                      # upstream's order
+        ggrt_official_amd.set_list_hint(True)
+        first = _run(sc, dL)                     # nothing known about this shape yet: upstream's order, notes N
+        key = (0, P, W, H, 1, None)
+        assert R._capacity_guess(key) >= want[4]
+        second = _run(sc, dL)                    # guessed buffer
+        _same(want, first)
+        _same(want, second)
+    finally:
+        ggrt_official_amd.set_list_hint(prev)
+
+
+def test_a_guess_that_is_too_small_repeats_the_call():
+    P, W, H = 50_000, 320, 240
+    small = make_scene(P, W, H, sh_degree=1, profile="B", seed=6)      # small splats: few list entries
+    big = make_scene(P, W, H, sh_degree=1, profile="A", seed=7)        # same shape, several times the entries
+    dL = upstream_gradient(W, H, seed=3)
+    prev = ggrt_official_amd.set_list_hint(False)
+    try:
+        want_small, want_big = _run(small, dL), _run(big, dL)
+        assert want_big[4] > 1.5 * want_small[4]
+        ggrt_official_amd.set_list_hint(True)
+        _same(want_small, _run(small, dL))       # notes the small N
+        got_big = _run(big, dL)                  # guess too small → GGR_E_CAPACITY inside → repeated in upstream's order
+        _same(want_big, got_big)
+        _same(want_big, _run(big, dL))           # now guessed from the big N
+        _same(want_small, _run(small, dL))       # (an over-sized buffer is fine)
+    finally:
+        ggrt_official_amd.set_list_hint(prev)
