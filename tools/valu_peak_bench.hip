@@ -16,15 +16,16 @@
 #define ITERS 32768
 #define CHAINS 8
 
-enum { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERM32, PERM16, PK_FMA, FMA_DEP, MIX_BLEND, CMP_VCC, CNDMASK_VCC, CMP_CND, CMP_SGPR_CND, MIN_LIT, MOV, NMODES };
+enum { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERM32, PERM16, PK_FMA, FMA_DEP, MIX_BLEND, CMP_VCC, CNDMASK_VCC, CMP_CND, CMP_SGPR_CND, MIN_LIT, MOV, MUL_LO, MUL_U24, MAD_U64, LSHL_ADD_U64, MED3, NMODES };
 static const char* kNames[NMODES] = {"v_fma_f32 (8 indep chains)", "v_mul_f32 + v_add_f32", "v_exp_f32",
                                      "v_rcp_f32", "v_add_f32_dpp quad_perm", "v_permlane32_swap",
                                      "v_permlane16_swap", "v_pk_fma_f32 (2 flop-pairs/inst)",
                                      "v_fma_f32 (ONE dependent chain)", "blend-like mix: 6 fma + exp + rcp",
                                      "v_cmp_lt_f32 -> vcc", "v_cndmask_b32 (vcc)", "v_cmp (vcc) + v_cndmask (vcc)",
-                                     "v_cmp_e64 -> sgpr pair + v_cndmask_e64", "v_min_f32 with a literal", "v_mov_b32"};
+                                     "v_cmp_e64 -> sgpr pair + v_cndmask_e64", "v_min_f32 with a literal", "v_mov_b32",
+                                     "v_mul_lo_u32", "v_mul_u32_u24", "v_mad_u64_u32", "v_lshl_add_u64", "v_med3_f32"};
 // VALU instructions issued per chain per iteration
-static const int kInstPerChainIter[NMODES] = {1, 2, 1, 1, 1, 1, 1, 1, 1, 8, 1, 1, 2, 2, 1, 1};
+static const int kInstPerChainIter[NMODES] = {1, 2, 1, 1, 1, 1, 1, 1, 1, 8, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1};
 
 template <int MODE>
 __global__ void __launch_bounds__(256) k(float* out, int iters) {
@@ -62,6 +63,11 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
             }
             if (MODE == MIN_LIT) asm volatile("v_min_f32 %0, 0x3f7d70a4, %0" : "+v"(v[c]));
             if (MODE == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(v[c]) : "v"(w[c]));
+            if (MODE == MUL_LO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
+            if (MODE == MUL_U24) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
+            if (MODE == MAD_U64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(pv[c]) : "v"(v[c]), "v"(w[c]) : "vcc");
+            if (MODE == LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 2, %0" : "+v"(pv[c]));
+            if (MODE == MED3) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(v[c]) : "v"(w[c]));
             if (MODE == MIX_BLEND) {  // the shape of one (entry, pixel) evaluation: geometry fmas, exp, rcp, recurrences
                 float t;
                 asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(t) : "v"(v[c]), "v"(w[c]));
@@ -141,6 +147,6 @@ int main(int argc, char** argv) {
     const int ws[] = {1, 2, 4, 8};
 #define SWEEP(M) for (int w : ws) run<M>(out, w, clk, cus);
     SWEEP(FMA) SWEEP(MUL_ADD) SWEEP(EXP) SWEEP(RCP) SWEEP(DPP_ADD) SWEEP(PERM32) SWEEP(PERM16) SWEEP(PK_FMA)
-    SWEEP(FMA_DEP) SWEEP(MIX_BLEND) SWEEP(CMP_VCC) SWEEP(CNDMASK_VCC) SWEEP(CMP_CND) SWEEP(CMP_SGPR_CND) SWEEP(MIN_LIT) SWEEP(MOV)
+    SWEEP(FMA_DEP) SWEEP(MIX_BLEND) SWEEP(CMP_VCC) SWEEP(CNDMASK_VCC) SWEEP(CMP_CND) SWEEP(CMP_SGPR_CND) SWEEP(MIN_LIT) SWEEP(MOV) SWEEP(MUL_LO) SWEEP(MUL_U24) SWEEP(MAD_U64) SWEEP(LSHL_ADD_U64) SWEEP(MED3)
     return 0;
 }
