@@ -162,6 +162,11 @@ def set_list_hint(enabled: bool) -> bool:
     return prev
 
 
+def _scissor_key(rs):
+    sc = getattr(rs, "scissor", None)
+    return tuple(int(v) for v in sc) if sc else None
+
+
 def _capacity_guess(key) -> int:
     if not _HINTS_ON:
         return 0
@@ -299,7 +304,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 fout.stage_ms = C.cast(prof.fwd, C.c_void_p)
                 prof.fwd_calls += 1
             _forward_with_guess(lambda: lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream),
-                                fout, holder, lib, dev, W, H, (dev.index, P, W, H, 1, getattr(rs, "scissor", None)),
+                                fout, holder, lib, dev, W, H, (dev.index, P, W, H, 1, _scissor_key(rs)),
                                 capacity, prof is not None)
 
         # exact mode: count known, nothing to keep.  Sync-free mode: count + flags live in the geometry buffer on the
@@ -476,7 +481,7 @@ class _RasterizeViews(torch.autograd.Function):
                 prof.fwd_calls += 1
             _forward_with_guess(lambda: lib.ggr_forward_views(C.byref(st), C.byref(vw), C.byref(fin), C.byref(fout), cb,
                                                               None, stream),
-                                fout, holder, lib, dev, W, H, (dev.index, P, W, H, V, getattr(rs, "scissor", None)),
+                                fout, holder, lib, dev, W, H, (dev.index, P, W, H, V, _scissor_key(rs)),
                                 capacity, prof is not None)
         _tls.last_forward = (geom, P * V) if capacity > 0 else (None, int(fout.num_rendered))
         ctx.raster_settings = rs
