@@ -21,8 +21,8 @@ namespace ggr {
 
 #define BATCH GGR_BATCH
 #ifndef SURV_GROUP
-#define SURV_GROUP 4   // survivors per trip of the blend loop (one broadcast read of their offsets; measured at C3, 2 / 4 / 8:
-                       // 189 / 187 / 218 µs — at 8 the compiler keeps all eight records live: 120 VGPRs)
+#define SURV_GROUP 4   // survivors per trip of the blend loop (one broadcast read of their offsets; measured, 2 / 4 / 8:
+                       // C3 150 / 150 / 176 µs, C5′ 195 / 173 / 173 — at 8 the compiler keeps all eight records live)
 #endif
 
 __global__ void __launch_bounds__(256)
