@@ -5,9 +5,12 @@ hipcc cross-compiles for gfx950 without a GPU, so this runs in the build contain
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -30,27 +33,70 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 with gfx950 support)")
 
 
+HASH_MARKER = b"ggr-source-hash:"   # followed by 64 hex digits inside the .so (api.hip, ggr_source_hash())
+
+# what the last build_library() call of this process did: {"compiled": bool, "source_hash": str, "seconds": float}
+last_build: dict = {}
+
+
+def source_hash() -> str:
+    """sha256 over every translation unit and header of the library (name + contents) and the compiler flags.  The
+    library carries the hash it was built from (``ggr_source_hash()``); ``_lib.load()`` refuses a library whose hash
+    differs from ``csrc/`` as it is now — a stale ``.so`` can neither pass for a build nor be measured by accident."""
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        h.update(os.path.basename(name).encode() + b"\0")
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS).encode())
+    for k in sorted(EXTRA_FLAGS):
+        h.update((k + " " + " ".join(EXTRA_FLAGS[k])).encode())
+    return h.hexdigest()
+
+
+def embedded_hash(path: str = None):
+    """The source hash a built library carries, read from the file's bytes (no dlopen); None if absent."""
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        blob = f.read()
+    i = blob.find(HASH_MARKER)
+    if i < 0:
+        return None
+    hx = blob[i + len(HASH_MARKER): i + len(HASH_MARKER) + 64]
+    try:
+        return hx.decode("ascii") if len(hx) == 64 and int(hx, 16) >= 0 else None
+    except ValueError:
+        return None
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return embedded_hash() != source_hash()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+    """Compiles csrc/*.hip for gfx950 and links ``libggr_raster.so`` unless the library in the tree was built from
+    exactly these sources (its embedded hash equals ``source_hash()``) — `force` compiles regardless.  Objects go
+    to a fresh temporary directory (no stale ``.o`` can be linked); ``last_build`` records what happened."""
+    want = source_hash()
+    if not force and embedded_hash() == want:
+        last_build.clear()
+        last_build.update(compiled=False, source_hash=want, seconds=0.0)
         return LIB
+    t0 = time.time()
     hipcc = _hipcc()
     extra_env = os.environ.get("GGR_EXTRA_HIPCC_FLAGS", "").split()  # dev experiments only (e.g. -DGGR_XCD_SPLIT=4)
-    objdir = os.path.join(CSRC, "build")
-    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    objdir = tempfile.mkdtemp(prefix="ggr_build_", dir=os.path.join(CSRC, "build"))  # (same filesystem as LIB: os.replace)
     procs = []
     objs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *extra_env, "-c", os.path.join(CSRC, src), "-o", obj]
+        stamp = [f'-DGGR_SOURCE_HASH="{want}"'] if src == "api.hip" else []
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *extra_env, *stamp, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -60,12 +106,20 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    tmp_lib = os.path.join(objdir, "libggr_raster.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp_lib]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if out.returncode != 0:
         raise RuntimeError(f"link failed:\n{out.stdout}")
+    if embedded_hash(tmp_lib) != want:
+        raise RuntimeError("the linked library does not carry the source hash it was built with")
+    os.replace(tmp_lib, LIB)   # (atomic: a process that has the old library mapped keeps its inode)
+    shutil.rmtree(objdir, ignore_errors=True)
+    last_build.clear()
+    last_build.update(compiled=True, source_hash=want, seconds=round(time.time() - t0, 1))
     return LIB
 
 
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(last_build)

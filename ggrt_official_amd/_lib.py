@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libggr_raster.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -78,6 +78,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 SYMBOLS = [
     ("ggr_abi_version", C.c_int, []),
     ("ggr_last_error", C.c_char_p, []),
+    ("ggr_source_hash", C.c_char_p, []),
     ("ggr_geom_bytes", C.c_size_t, [C.c_int32]),
     ("ggr_image_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
     ("ggr_binning_bytes", C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
@@ -129,6 +130,15 @@ def load():
     v = lib.ggr_abi_version()
     if v != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {v}, binding expects {ABI_VERSION}")
+    # the library must have been built from the csrc/ tree next to it (a stale .so would otherwise be what gets tested
+    # and measured).  GGR_SKIP_SOURCE_HASH=1: dev builds only (scripts/build_variants.sh ships several libraries).
+    if os.environ.get("GGR_SKIP_SOURCE_HASH", "0") != "1":
+        from . import _build
+        built, want = lib.ggr_source_hash().decode("ascii", "replace"), _build.source_hash()
+        if built != want:
+            raise ImportError(
+                f"{LIB_PATH} was built from other sources than {_build.CSRC} holds now (library {built[:12]}…, tree "
+                f"{want[:12]}…): run `python __graft_entry__.py build`. There is no CPU fallback.")
     _lib = lib
     return lib
 

@@ -199,6 +199,15 @@ int view_set(const GgrSettings* st, const GgrViews* v, ViewSet* vs) {
 extern "C" {
 
 int ggr_abi_version(void) { return GGR_ABI_VERSION; }
+// the sha256 of the sources this library was compiled from (ggrt_official_amd/_build.py source_hash(): the build passes
+// it as -DGGR_SOURCE_HASH).  The marker in front lets the build read it from the file's bytes without loading it.
+#ifndef GGR_SOURCE_HASH
+#define GGR_SOURCE_HASH "0000000000000000000000000000000000000000000000000000000000000000"
+#endif
+const char* ggr_source_hash(void) {
+    static const char tagged[] = "ggr-source-hash:" GGR_SOURCE_HASH;
+    return tagged + 16;
+}
 const char* ggr_last_error(void) { return g_err; }
 
 size_t ggr_geom_bytes(int32_t P) { return ggr_carve_geom(nullptr, (size_t)(P > 0 ? P : 0)).bytes; }

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 7
+#define GGR_ABI_VERSION 8
 
 enum {
     GGR_OK = 0,
@@ -204,6 +204,10 @@ typedef struct GgrBackwardOut {
 } GgrBackwardOut;
 
 int ggr_abi_version(void);
+/* ABI 8: sha256 (64 hex digits) of the kernel sources + compiler flags this library was built from.  The Python
+ * binding compares it with the csrc/ tree next to it and refuses a library built from anything else (a stale .so can
+ * neither pass for a build nor be measured by accident).  No counterpart in the reference's extension. */
+const char* ggr_source_hash(void);
 const char* ggr_last_error(void);
 
 size_t ggr_geom_bytes(int32_t num_points);

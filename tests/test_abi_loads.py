@@ -19,7 +19,43 @@ def test_library_builds_and_loads():
     path = _build.build_library()
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.ggr_abi_version() == 7
+    assert lib.ggr_abi_version() == 8
+    assert lib.ggr_source_hash().decode() == _build.source_hash() == _build.embedded_hash()
+
+
+def test_build_is_evidence(tmp_path):
+    """`__graft_entry__.build()` must COMPILE — with the library deleted from the tree it has to come
+    back, carrying the hash of the sources as they are now; and a library built from other sources is refused on load."""
+    import importlib
+    import subprocess
+    import sys
+    # in a child process: this one may have the library mapped already
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from ggrt_official_amd import _build\n"
+            "os.remove(_build.LIB) if os.path.exists(_build.LIB) else None\n"
+            "import __graft_entry__ as g; g.build()\n"
+            "assert _build.last_build['compiled'] and os.path.exists(_build.LIB)\n"
+            "from ggrt_official_amd import _lib\n"
+            "assert _lib.load().ggr_source_hash().decode() == _build.source_hash()\n"
+            "print('REBUILT', _build.last_build['seconds'])\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "REBUILT" in out.stdout, out.stdout + out.stderr
+    assert "compiled=True" in out.stdout
+    # an up-to-date tree is NOT recompiled by build_library() (only build() forces) …
+    _build.build_library()
+    assert _build.last_build["compiled"] is False
+    # … and a library that carries another hash is refused (a copy with one hex digit of the stamp changed)
+    blob = bytearray(open(_build.LIB, "rb").read())
+    i = blob.find(_build.HASH_MARKER) + len(_build.HASH_MARKER)
+    blob[i] = ord("0") if blob[i] != ord("0") else ord("1")
+    fake = tmp_path / "libggr_raster.so"
+    fake.write_bytes(bytes(blob))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from ggrt_official_amd import _lib\n"
+            "_lib.LIB_PATH = %r\n"
+            "try:\n    _lib.load()\nexcept ImportError as e:\n    print('REFUSED', e)\n") % (ROOT, str(fake))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "REFUSED" in out.stdout and "built from other sources" in out.stdout, out.stdout + out.stderr
 
 
 def test_every_declared_symbol_is_exported_and_bound():
