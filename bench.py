@@ -162,7 +162,7 @@ class Workload:
     def rooflines(self, stages: dict, N: int, N_built: int = None) -> dict:
         D = self.cfg["sh_degree"]
         M = self.sc.shs.shape[1]
-        deg = min(D, int(getattr(self.rs, "sh_max_degree", 3) or 3))
+        deg = min(D, int(getattr(self.rs, "sh_max_degree", 0) or 3))
         while (deg + 1) ** 2 > M:
             deg -= 1
         K = (deg + 1) ** 2

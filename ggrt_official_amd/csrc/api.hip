@@ -9,6 +9,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -81,8 +82,11 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
         return fail(GGR_E_INVALID, "sh_stride %d too small for sh_degree %d", st->sh_stride, st->sh_degree);
     const int64_t tiles = (int64_t)((st->image_width + GGR_TILE - 1) / GGR_TILE) * ((st->image_height + GGR_TILE - 1) / GGR_TILE);
     if (tiles > (1 << 24)) return fail(GGR_E_LIMIT, "image has %lld tiles; at most 2^24 supported", (long long)tiles);
-    if (st->image_width > 768 * GGR_TILE || st->image_height > 65535 * GGR_TILE)  // (a tile row must fit a count wave's slots)
-        return fail(GGR_E_LIMIT, "image too large");
+    if (st->image_width > GGR_MAX_WIDTH_TILES * GGR_TILE)  // (a tile row must fit a count wave's slots: tile_lists.hip)
+        return fail(GGR_E_LIMIT, "image width %d exceeds %d px (%d tiles of %d px: the tile-count kernel's row limit)",
+                    st->image_width, GGR_MAX_WIDTH_TILES * GGR_TILE, GGR_MAX_WIDTH_TILES, GGR_TILE);
+    if (st->image_height > 65535 * GGR_TILE)
+        return fail(GGR_E_LIMIT, "image height %d exceeds %d px (65535 tile rows)", st->image_height, 65535 * GGR_TILE);
     return GGR_OK;
 }
 
@@ -92,7 +96,8 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
 #define GGR_READBACK_ARMED GGR_HOST_ARMED  // (counts stop at 0x7FFFFFFF; GGR_HOST_FAULT_* report a sort fault)
 struct ReadbackSlot {
     uint32_t* host = nullptr;
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr;        // behind the kernel that writes the word
+    hipEvent_t ev_start = nullptr;  // in front of the tile-list kernels: the wait's time bound starts here
 };
 ReadbackSlot* readback_slot() {
     static thread_local ReadbackSlot slots[32];
@@ -105,6 +110,9 @@ ReadbackSlot* readback_slot() {
         // host while the kernel is still running; a non-coherent mapping would only show it at the kernel's end
         if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); return nullptr; }
+        if (hipEventCreateWithFlags(&r.ev_start, hipEventDisableTiming) != hipSuccess) {
+            (void)hipEventDestroy(r.ev); r.ev = nullptr; (void)hipHostFree(p); return nullptr;
+        }
         r.host = (uint32_t*)p;
     }
     return &r;
@@ -115,12 +123,23 @@ ReadbackSlot* readback_slot() {
 // kernel has ended.  Leaves on: the word changed; the query says "done" (the word is then re-read once — a
 // non-coherent mapping shows it only now); the query returns ANYTHING other than hipErrorNotReady (stream in error,
 // device lost: the word will never change) → GGR_E_HIP; or `timeout_s` seconds without either (a hung GPU) →
-// GGR_E_HIP.  The device-side spins are bounded the same way — nothing in a forward can wait forever.
+// GGR_E_HIP.  The clock of that bound only starts once `query_start` (the event recorded on the stream right IN FRONT
+// of the tile-list kernels, or NULL: at once) reports completion: work that was queued on the stream ahead of this
+// forward — a long evaluation queue, a device shared with another process — is not this forward's hang.
+// The bound itself is GGR_READBACK_TIMEOUT_S seconds (environment, default 30; ≤ 0 = wait for as long as the event
+// query keeps answering "not ready").  The device-side spins are bounded the same way — nothing in a forward can wait
+// forever on a GPU that makes progress.
 typedef hipError_t (*ReadbackQueryFn)(void*);
-#define GGR_READBACK_TIMEOUT_S 30.0
-int wait_readback(volatile uint32_t* hw, ReadbackQueryFn query, void* ctx, double timeout_s, uint32_t* value) {
+double readback_timeout_s() {
+    const char* e = getenv("GGR_READBACK_TIMEOUT_S");
+    if (e && *e) { char* end = nullptr; const double v = strtod(e, &end); if (end != e) return v; }
+    return 30.0;
+}
+int wait_readback(volatile uint32_t* hw, ReadbackQueryFn query, void* ctx, double timeout_s, uint32_t* value,
+                  ReadbackQueryFn query_start = nullptr, void* ctx_start = nullptr) {
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    bool started = query_start == nullptr;
     uint32_t v = *hw;
     for (uint32_t spins = 0; v == GGR_READBACK_ARMED; v = *hw) {
         if ((++spins & 0x3FFu) == 0) {
@@ -128,10 +147,18 @@ int wait_readback(volatile uint32_t* hw, ReadbackQueryFn query, void* ctx, doubl
             if (q == hipSuccess) { v = *hw; break; }
             if (q != hipErrorNotReady)
                 return fail(GGR_E_HIP, "num_rendered read-back: the stream is in error (%s); frame not rendered", hipGetErrorString(q));
+            if (!started) {   // still behind earlier work of the stream: the bound does not run yet
+                const hipError_t qs = query_start(ctx_start);
+                if (qs == hipSuccess) { started = true; clock_gettime(CLOCK_MONOTONIC, &t0); }
+                else if (qs != hipErrorNotReady)
+                    return fail(GGR_E_HIP, "num_rendered read-back: the stream is in error (%s); frame not rendered", hipGetErrorString(qs));
+                continue;
+            }
             timespec t1;
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s)
-                return fail(GGR_E_HIP, "num_rendered read-back: no answer from the GPU within %.0f s; frame not rendered", timeout_s);
+            if (timeout_s > 0.0 && (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s)
+                return fail(GGR_E_HIP, "num_rendered read-back: no answer from the GPU within %.0f s of the tile-list kernels' turn "
+                                       "(GGR_READBACK_TIMEOUT_S); frame not rendered", timeout_s);
         }
         __builtin_ia32_pause();
     }
@@ -280,7 +307,10 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // buffer allocated and the scatter queued by the time the GPU gets there (a device→host memcpy into pageable
     // memory + stream sync left the GPU idle for that long)
     ReadbackSlot* rb = ((!sync_free || hinted) && P > 0) ? readback_slot() : nullptr;
-    if (rb) *(volatile uint32_t*)rb->host = GGR_READBACK_ARMED;
+    if (rb) {
+        *(volatile uint32_t*)rb->host = GGR_READBACK_ARMED;
+        (void)hipEventRecord(rb->ev_start, s);
+    }
     if (P > 0) {
         ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, capacity, s,
                                     /*rects_gathered=*/true, rb ? rb->host : nullptr, rb ? rb->ev : nullptr,
@@ -302,7 +332,8 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         if (rb) {
             // the single host sync of forward.  N is written by the FIRST block of the last tile-list kernel: the host
             // watches the pinned word instead of waiting for that kernel's end (wait_readback above)
-            const int rc = wait_readback((volatile uint32_t*)rb->host, query_event, (void*)rb->ev, GGR_READBACK_TIMEOUT_S, &num_rendered);
+            const int rc = wait_readback((volatile uint32_t*)rb->host, query_event, (void*)rb->ev, readback_timeout_s(), &num_rendered,
+                                         query_event, (void*)rb->ev_start);
             if (rc != GGR_OK) return rc;
         } else {
             uint32_t two[2] = {0u, 0u};
@@ -345,15 +376,21 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     if (hinted) {   // num_rendered, while the device works on scatter and blend; the guess must have held
         out->num_rendered = 0;
         if (rb) {
-            const int rc = wait_readback((volatile uint32_t*)rb->host, query_event, (void*)rb->ev, GGR_READBACK_TIMEOUT_S, &num_rendered);
+            const int rc = wait_readback((volatile uint32_t*)rb->host, query_event, (void*)rb->ev, readback_timeout_s(), &num_rendered,
+                                         query_event, (void*)rb->ev_start);
             if (rc != GGR_OK) return rc;
-            if (num_rendered == GGR_HOST_FAULT_SPIN) return fail(GGR_E_HIP, "%s", kSpinFault);
-            if (num_rendered == GGR_HOST_FAULT_RANGE) return fail(GGR_E_LIMIT, "%s", kRangeFault);
-            if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
-            out->num_rendered = (int64_t)num_rendered;
-            if (num_rendered > capacity)
-                return fail(GGR_E_CAPACITY, "num_rendered %u exceeds the hinted capacity %u", num_rendered, capacity);
+        } else if (P > 0) {   // no pinned slot (hipHostMalloc / hipEventCreate failed): copy + sync, like the exact mode —
+            uint32_t two[2] = {0u, 0u};   // a hinted frame is never returned unchecked
+            HIP_TRY(hipMemcpyAsync(two, g.counters, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            num_rendered = (two[1] & 2u) ? GGR_HOST_FAULT_SPIN : (two[1] & 4u) ? GGR_HOST_FAULT_RANGE : two[0];
         }
+        if (num_rendered == GGR_HOST_FAULT_SPIN) return fail(GGR_E_HIP, "%s", kSpinFault);
+        if (num_rendered == GGR_HOST_FAULT_RANGE) return fail(GGR_E_LIMIT, "%s", kRangeFault);
+        if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
+        out->num_rendered = (int64_t)num_rendered;
+        if (num_rendered > capacity)
+            return fail(GGR_E_CAPACITY, "num_rendered %u exceeds the hinted capacity %u", num_rendered, capacity);
     }
     tm.finish();
     return GGR_OK;
@@ -498,7 +535,7 @@ int ggr_forward_status(const void* geom_buffer, int32_t P, int64_t* num_rendered
 }
 
 namespace {
-struct FakeQuery { int scenario; int calls; volatile uint32_t* word; };
+struct FakeQuery { int scenario; int calls; volatile uint32_t* word; timespec t0; double late_s; };
 hipError_t fake_query(void* p) {
     FakeQuery* q = (FakeQuery*)p;
     q->calls++;
@@ -506,16 +543,30 @@ hipError_t fake_query(void* p) {
         case 0: if (q->calls == 3) *q->word = 1234u; return hipErrorNotReady;
         case 1: return q->calls < 2 ? hipErrorNotReady : hipErrorLaunchFailure;
         case 2: return hipErrorNotReady;
+        case 4: return hipErrorNotReady;   // (the word arrives through fake_start, below)
         default: return hipSuccess;
     }
+}
+// scenario 4: the stream is busy with EARLIER work for `late_s` seconds (longer than the time bound), then the
+// tile-list kernels get their turn and the word arrives a few polls later — must succeed
+hipError_t fake_start(void* p) {
+    FakeQuery* q = (FakeQuery*)p;
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double dt = (double)(t1.tv_sec - q->t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - q->t0.tv_nsec);
+    if (dt < q->late_s) return hipErrorNotReady;
+    *q->word = 4321u;
+    return hipSuccess;
 }
 }  // namespace
 
 int ggr_debug_readback_wait(int32_t scenario, double timeout_s, uint32_t* value) {
     g_err[0] = 0;
-    if (scenario < 0 || scenario > 3 || !value) return fail(GGR_E_INVALID, "bad arguments");
+    if (scenario < 0 || scenario > 4 || !value) return fail(GGR_E_INVALID, "bad arguments");
     volatile uint32_t word = GGR_READBACK_ARMED;
-    FakeQuery q{scenario, 0, &word};
+    FakeQuery q{scenario, 0, &word, {}, 3.0 * timeout_s};
+    clock_gettime(CLOCK_MONOTONIC, &q.t0);
+    if (scenario == 4) return wait_readback(&word, fake_query, &q, timeout_s, value, fake_start, &q);
     return wait_readback(&word, fake_query, &q, timeout_s, value);
 }
 

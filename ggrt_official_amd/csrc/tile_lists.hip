@@ -71,7 +71,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 //   table[c][t]  = entries of the workgroup's EARLIER chunks in tile t        (exclusive prefix inside the workgroup)
 //   wsum[w][t]   = entries of all its chunks                                  (K2 turns it into the absolute base)
 // so that K2 sweeps the 8 MB of wsum instead of the 32 MB table (round 2: 27 + 8 + 15.5 µs → 21 + 5.4 + 11.9 µs at C3).
-#define GGR_COUNT_SLOTS 12  // (row, 64-tile piece) pairs per wave: bounds the band, = registers for the running counts
+// GGR_COUNT_SLOTS (ggr_common.h) = (row, 64-tile piece) pairs per wave: bounds the band, = registers for the running counts
 __global__ void __launch_bounds__(256)
 bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, uint32_t T, uint32_t grid_x,
                  uint32_t rows_total, uint32_t band_rows, uint32_t nchunks, uint32_t* __restrict__ table,
@@ -502,7 +502,12 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     // 245 workgroups of 4 chunks × 4 bands of 17 rows.
     const uint32_t gx = (uint32_t)grid_x, rows = (uint32_t)(T / gx);
     const uint32_t pieces = (gx + 63u) / 64u;
-    const uint32_t max_rows = 4u * (GGR_COUNT_SLOTS / pieces);  // (pieces ≤ GGR_COUNT_SLOTS: image width ≤ 768 tiles, api.hip)
+    if (pieces > GGR_COUNT_SLOTS) {   // image wider than GGR_MAX_WIDTH_TILES: api.hip's validate() refuses it (GGR_E_LIMIT);
+        (void)hipMemsetAsync(total_out, 0, 8, s);            // reached by any other route: an empty frame, never a
+        (void)hipMemsetAsync(ranges, 0, T * sizeof(uint2), s);  // division by zero below
+        return;
+    }
+    const uint32_t max_rows = 4u * (GGR_COUNT_SLOTS / pieces);
     uint32_t nbands = (rows + max_rows - 1) / max_rows;
     const uint32_t want = (1000u + pl.nw - 1) / pl.nw;
     if (nbands < want) nbands = want < rows ? want : rows;

@@ -84,6 +84,10 @@ class ChunkedMeanAllReduce:
             return
         use_avg = dist.get_backend() == "nccl"
         n = flat.numel()
+        if n == 0:   # (an empty buffer still takes part in the collective sequence: every rank issues the same calls)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, async_op=True)
+            self.pending.append((work, None))
+            return
         step = (n + self.chunks - 1) // self.chunks
         for lo in range(0, n, step):
             part = flat[lo:lo + step]

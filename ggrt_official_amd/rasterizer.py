@@ -63,10 +63,12 @@ class GaussianRasterizationSettings(NamedTuple):
     reference_rects: bool = False    # False: tight tile rects (a Gaussian is listed only where its α ≥ 1/255 ellipse can reach:
     #                         same outputs bit for bit, shorter internal lists); True: the reference's rects — lists identical
     #                         to the reference's, entry for entry
-    sh_max_degree: int = 3  # highest SH band evaluated.  3 (default): graphdeco and its w-depth forks — the family the
-    #                         live call site's signature belongs to (3-tuple return, no `debug`: cuda_splatting.py:101-118)
-    #                         — ignore coefficients 16.. (zero gradient); 4: the nine degree-4 terms are evaluated when
-    #                         sh_degree >= 4 with >= 25 coefficients
+    sh_max_degree: int = 0  # highest SH band evaluated — an EXPLICIT choice where it matters.
+    #                         3: graphdeco and its w-depth forks — the family the live call site's signature belongs to
+    #                         (3-tuple return, no `debug`: cuda_splatting.py:101-118) — ignore coefficients 16.. (zero
+    #                         gradient); 4: the nine degree-4 terms are evaluated when sh_degree >= 4 with >= 25
+    #                         coefficients.  0 = not chosen (also settable process-wide: GGR_SH_MAX_DEGREE=3|4): bands
+    #                         0..3, and the first call that thereby leaves coefficients 16.. unused warns once
 
 
 class StageProfile:
@@ -216,6 +218,33 @@ def _forward_with_guess(call, fout, holder, lib, dev, W, H, key, user_capacity, 
     _note_rendered(key, int(fout.num_rendered))
 
 
+_sh_warned = False
+
+
+def _sh_cap(rs, M: int) -> int:
+    """GgrSettings.sh_max_degree for this call: the settings' explicit 3 / 4, else GGR_SH_MAX_DEGREE, else 0 (= bands
+    0..3) — and ONE warning per process when that undecided default leaves coefficients unused (GGRt passes
+    sh_degree 4 with 25 coefficients per channel; what the replaced extension does with band 4 is not verifiable from
+    the reference tree)."""
+    global _sh_warned
+    cap = int(getattr(rs, "sh_max_degree", 0) or 0)
+    if cap == 0:
+        cap = int(__import__("os").environ.get("GGR_SH_MAX_DEGREE", "0") or 0)
+    if cap not in (0, 3, 4):
+        raise RuntimeError("sh_max_degree must be 3 or 4 (0 = not chosen)")
+    if cap == 0 and not _sh_warned and int(rs.sh_degree) >= 4 and M >= 25:
+        _sh_warned = True
+        import warnings
+        warnings.warn(
+            "ggrt_official_amd: sh_degree >= 4 with >= 25 SH coefficients per channel, and sh_max_degree was not chosen: "
+            "bands 0..3 are evaluated, coefficients 16.. are ignored and get zero gradient (the behaviour of the "
+            "rasterizer family GGRt's live call site is written against).  If the extension you are replacing evaluates "
+            "band 4, pass sh_max_degree=4 (GaussianRasterizationSettings / DecoderSplattingCUDA / GGR_SH_MAX_DEGREE=4); "
+            "pass 3 to keep this behaviour silently.  See INTEGRATION.md §7 and scripts/export_upstream_goldens.py.",
+            UserWarning, stacklevel=3)
+    return cap
+
+
 def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view, proj, campos) -> _lib.GgrSettings:
     tf = getattr(rs, "tanfov", None)
     if tf is not None and (tf.dtype != torch.float32 or not tf.is_contiguous() or (bg is not None and tf.device != bg.device)):
@@ -225,7 +254,7 @@ def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view
         sh_stride=int(M), num_points=int(P), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
         scale_modifier=float(rs.scale_modifier), bg=_ptr(bg), viewmatrix=_ptr(view), projmatrix=_ptr(proj),
         campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfov_dev=_ptr(tf),
-        sh_max_degree=int(getattr(rs, "sh_max_degree", 3) or 3),
+        sh_max_degree=_sh_cap(rs, int(M)),
         scissor=(C.c_int32 * 4)(*[int(v) for v in (getattr(rs, "scissor", None) or (0, 0, 0, 0))]),
         reference_rects=int(bool(getattr(rs, "reference_rects", False))))
 

@@ -15,7 +15,9 @@ Reference quirks kept on purpose (drop-in parity):
   * the depth pass feeds depth as a degree-0 SH coefficient, so the rasterizer returns
     ``0.5 + C0·z`` per channel and the result is the channel mean (:256-269);
   * ``sh_degree = isqrt(d_sh) - 1`` (GGRt: d_sh = 25 → 4); bands 0..min(sh_degree, ``SH_MAX_DEGREE``) are
-    evaluated — ``SH_MAX_DEGREE`` = 3 by default, 4 on request.
+    evaluated — ``SH_MAX_DEGREE`` (``set_sh_max_degree`` / ``DecoderSplattingCUDA(sh_max_degree=…)`` /
+    ``GGR_SH_MAX_DEGREE``) is an explicit choice of 3 or 4; left at 0 it means 3 and the rasterizer warns once
+    (INTEGRATION.md §7).
 """
 from __future__ import annotations
 
@@ -32,8 +34,19 @@ DepthRenderingMode = Literal["depth", "disparity", "relative_disparity", "log"]
 
 # Highest SH band the rasterizer evaluates for this call site (GaussianRasterizationSettings.sh_max_degree).
 # 3: what the rasterizer family behind the reference's live call site does with GGRt's sh_degree = 4 / 25
-# coefficients; set to 4 if the installed extension being replaced evaluates band 4.
-SH_MAX_DEGREE = 3
+# coefficients; 4 if the installed extension being replaced evaluates band 4; 0 = not chosen (3,
+# with one warning from the rasterizer the first time coefficients 16.. go unused).
+SH_MAX_DEGREE = int(__import__("os").environ.get("GGR_SH_MAX_DEGREE", "0") or 0)
+
+
+def set_sh_max_degree(cap: int) -> int:
+    """Chooses (process-wide, for this call-site layer) the highest SH band the rasterizer evaluates: 3 or 4 (0 = back to
+    "not chosen").  Returns the previous setting."""
+    global SH_MAX_DEGREE
+    if int(cap) not in (0, 3, 4):
+        raise ValueError("sh_max_degree must be 3 or 4")
+    prev, SH_MAX_DEGREE = SH_MAX_DEGREE, int(cap)
+    return prev
 
 
 @dataclass
@@ -444,9 +457,13 @@ class DecoderSplattingCUDA(nn.Module):
     ``forward(gaussians, extrinsics[b,v,4,4], intrinsics[b,v,3,3], near[b,v], far[b,v], image_shape,
     depth_mode) -> DecoderOutput(color[b,v,3,h,w], depth[b,v,h,w] | None)``."""
 
-    def __init__(self, cfg=None, fused_depth: bool = True, fused_inputs: bool = True, list_capacity: int = 0):
+    def __init__(self, cfg=None, fused_depth: bool = True, fused_inputs: bool = True, list_capacity: int = 0,
+                 sh_max_degree: Optional[int] = None):
         super().__init__()
         self.cfg = cfg
+        # 3 / 4: the explicit choice of INTEGRATION.md §7 (process-wide for this module); None leaves it as it is
+        if sh_max_degree is not None:
+            set_sh_max_degree(sh_max_degree)
         # > 0: sync-free rasterizer forward with per-tile lists of at most this many entries — with the fused
         # inputs the whole decoder call then has no host sync and can be captured in a HIP graph
         # (check ``ggrt_official_amd.last_forward_status()`` for overflow when a sync is affordable)

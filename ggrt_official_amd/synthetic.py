@@ -50,7 +50,8 @@ class Scene:
         return GaussianRasterizationSettings(
             image_height=self.height, image_width=self.width, tanfovx=self.tanfovx, tanfovy=self.tanfovy,
             bg=self.bg, scale_modifier=1.0, viewmatrix=self.viewmatrix, projmatrix=self.projmatrix,
-            sh_degree=self.sh_degree, campos=self.campos, prefiltered=False, debug=debug)
+            sh_degree=self.sh_degree, campos=self.campos, prefiltered=False, debug=debug,
+            sh_max_degree=3)  # (explicit: the synthetic D = 4 / M = 25 shapes evaluate bands 0..3)
 
 
 def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:

@@ -106,6 +106,11 @@ def test_readback_wait_never_spins_forever():
     assert 0.15 < time.time() - t0 < 5.0 and "within" in _lib.last_error()
     assert lib.ggr_debug_readback_wait(3, 5.0, ctypes.byref(v)) == 2                          # done, but never written
     assert lib.ggr_debug_readback_wait(7, 5.0, ctypes.byref(v)) == 1                          # GGR_E_INVALID
+    # the bound only runs from the tile-list kernels' turn — a stream busy with EARLIER work for 3 × the
+    # bound does not void the frame
+    t0 = time.time()
+    assert lib.ggr_debug_readback_wait(4, 0.1, ctypes.byref(v)) == 0 and v.value == 4321
+    assert time.time() - t0 >= 0.29
 
 
 def test_no_cpu_fallback():
@@ -159,3 +164,34 @@ def test_error_paths_return_codes_and_messages_without_touching_a_gpu():
     assert lib.ggr_forward_status(None, 4, None, None, None) != 0 and err()
     # a successful query clears nothing it should not: size queries never fail
     assert lib.ggr_geom_bytes(0) > 0 and lib.ggr_backward_scratch_bytes(0) > 0
+
+
+def test_sh_cap_is_an_explicit_choice(monkeypatch):
+    """GGRt passes sh_degree 4 with 25 coefficients; leaving `sh_max_degree` undecided evaluates bands
+    0..3 and must say so once — an explicit 3 or 4 (settings, DecoderSplattingCUDA, GGR_SH_MAX_DEGREE) is silent."""
+    import warnings
+    from types import SimpleNamespace
+    from ggrt_official_amd import rasterizer, splatting
+    monkeypatch.delenv("GGR_SH_MAX_DEGREE", raising=False)
+    monkeypatch.setattr(rasterizer, "_sh_warned", False)
+    rs = SimpleNamespace(sh_degree=4, sh_max_degree=0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert rasterizer._sh_cap(rs, 25) == 0 and len(w) == 1 and "sh_max_degree" in str(w[0].message)
+        assert rasterizer._sh_cap(rs, 25) == 0 and len(w) == 1          # once per process
+    monkeypatch.setattr(rasterizer, "_sh_warned", False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert rasterizer._sh_cap(SimpleNamespace(sh_degree=4, sh_max_degree=3), 25) == 3
+        assert rasterizer._sh_cap(SimpleNamespace(sh_degree=4, sh_max_degree=4), 25) == 4
+        assert rasterizer._sh_cap(SimpleNamespace(sh_degree=3, sh_max_degree=0), 16) == 0   # nothing is truncated
+        monkeypatch.setenv("GGR_SH_MAX_DEGREE", "4")
+        assert rasterizer._sh_cap(rs, 25) == 4
+        assert not w
+    prev = splatting.set_sh_max_degree(4)
+    try:
+        assert splatting.SH_MAX_DEGREE == 4
+        splatting.DecoderSplattingCUDA(sh_max_degree=3)
+        assert splatting.SH_MAX_DEGREE == 3
+    finally:
+        splatting.set_sh_max_degree(prev)

@@ -47,7 +47,7 @@ class _OracleRasterizer(torch.nn.Module):
         return tr.rasterize(means3D, opacities, rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg, rs.image_width,
                             rs.image_height, rs.tanfovx, rs.tanfovy, rs.sh_degree, shs=shs,
                             colors_precomp=colors_precomp, cov3D_precomp=cov3D_precomp, aux=aux_precomp,
-                            sh_cap=int(getattr(rs, "sh_max_degree", 3)))
+                            sh_cap=int(getattr(rs, "sh_max_degree", 0) or 3))
 
 
 def test_golden_files_present():
