@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libggr_raster.so")
 SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "tile_lists.hip", "blend_fwd.hip", "blend_bwd.hip",
-           "preprocess_bwd.hip", "camera.hip"]
+           "preprocess_bwd.hip", "camera.hip", "util.hip"]
 HEADERS = ["ggr_common.h", "blend_common.h", "sh_stage.h", os.path.join("..", "..", "include", "ggr_raster.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
@@ -103,6 +103,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
+            for _, q in procs:
+                if q.poll() is None:
+                    q.kill()
+            shutil.rmtree(objdir, ignore_errors=True)
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)

@@ -570,6 +570,14 @@ int ggr_debug_readback_wait(int32_t scenario, double timeout_s, uint32_t* value)
     return wait_readback(&word, fake_query, &q, timeout_s, value);
 }
 
+int ggr_debug_copy(const void* src, void* dst, size_t bytes, int32_t blocks, void* stream) {
+    g_err[0] = 0;
+    if (!src || !dst || (bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return fail(GGR_E_INVALID, "bad arguments (16-byte granularity)");
+    ggr::launch_copy_f4(src, dst, bytes, blocks, (hipStream_t)stream);
+    KCHECK(false, (hipStream_t)stream, "copy_f4");
+    return GGR_OK;
+}
+
 int ggr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present,
                      void* stream) {
     g_err[0] = 0;

@@ -123,6 +123,32 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter]) -> None:
         o += n
 
 
+def device_identity(device) -> dict:
+    """What tells physical GPUs apart: PCI domain:bus:device where torch exposes it, else the device UUID / name."""
+    pr = torch.cuda.get_device_properties(device)
+    ident = None
+    if all(hasattr(pr, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        ident = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    elif getattr(pr, "uuid", None) is not None:
+        ident = str(pr.uuid)
+    return {"index": torch.device(device).index, "pci": ident, "name": pr.name}
+
+
+def rank_device_report(device, shared_ok: bool = False) -> list:
+    """All ranks' device identities, gathered on every rank; raises if two ranks of the job sit on the same physical
+    device (unless `shared_ok`: the 1-GPU dry run of the N > 1 control flow).  One process per GPU is what the frame
+    sharding assumes (reference ggrt/base/trainer.py:115-117: `device = cuda:{local_rank}`)."""
+    mine = dict(rank=dist.get_rank() if dist.is_initialized() else 0, **device_identity(device))
+    if not dist.is_initialized():
+        return [mine]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, mine)
+    ids = [o["pci"] if o["pci"] is not None else f"index{o['index']}" for o in out]
+    if not shared_ok and len(set(ids)) != len(ids):
+        raise RuntimeError(f"two ranks share one physical GPU: {out}")
+    return out
+
+
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized():
         return value

@@ -164,6 +164,27 @@ def set_list_hint(enabled: bool) -> bool:
     return prev
 
 
+# what the default mode did with its guesses (process-wide): calls that ran with a guessed list buffer that held
+# ("hinted"), that had to be repeated in upstream's order ("missed"), and that ran in upstream's order from the start
+# ("exact": first call of a shape, hints off, stage profiling)
+_hint_stats = {"hinted": 0, "missed": 0, "exact": 0}
+
+
+def list_hint_stats(reset: bool = False) -> dict:
+    with _hint_lock:
+        out = dict(_hint_stats)
+        if reset:
+            for k in _hint_stats:
+                _hint_stats[k] = 0
+    return out
+
+
+def clear_list_hints() -> None:
+    """Forgets every shape's list-size history (the next forward of each shape runs in upstream's order)."""
+    with _hint_lock:
+        _hints.clear()
+
+
 def _scissor_key(rs):
     sc = getattr(rs, "scissor", None)
     return tuple(int(v) for v in sc) if sc else None
@@ -206,7 +227,9 @@ def _forward_with_guess(call, fout, holder, lib, dev, W, H, key, user_capacity, 
         if rc != _GGR_E_CAPACITY:
             _check(rc, "ggr_forward")
             _note_rendered(key, int(fout.num_rendered))
+            _hint_stats["hinted"] += 1
             return
+        _hint_stats["missed"] += 1
         # the guess did not hold: once more, in upstream's order (the buffers of the first attempt are released to the
         # stream-ordered allocator: what is still running on them was enqueued before what follows)
         _note_rendered(key, int(fout.num_rendered))

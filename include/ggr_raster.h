@@ -320,8 +320,15 @@ int ggr_debug_unpack_binning(const void* binning_buffer, const void* image_buffe
  * scenario 0: the query reports "not ready" and the word receives 1234 after a few polls → GGR_OK (*value = 1234);
  * scenario 1: the query reports an error status (a stream in error / a lost device) → GGR_E_HIP at once;
  * scenario 2: the query never becomes ready and the word never changes (a hung GPU) → GGR_E_HIP after timeout_s;
- * scenario 3: the query reports "done" but the word was never written → GGR_E_HIP. */
+ * scenario 3: the query reports "done" but the word was never written → GGR_E_HIP;
+ * scenario 4: the stream is busy with EARLIER work for 3·timeout_s before the tile-list kernels get their turn, then
+ *             the word receives 4321 → GGR_OK: the time bound only runs from those kernels' turn. */
 int ggr_debug_readback_wait(int32_t scenario, double timeout_s, uint32_t* value);
+
+/* The streaming yardstick (no counterpart in the reference): a float4 copy of `bytes` (multiple of 16; both pointers
+ * 16-byte aligned) from `src` to `dst` in `blocks` workgroups of 256 threads (0 = default).  bench.py times it to quote
+ * what a pure HBM streaming kernel reaches on this part next to the 8 TB/s spec. */
+int ggr_debug_copy(const void* src, void* dst, size_t bytes, int32_t blocks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,11 @@ import callsite_bench, torch
 from ggrt_official_amd import splatting
 print(callsite_bench.measure_views(steps=10, warmup=3))" > $OUT/views.log 2>&1
 cd $R
+# which kernels these profiles were taken on: bench.py compares the hash with csrc/ and flags a stale profile
+python -c "
+import json, sys; sys.path.insert(0, '$R')
+from ggrt_official_amd import _build
+json.dump({'source_hash': _build.source_hash(), 'git_sha': '${GGR_GIT_SHA:-unknown}', 'tag': '$TAG', 'config': '$CFG'}, open('$OUT/meta.json', 'w'))"
 python scripts/rocprof_summary.py $OUT/trace_results.db > $OUT/c3_kernel_stats.txt 2>&1
 python scripts/rocprof_summary.py $OUT/views_results.db > $OUT/views4_c5p_kernel_stats.txt 2>&1
 python scripts/pmc_summary.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1

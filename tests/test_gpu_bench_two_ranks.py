@@ -43,6 +43,12 @@ def test_bench_two_ranks_share_one_gpu(mode):
     for k in ("raster_ms", "allreduce_ms", "serial_ms_per_step", "overlapped_ms_per_step"):
         assert mg[k] > 0, k
     assert "cpu_baseline" not in rec and "secondary" not in rec   # rank 0 at N = 1 only
+    # what tells a path-bound step from an exchange-bound one sits at the TOP level of the record
+    assert rec["raster_only_mpix_s"] == mg["raster_only_mpix_s"] > 0 and rec["allreduce_ms"] == mg["allreduce_ms"]
+    assert rec["allreduce_busbw_GBps"] >= 0 and rec["allreduce_over_raster"] == pytest.approx(mg["allreduce_ms"] / mg["raster_ms"], rel=1e-2)
+    assert rec["exchange_bound"] == (mg["allreduce_ms"] > mg["raster_ms"])
+    # … and every rank reported its device (here both ranks share GPU 0 on purpose: `--device 0`)
+    assert [r["rank"] for r in rec["ranks"]] == [0, 1] and all(r["index"] == 0 for r in rec["ranks"])
 
 
 @pytest.mark.timeout(900)
@@ -63,3 +69,4 @@ def test_bench_one_rank_over_rccl():
     assert mg["backend"] == "nccl" and mg["world"] == 1 and mg["chunks"] == 8
     assert mg["allreduce_ms"] > 0 and mg["overlapped_ms_per_step"] > 0 and mg["serial_ms_per_step"] > 0
     assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["ranks"][0]["rank"] == 0 and rec["ranks"][0]["index"] == 0 and rec["allreduce_over_raster"] > 0

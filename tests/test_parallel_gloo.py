@@ -51,6 +51,10 @@ def _worker(rank, world, port, out):
     red.issue(chunked)
     n_pending = len(red.pending)
     red.wait()
+    # 3d. an empty buffer (range() with step 0 raised) still goes through the collective sequence
+    empty = torch.zeros(0)
+    red.issue(empty)
+    red.wait()
     # 4. timing reduction used by bench.py
     t = parallel.max_over_ranks(0.5 + rank, "cpu")
     parallel.barrier()
