@@ -618,6 +618,7 @@ def main():
             wl_b = Workload(args.config, cfg, dev, seed=rank + 7)
             with torch.no_grad():
                 wl_b.cov.mul_(1.7)          # the same shape, larger footprints: ≈ 1.5 × the list entries
+                wl_b.sc.cov3D.mul_(1.7)     # (what num_rendered() renders)
             n_a, n_b = wl.num_rendered(reference=False), wl_b.num_rendered(reference=False)
             pair = (wl, wl_b)
             _r.clear_list_hints()
