@@ -8,30 +8,33 @@
 
 namespace ggr {
 
-// one float4 (16 B) per lane and trip, UNROLL trips in flight per thread, grid-stride; plain (cached) loads and
-// non-temporal stores (the destination is not read again)
-typedef float v4f __attribute__((ext_vector_type(4)));   // (the non-temporal builtin wants a native vector type)
+// ONE float4 (16 B) per thread, one 256-thread workgroup per 4 KB, plain load and store — the plainest shape is the
+// fastest on this part (tools/copy_bench.hip, round 4, 512 MB … 1 GB per buffer, read + write counted):
+//     this shape 6.14-6.24 TB/s (the guide's 6.29) | contiguous chunk per workgroup, 4 loads in flight 5.3-5.9 |
+//     grid-stride with 4 far-apart streams per thread 4.2-5.1 | hipMemcpyDtoD 4.9-5.2 | read-only 5.0-5.5, write-only
+//     4.3-4.5 TB/s: a kernel that only reads or only writes does NOT reach the copy's rate.
+// `blocks` > 0 selects the grid-stride form instead (kept for the comparison).
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int UNROLL>
 __global__ void __launch_bounds__(256)
 copy_f4_kernel(const v4f* __restrict__ src, v4f* __restrict__ dst, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(256)
+copy_f4_stride_kernel(const v4f* __restrict__ src, v4f* __restrict__ dst, size_t n4) {
     const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
-        v4f v[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) v[u] = src[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) __builtin_nontemporal_store(v[u], &dst[i + u * stride]);
-    }
-    for (; i < n4; i += stride) dst[i] = src[i];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
 }
 
 void launch_copy_f4(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s) {
     const size_t n4 = bytes / 16;
     if (n4 == 0) return;
-    if (blocks <= 0) blocks = 256 * 16;   // 16 workgroups per CU
-    hipLaunchKernelGGL(copy_f4_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, (const v4f*)src, (v4f*)dst, n4);
+    if (blocks > 0)
+        hipLaunchKernelGGL(copy_f4_stride_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const v4f*)src, (v4f*)dst, n4);
+    else
+        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const v4f*)src, (v4f*)dst, n4);
 }
 
 }  // namespace ggr
