@@ -78,50 +78,44 @@ radix_block_max_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __
 #ifndef GGR_HIST_ITEMS
 #define GGR_HIST_ITEMS 8
 #endif
-#define GGR_HIST_BLOCK_KEYS (GGR_HIST_THREADS * GGR_HIST_ITEMS)   // keys per histogram work item (either form)
-// body shared by the stand-alone histogram kernel (THREADS = 1024) and the histogram role of the fused sort kernel
-// (THREADS = 512): `item` = which GGR_HIST_BLOCK_KEYS keys.  h: [3][1024] u32 of LDS, wm: [THREADS / 64] u32 of LDS.
-template <int THREADS>
-__device__ __forceinline__ void radix_hist_body(const uint32_t* __restrict__ keys, size_t n /*keys per segment*/,
-                                                uint32_t blocks_per_seg, uint32_t item, uint32_t* __restrict__ hist,
-                                                const uint32_t* __restrict__ block_max, uint32_t nmax,
-                                                uint32_t (*h)[GGR_SORT_MAX_BINS], uint32_t* wm) {
-    constexpr int ITEMS = GGR_HIST_BLOCK_KEYS / THREADS;
+__global__ void __launch_bounds__(GGR_HIST_THREADS)
+radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per segment*/, uint32_t blocks_per_seg,
+                         uint32_t* __restrict__ hist, const uint32_t* __restrict__ block_max, uint32_t nmax) {
+    __shared__ uint32_t h[GGR_SORT_PASSES][GGR_SORT_MAX_BINS];
+    __shared__ uint32_t wm[GGR_HIST_THREADS / 64];
     const int tid = threadIdx.x;
     // this block's keys: all loads issued before anything waits (the kernel is latency-bound)
-    uint32_t ks[ITEMS];
-    const uint32_t seg = item / blocks_per_seg, bseg = item - seg * blocks_per_seg;
+    uint32_t ks[GGR_HIST_ITEMS];
+    const uint32_t seg = blockIdx.x / blocks_per_seg, bseg = blockIdx.x - seg * blocks_per_seg;
     keys += (size_t)seg * n;
-    const size_t base = (size_t)bseg * GGR_HIST_BLOCK_KEYS;
+    const size_t base = (size_t)bseg * (GGR_HIST_THREADS * GGR_HIST_ITEMS);
 #pragma unroll
-    for (int u = 0; u < ITEMS; u++) {
-        const size_t idx = base + (size_t)u * THREADS + tid;
+    for (int u = 0; u < GGR_HIST_ITEMS; u++) {
+        const size_t idx = base + (size_t)u * GGR_HIST_THREADS + tid;
         ks[u] = idx < n ? keys[idx] : 0xFFFFFFFFu;   // (0xFFFFFFFF marks "no key": real keys are < 2^31)
     }
     uint32_t m = 0;
-    for (uint32_t i0 = 0; i0 < nmax; i0 += 4 * THREADS) {
+    for (uint32_t i0 = 0; i0 < nmax; i0 += 4 * GGR_HIST_THREADS) {
         uint32_t v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = block_max[min(i0 + u * THREADS + tid, nmax - 1)];
+        for (int u = 0; u < 4; u++) v[u] = block_max[min(i0 + u * GGR_HIST_THREADS + tid, nmax - 1)];
         m = max(max(m, v[0]), max(v[1], max(v[2], v[3])));
     }
-    for (int x = tid; x < GGR_SORT_PASSES * GGR_SORT_MAX_BINS; x += THREADS) (&h[0][0])[x] = 0;
+    for (int x = tid; x < GGR_SORT_PASSES * GGR_SORT_MAX_BINS; x += GGR_HIST_THREADS) (&h[0][0])[x] = 0;
     m = wave_max_u32(m);
     if ((tid & 63) == 0) wm[tid >> 6] = m;
     __syncthreads();
-    m = wave_max_u32(wm[tid & (THREADS / 64 - 1)]);  // (the first lanes hold the wave maxima, the others repeat them)
+    m = wave_max_u32(wm[tid & (GGR_HIST_THREADS / 64 - 1)]);  // (the first lanes hold the wave maxima, the others repeat them)
     const uint32_t bits = m ? 32u - (uint32_t)__builtin_clz(m) : 1u;
     uint32_t w = (bits + 2u) / 3u;
     if (w > GGR_SORT_MAX_BITS) {
         w = GGR_SORT_MAX_BITS;
-        if (tid == 0 && item == 0) atomicOr(&hist[GGR_HIST_FAULT], GGR_FAULT_RANGE);
+        if (tid == 0 && blockIdx.x == 0) atomicOr(&hist[GGR_HIST_FAULT], GGR_FAULT_RANGE);
     }
-    // (read by the pass kernels — later launches — or, in the fused kernel, by pass roles that have seen this role's
-    //  completion: an agent-scope store either way)
-    if (tid == 0 && item == 0) __hip_atomic_store(&hist[GGR_HIST_PARAMS], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && blockIdx.x == 0) hist[GGR_HIST_PARAMS] = w;   // (read by the pass kernels: later launches)
     const uint32_t mask = (1u << w) - 1u;
 #pragma unroll
-    for (int u = 0; u < ITEMS; u++) {
+    for (int u = 0; u < GGR_HIST_ITEMS; u++) {
         if (ks[u] != 0xFFFFFFFFu) {
             atomicAdd(&h[0][ks[u] & mask], 1u);
             atomicAdd(&h[1][(ks[u] >> w) & mask], 1u);
@@ -130,19 +124,11 @@ __device__ __forceinline__ void radix_hist_body(const uint32_t* __restrict__ key
     }
     __syncthreads();
     const uint32_t bins = 1u << w;
-    for (uint32_t x = tid; x < GGR_SORT_PASSES * bins; x += THREADS) {
+    for (uint32_t x = tid; x < GGR_SORT_PASSES * bins; x += GGR_HIST_THREADS) {
         const uint32_t p = x >> w, d = x & mask;
         const uint32_t c = h[p][d];
         if (c) atomicAdd(&hist[GGR_HIST_TOTALS + (seg * GGR_SORT_PASSES + p) * GGR_SORT_MAX_BINS + d], c);
     }
-}
-
-__global__ void __launch_bounds__(GGR_HIST_THREADS)
-radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per segment*/, uint32_t blocks_per_seg,
-                         uint32_t* __restrict__ hist, const uint32_t* __restrict__ block_max, uint32_t nmax) {
-    __shared__ uint32_t h[GGR_SORT_PASSES][GGR_SORT_MAX_BINS];
-    __shared__ uint32_t wm[GGR_HIST_THREADS / 64];
-    radix_hist_body<GGR_HIST_THREADS>(keys, n, blocks_per_seg, blockIdx.x, hist, block_max, nmax, h, wm);
 }
 
 // GATHER (last pass of the depth sort only): every pair also carries an 8-byte payload looked up by its value,
@@ -150,97 +136,43 @@ radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per 
 // stream the rects in depth order without a separate gather launch; the pass also clears `zero_area`.
 // ITEMS keys per thread (8 … 16): a sort of a little more than 256 tiles of 4096 keys (GGRt's LLFF eval frame:
 // 1 146 880 Gaussians = 281 tiles on 256 CUs) runs with larger tiles instead of doubling up on 25 CUs.
-// LDS of one sort workgroup (the histogram role of the fused kernel reuses `sorted` for its three digit histograms)
-template <int ITEMS>
-struct SortLds {
-    uint16_t wcount[GGR_SORT_THREADS / 64][GGR_SORT_MAX_BINS];  // per-wave digit counters (a wave holds 512 keys), later per-wave prefixes
-    uint32_t dbase[GGR_SORT_MAX_BINS];       // global start of this tile's run of every digit
-    uint32_t texcl[GGR_SORT_MAX_BINS];       // start of that run inside the tile's locally sorted order
-    uint2 sorted[(GGR_SORT_THREADS * ITEMS)];   // the tile's (key, val) pairs — then its payloads — in output order
-    uint32_t wsum[GGR_SORT_THREADS / 64];
-    uint32_t tile_sh;
-    uint32_t role_sh;
-};
-
-// ---- hand-over between the roles of the fused kernel, WITHOUT cache maintenance ----------------------------------------
-// First built with an agent-scope release (after a tile's last store) / acquire (before the next pass's first load): correct,
-// and 133 µs instead of 76 for 1 M keys — a release writes back EVERY dirty line of the XCD's L2, which during a pass is full
-// of everybody's scatter stores, and each tile waited ≈ 13 µs for it.  Instead, everything that crosses workgroups inside the
-// launch moves with relaxed agent-scope atomic stores and loads (`sc1`: written through / fetched past the non-coherent
-// L2, the same instructions the look-back status words use): nothing is ever dirty or stale in an L2, so the hand-over is
-// "all my stores have completed (s_waitcnt, barrier) → count myself in (relaxed atomic)" and "count is full (relaxed
-// atomic polls, barrier) → load".
-__device__ __forceinline__ uint32_t xwg_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void xwg_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// thread 0 polls until *word ≥ need (bounded), then the barrier releases the workgroup's loads
-__device__ __forceinline__ void wait_for_count(const uint32_t* word, uint32_t need, uint32_t* fault_word) {
-    if (threadIdx.x == 0) {
-        uint32_t spins = 0;
-        while (xwg_load(word) < need) {
-            if (++spins > GGR_SPIN_LIMIT) { atomicOr(fault_word, GGR_FAULT_SPIN); break; }   // never hang
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-}
-// every wave waits for its own stores (workgroup-scope release = s_waitcnt vmcnt(0): a written-through store is complete
-// when it has reached the level all XCDs see), the barrier collects the waves, then thread 0 counts the workgroup in
-__device__ __forceinline__ void count_in(uint32_t* word) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// One digit pass over one sort tile.  `widx` / `nwg`: this workgroup's index among the pass's workgroups and their number
-// (the stand-alone kernel: blockIdx.x / gridDim.x).  Fused kernel only (XWG): `wait_word` / `wait_need` = what must have
-// completed before ANY input of the pass may be read (the histogram role for pass 0, all tiles of the previous pass of
-// this segment otherwise); `done_word` = where this tile counts itself in after its last store (or null: last pass).
-// XWG: inputs are loaded, and outputs that a later role of the same launch reads are stored, past the non-coherent L2.
-template <bool GATHER, int ITEMS, bool XWG = false>
-__device__ __forceinline__ void
-radix_onesweep_body(SortLds<ITEMS>& L, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n /*keys per segment*/,
-                    int pass, uint32_t ntiles /*per segment*/, uint32_t nseg, int tree_lookback, uint32_t* __restrict__ hist,
-                    const uint2* __restrict__ gather_src, uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area,
-                    uint32_t zero_words, uint32_t widx, uint32_t nwg, const uint32_t* wait_word, uint32_t wait_need,
-                    uint32_t* done_word_base /*[segment], or null*/) {
+template <bool GATHER, int ITEMS>
+__global__ void __launch_bounds__(GGR_SORT_THREADS)
+radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n /*keys per segment*/,
+                      int pass, uint32_t ntiles /*per segment*/, uint32_t nseg, int tree_lookback, uint32_t* __restrict__ hist,
+                      const uint2* __restrict__ gather_src,
+                      uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
     constexpr int NW = GGR_SORT_THREADS / 64;
     constexpr int DPT = GGR_SORT_MAX_BINS / GGR_SORT_THREADS;  // digits per thread at the widest digit
-    auto& wcount = L.wcount;
-    auto& dbase = L.dbase;
-    auto& texcl = L.texcl;
-    auto& sorted = L.sorted;
-    auto& wsum = L.wsum;
-    uint32_t& tile_sh = L.tile_sh;
+    __shared__ uint16_t wcount[NW][GGR_SORT_MAX_BINS];  // per-wave digit counters (a wave holds 512 keys), later per-wave prefixes
+    __shared__ uint32_t dbase[GGR_SORT_MAX_BINS];       // global start of this tile's run of every digit
+    __shared__ uint32_t texcl[GGR_SORT_MAX_BINS];       // start of that run inside the tile's locally sorted order
+    __shared__ uint2 sorted[(GGR_SORT_THREADS * ITEMS)];             // the tile's (key, val) pairs — then its payloads — in output order
+    __shared__ uint32_t wsum[NW];
+    __shared__ uint32_t tile_sh;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     // segments are dealt round robin to the workgroups, so that all of them progress together
-    const uint32_t seg = widx % nseg;
+    const uint32_t seg = blockIdx.x % nseg;
     if (tid == 0) tile_sh = atomicAdd(&hist[GGR_HIST_TICKETS + pass * GGR_SORT_MAX_SEGMENTS + seg], 1u);
     {
         const size_t so = (size_t)seg * n;
         keys_in += so; vals_in += so; keys_out += so; vals_out += so;
-        if (GATHER && gather_src != nullptr) gather_dst += so;
+        if (GATHER) gather_dst += so;
     }
-    for (uint32_t x = tid; x < NW * GGR_SORT_MAX_BINS / 2; x += GGR_SORT_THREADS)
-        reinterpret_cast<uint32_t*>(&wcount[0][0])[x] = 0u;
-    // fused kernel: nothing of this pass's inputs (digit width and totals, keys, values) is read before what produces
-    // them has completed
-    if (wait_word) wait_for_count(wait_word + (pass > 0 ? seg : 0u), wait_need, &hist[GGR_HIST_FAULT]);
-    // bits per digit.  Block-uniform — and it must be so for the compiler too (a vector atomic load is not: without the
-    // readfirstlane every digit loop below is predicated instead of branched and the kernel needs 130 VGPRs instead of 64)
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)__hip_atomic_load(&hist[GGR_HIST_PARAMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const uint32_t w = hist[GGR_HIST_PARAMS];            // bits per digit (block-uniform)
     const uint32_t bins = 1u << w, mask = bins - 1u;
     const uint32_t shift = (uint32_t)pass * w;
-    // this pass's digit totals, requested now (they are final: the histogram has ended)
+    // this pass's digit totals, requested now (they are final: the histogram kernel has ended)
     uint32_t tot[DPT];
 #pragma unroll
     for (int q = 0; q < DPT; q++) {
         const uint32_t d = tid + q * GGR_SORT_THREADS;
-        const uint32_t* tp = &hist[GGR_HIST_TOTALS + (seg * GGR_SORT_PASSES + pass) * GGR_SORT_MAX_BINS + (d < bins ? d : 0u)];
-        tot[q] = d < bins ? (XWG ? xwg_load(tp) : *tp) : 0u;
+        tot[q] = d < bins ? hist[GGR_HIST_TOTALS + (seg * GGR_SORT_PASSES + pass) * GGR_SORT_MAX_BINS + d] : 0u;
     }
+    for (uint32_t x = tid; x < NW * GGR_SORT_MAX_BINS / 2; x += GGR_SORT_THREADS)
+        reinterpret_cast<uint32_t*>(&wcount[0][0])[x] = 0u;
     __syncthreads();
     const uint32_t tile = tile_sh;
     PROBE(0);
@@ -255,12 +187,12 @@ radix_onesweep_body(SortLds<ITEMS>& L, const uint32_t* __restrict__ keys_in, con
     for (int r = 0; r < ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
         const bool valid = idx < n;
-        key[r] = valid ? (XWG ? xwg_load(keys_in + idx) : keys_in[idx]) : 0xFFFFFFFFu;
-        val[r] = valid ? (XWG ? xwg_load(vals_in + idx) : vals_in[idx]) : 0u;
+        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = valid ? vals_in[idx] : 0u;
     }
     uint2 pay[GATHER ? ITEMS : 1];
-    if (GATHER && gather_src != nullptr) {
-        for (uint32_t wz = widx * GGR_SORT_THREADS + tid; wz < zero_words; wz += nwg * GGR_SORT_THREADS)
+    if (GATHER) {
+        for (uint32_t wz = blockIdx.x * GGR_SORT_THREADS + tid; wz < zero_words; wz += gridDim.x * GGR_SORT_THREADS)
             zero_area[wz] = 0u;
         // issued now, consumed after the ranking and the look-back: the random 8-B reads hide behind them
 #pragma unroll
@@ -499,16 +431,11 @@ radix_onesweep_body(SortLds<ITEMS>& L, const uint32_t* __restrict__ keys_in, con
             const uint2 kv = sorted[j];
             const uint32_t d = (kv.x >> shift) & mask;
             gpos[k] = dbase[d] + (j - texcl[d]);
-            if (XWG && done_word_base) {   // (uniform: read by the next pass of this launch)
-                xwg_store(keys_out + gpos[k], kv.x);
-                xwg_store(vals_out + gpos[k], kv.y);
-            } else {
-                keys_out[gpos[k]] = kv.x;
-                vals_out[gpos[k]] = kv.y;
-            }
+            keys_out[gpos[k]] = kv.x;
+            vals_out[gpos[k]] = kv.y;
         }
     }
-    if (GATHER && gather_src != nullptr) {
+    if (GATHER) {
         __syncthreads();  // every pair has been read: the same LDS now carries the payloads
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
@@ -523,59 +450,6 @@ radix_onesweep_body(SortLds<ITEMS>& L, const uint32_t* __restrict__ keys_in, con
         }
     }
     PROBE(6);
-    if (done_word_base) count_in(done_word_base + seg);
-}
-
-template <bool GATHER, int ITEMS>
-__global__ void __launch_bounds__(GGR_SORT_THREADS)
-radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n /*keys per segment*/,
-                      int pass, uint32_t ntiles /*per segment*/, uint32_t nseg, int tree_lookback, uint32_t* __restrict__ hist,
-                      const uint2* __restrict__ gather_src,
-                      uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
-    __shared__ SortLds<ITEMS> L;
-    radix_onesweep_body<GATHER, ITEMS>(L, keys_in, vals_in, keys_out, vals_out, n, pass, ntiles, nseg, tree_lookback, hist,
-                                       gather_src, gather_dst, zero_area, zero_words, blockIdx.x, gridDim.x, nullptr, 0u, nullptr);
-}
-
-// ---- the whole sort in ONE launch (round 4) -------------------------------------------------------------------------
-// histogram + three digit passes were four dependent launches of ≈ 8 + 20 + 20 + 28 µs, of which each pass spent ≈ 7 µs in
-// launch ramp and end-of-kernel write-back (first tile start → last tile end ≈ 12 of ≈ 20 µs).  Here every workgroup takes a
-// ROLE from one global ticket: roles [0, nhist) are histogram items, then the tiles of pass 0, of pass 1, of pass 2, in that
-// order.  A role only ever waits for roles with LOWER tickets — pass p of a segment for all tiles of pass p − 1 of that
-// segment (pass 0 for the histogram roles), a tile's look-back for lower tiles of its pass — and a lower ticket belongs to
-// a workgroup that is already running (or done): no co-residency is assumed, a device shared with RCCL kernels only makes
-// the waits longer.  Hand-over between passes: written-through stores, a completion count per (pass, segment), loads past
-// the L2 (wait_for_count / count_in above: no cache maintenance).
-template <int ITEMS>
-__global__ void __launch_bounds__(GGR_SORT_THREADS)
-radix_fused_kernel(uint32_t* __restrict__ keys_a, uint32_t* __restrict__ vals_a, uint32_t* __restrict__ keys_b,
-                   uint32_t* __restrict__ vals_b, size_t n /*keys per segment*/, uint32_t ntiles /*per segment*/, uint32_t nseg,
-                   uint32_t nhist /*histogram roles, all segments*/, uint32_t hist_bps, int tree_lookback,
-                   uint32_t* __restrict__ hist, const uint32_t* __restrict__ block_max, uint32_t nmax,
-                   const uint2* __restrict__ gather_src, uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area,
-                   uint32_t zero_words) {
-    __shared__ SortLds<ITEMS> L;
-    if (threadIdx.x == 0) L.role_sh = atomicAdd(&hist[GGR_HIST_ROLE_TICKET], 1u);
-    __syncthreads();
-    const uint32_t role = L.role_sh;
-    if (role < nhist) {
-        radix_hist_body<GGR_SORT_THREADS>(keys_a, n, hist_bps, role, hist, block_max, nmax,
-                                          reinterpret_cast<uint32_t (*)[GGR_SORT_MAX_BINS]>(&L.sorted[0]), L.wsum);
-        count_in(&hist[GGR_HIST_HIST_DONE]);
-        return;
-    }
-    const uint32_t per_pass = ntiles * nseg;
-    const uint32_t r = role - nhist, pass = r / per_pass, widx = r - pass * per_pass;
-    uint32_t* const done = &hist[GGR_HIST_PASS_DONE];   // [pass][segment]
-    // ONE instantiation of the pass body for all three passes (four inlined copies cost 130 VGPRs instead of ≈ 70 and with
-    // them the second workgroup per CU): buffers, wait / done words and the gather are selected at run time
-    const bool odd = pass == 1, last = pass == 2;
-    radix_onesweep_body<true, ITEMS, true>(L, odd ? keys_b : keys_a, odd ? vals_b : vals_a, odd ? keys_a : keys_b, odd ? vals_a : vals_b, n,
-                                     (int)pass, ntiles, nseg, tree_lookback, hist, last ? gather_src : nullptr,
-                                     last ? gather_dst : nullptr, last ? zero_area : nullptr, last ? zero_words : 0u, widx, per_pass,
-                                     pass == 0 ? &hist[GGR_HIST_HIST_DONE] : done + (pass - 1) * GGR_SORT_MAX_SEGMENTS,
-                                     pass == 0 ? nhist : ntiles, last ? nullptr : done + pass * GGR_SORT_MAX_SEGMENTS);
 }
 
 const uint32_t* radix_sort_fault_word(const uint32_t* hist) { return hist + GGR_HIST_FAULT; }
@@ -601,34 +475,8 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
             (void)hipMemsetAsync(hist, 0, ggr_sort_zero_words(n, S) * sizeof(uint32_t), s);
         if (!block_max_ready)  // (ggr_forward: preprocess_fwd leaves them)
             hipLaunchKernelGGL(radix_block_max_kernel, dim3(nmax), dim3(GGR_PRE_THREADS), 0, s, kin, n, block_max);
-        const unsigned bps = (unsigned)((nseg + GGR_HIST_BLOCK_KEYS - 1) / GGR_HIST_BLOCK_KEYS);
-#ifndef GGR_SORT_FUSED
-#define GGR_SORT_FUSED 0   // 1: the one-launch form below — built, correct, and SLOWER (round 4: 104-133 µs against 76 at 1 M keys)
-#endif
-        if (GGR_SORT_FUSED) {
-            // ONE launch: bps·S histogram roles, then 3 × ntiles·S tile roles, dealt by a global ticket (kernel header)
-            const unsigned grid = bps * S + 3u * ntiles * S;
-            // ONE workgroup per CU (dynamic LDS padding up to > half a CU's 160 KB): with two, the dispatcher puts two tiles
-            // of a pass on some CUs and none on others, and a CU that runs two tiles runs each at half speed — the pass
-            // then lasts twice as long (measured: 156 instead of 76 µs for the whole sort at 1 M keys)
-#ifndef GGR_SORT_FUSED_LDS_PAD
-#define GGR_SORT_FUSED_LDS_PAD (84 * 1024)
-#endif
-#define GGR_FUSED(ITEMS_)                                                                                                     \
-    hipLaunchKernelGGL((radix_fused_kernel<ITEMS_>), dim3(grid), dim3(GGR_SORT_THREADS),                                       \
-                       sizeof(SortLds<ITEMS_>) < GGR_SORT_FUSED_LDS_PAD ? GGR_SORT_FUSED_LDS_PAD - sizeof(SortLds<ITEMS_>) : 0, s, \
-                       kin, vin, kout, vout, nseg, ntiles, \
-                       S, bps * S, bps, tree, hist, block_max, nmax, gather_src, gather_dst, zero_area, zero_words)
-            if (items == 8) GGR_FUSED(8);
-            else if (items == 10) GGR_FUSED(10);
-            else if (items == 12) GGR_FUSED(12);
-            else if (items == 14) GGR_FUSED(14);
-            else GGR_FUSED(16);
-#undef GGR_FUSED
-            *keys_out = kout;   // a → b → a → b
-            *vals_out = vout;
-            return;
-        }
+        const unsigned bps =
+            (unsigned)((nseg + GGR_HIST_THREADS * GGR_HIST_ITEMS - 1) / (GGR_HIST_THREADS * GGR_HIST_ITEMS));
         hipLaunchKernelGGL(radix_global_hist_kernel, dim3(bps * S), dim3(GGR_HIST_THREADS), 0, s, kin, nseg, bps, hist,
                            block_max, nmax);
 #define GGR_PASS(GATHER_, ITEMS_, SRC_, DST_, ZA_, ZW_)                                                                    \

@@ -69,7 +69,7 @@ static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) 
 // plain sort).  A launch set of V views sorts V segments — the per-view orders are all the tile lists need — with V
 // independent ticket sequences and look-back chains in the same three launches: a chain over the V·P/4096 tiles of all
 // views is what made one 4 M-key sort cost as much as four 1 M-key sorts one after the other.
-// Sort work area (u32 words): header [0, 512): tickets [pass·64 + segment], fault word, digit parameters | digit totals,
+// Sort work area (u32 words): header [0, 256): tickets [pass·64 + segment], fault word, digit parameters | digit totals,
 // (segment·3 + pass)·1024 + digit | look-back status words, ((pass·S + segment)·tiles_per_segment + tile)·bins + digit |
 // one key maximum per preprocess block.  Everything before the block maxima is zeroed by preprocess_fwd
 // (ggr_sort_zero_words); the maxima are plain stores.
@@ -81,12 +81,7 @@ static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) 
 #define GGR_HOST_ARMED 0xFFFFFFFEu         // not written yet
 #define GGR_HOST_FAULT_RANGE 0xFFFFFFFDu   // a sort key beyond 30 bits (cannot happen behind preprocess_fwd, which clamps)
 #define GGR_HIST_PARAMS 200   // [0] = bits per digit
-// the one-launch sort (binning.hip radix_fused_kernel): global role ticket, completed histogram roles, completed tiles
-// per (pass 0 … 1, segment)
-#define GGR_HIST_ROLE_TICKET 193
-#define GGR_HIST_HIST_DONE 194
-#define GGR_HIST_PASS_DONE 256   // [2][GGR_SORT_MAX_SEGMENTS]
-#define GGR_HIST_TOTALS 512
+#define GGR_HIST_TOTALS 256
 static inline size_t ggr_sort_segments(size_t views) { return views >= 1 && views <= GGR_SORT_MAX_SEGMENTS ? views : 1; }
 __host__ __device__ static inline size_t ggr_sort_status_base(size_t S) { return GGR_HIST_TOTALS + S * GGR_SORT_PASSES * GGR_SORT_MAX_BINS; }
 // look-back status words per (pass, segment): GGR_SORT_LEVELS arrays of [tiles][MAX_BINS] — level 0 the tiles' own digit
