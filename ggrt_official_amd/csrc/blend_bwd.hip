@@ -28,6 +28,7 @@ namespace ggr {
 #define BATCH GGR_BATCH
 #define RB 8  // entries per reduction batch
 
+// [budget: reduce-dpp-moves]  (scripts/valu_budget.py attributes the ISA below each marker to that phase)
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     // every lane has a source under these controls (rotations / permutations inside a row), so `old` is never
@@ -36,6 +37,7 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
+// [budget: reduce-rows]
 // Transposing reduction of v[0..7] over the 8 pixel ROWS of the quadrant (lane = 8·row + column).  Returns,
 // in lane l, the sum over the 8 lanes {column (l & 7) of every row} of v[l >> 3].
 __device__ __forceinline__ float transpose_rows8(float (&v)[RB], int lane) {
@@ -60,6 +62,7 @@ __device__ __forceinline__ float transpose_rows8(float (&v)[RB], int lane) {
     return keep + dpp_mov<0x128>(send);
 }
 
+// [budget: reduce-columns]
 // Butterfly sum over the 8 lanes of a group (the 8 pixel columns): every lane of the group gets the total.
 __device__ __forceinline__ float sum_cols8(float s) {
     s += dpp_mov<0xB1>(s);   // quad_perm [1,0,3,2]
@@ -95,6 +98,7 @@ __device__ __forceinline__ float transpose_cols8(const float (&o)[8], int lane) 
     return keep + dpp_mov<0x141>(send);       // row_half_mirror
 }
 
+// [budget: prologue]
 template <bool HAS_DEPTH>
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
@@ -182,6 +186,10 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
     float T = T_final;
     float R = T_final * bg_dot;  // everything behind the current entry, dotted with dL/dpixel (see the slot body)
+    // (scalar register operands instead of 32-bit literals in every v_min / v_cmp of the slot body: a literal costs 2 more
+    //  issue cycles per instruction — tools/valu_peak_bench.hip; scripts/valu_budget.py: 12 literal instructions per trip)
+    float amax = GGR_ALPHA_MAX, amin = GGR_ALPHA_MIN;
+    __asm__ volatile("" : "+s"(amax), "+s"(amin));
 
     // A pixel whose list goes on behind this segment starts from the forward's checkpoint there: T as the forward
     // had it, and R = (final sums − checkpoint sums)·dL/dpixel + T_final·(bg·dL/dpixel) — the same "everything
@@ -200,6 +208,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const int vix = vi < 4 ? vi : 11 - vi;   // the value transpose_cols8 leaves in this lane
     const int my_slot = lane >> 3;
 
+    // [budget: stage]
     // the list ids of a batch are requested one batch ahead (id → record is a chain of two global round trips)
     uint32_t g_next = tid < seg_hi - seg_lo ? point_list[range.x + seg_hi - 1 - tid] : 0u;
     for (int hi_ = seg_hi; hi_ > seg_lo; hi_ -= BATCH) {
@@ -217,6 +226,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             stage[tid].c = c;
         }
         __syncthreads();
+        // [budget: cull]
         // ---- cull: compact this wave's survivors of the whole 256-entry batch into a wave-private list,
         //      so that every reduction batch below is full (a reduction costs >1000 cycles whether 1 or
         //      8 of its slots are used)
@@ -240,6 +250,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         __builtin_amdgcn_wave_barrier();
         {
             for (int k0 = 0; k0 < ns; k0 += RB) {
+                // [budget: slot-setup]
                 const uint4 pk = *reinterpret_cast<const uint4*>(my_surv + k0);  // 8 × u16 indices, one broadcast read
                 const uint32_t pkw[4] = {pk.x, pk.y, pk.z, pk.w};
                 // ---- one reduction batch: up to RB surviving entries ---------------------------------
@@ -264,6 +275,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                     e_sl[sl] = ok_sl[sl] ? __builtin_amdgcn_readfirstlane((int)((pkw[sl >> 1] >> (16 * (sl & 1))) & 0xffffu)) : 0;
                     if (ok_sl[sl] && my_slot == sl) my_e = e_sl[sl];
                 }
+                // [budget: evaluate]
 #pragma unroll
                 for (int sl = 0; sl < RB; sl++) {
                     {
@@ -274,8 +286,8 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                         const float4 c = stage[e2].c;
                         const float q2 = staged_q2(a, b, a.x - pixx, a.y - pixy);  // = −power·log2(e)
                         const float G = __builtin_amdgcn_exp2f(-q2);
-                        const float alpha_raw = fminf(GGR_ALPHA_MAX, b.y * G);
-                        const bool valid = ok_sl[sl] && idx < last && q2 >= 0.0f && alpha_raw >= GGR_ALPHA_MIN;
+                        const float alpha_raw = fminf(amax, b.y * G);
+                        const bool valid = ok_sl[sl] && idx < last && q2 >= 0.0f && alpha_raw >= amin;
                         const float alpha = valid ? alpha_raw : 0.f;
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32 (1 ulp); __frcp_rn would expand to a 10-instruction IEEE division
                         T = T * inv;
@@ -298,6 +310,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                         g_m[sl] = mm; g_my[sl] = my_; g_myy[sl] = my_ * pyc;
                     }
                 }
+                // [budget: reduce-calls]
                 // ---- reductions.  lane = 8·y + x, so the three transposing levels (32, 16, 8) sum over the pixel
                 // ROWS and leave, in lane (slot, x), column x's partial sums of that slot: six arrays go through
                 // them (Σw·dp_{r,g,b}, Σm, Σm·y', Σm·y'²) instead of nine — the moments in x are products of the
@@ -311,6 +324,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 const float S0 = sum_cols8(Cm);   // (every lane: the pair value of the commit)
                 float t_z = 0.f;
                 if (HAS_DEPTH) t_z = sum_cols8(transpose_rows8(g_z, lane));
+                // [budget: commit]
                 // ---- commit: lane (slot, c) finishes value π(c) of its slot (transpose_cols8) -------------------
                 // The five geometric values are LINEAR in the six moment sums, with coefficients of the slot's entry:
                 // every lane forms them on its column's partial sums, and one transposing reduction over the columns

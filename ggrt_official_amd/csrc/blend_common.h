@@ -43,6 +43,7 @@ struct __attribute__((aligned(16))) StagedSplat {
     float4 c;  // b, z, qmax = 2·ln(255·opacity), id (bits)
 };
 
+// [budget: cull]
 // Exact minimum of q(d) = cxx·dx² + 2·cxy·dx·dy + cyy·dy² (d = mean − pixel) over the pixel box
 // [x0,x1]×[y0,y1], i.e. over d ∈ [dxl,dxh]×[dyl,dyh].  q is convex (the conic is positive definite) with its free
 // minimum at the mean (d = 0): the minimum over the box is 0 if the mean lies in it and otherwise sits on a face of the
@@ -74,6 +75,7 @@ __device__ __forceinline__ bool box_may_contribute(const float4 a, const float4 
     return qmin * 0.999f <= qmax + 1e-3f;
 }
 
+// [budget: evaluate]
 // ---- staged form of the conic ---------------------------------------------------------------------------------
 // The blend kernels evaluate G = exp(−q/2), q = cxx·dx² + 2·cxy·dx·dy + cyy·dy², once per (entry, pixel).  The
 // thread that stages an entry pre-multiplies the conic by k = log2(e)/2, so that the pixel loop needs
@@ -92,6 +94,7 @@ __device__ __forceinline__ float staged_q2(const float4 a, const float4 b, float
     const float u = fmaf(a.z, dx, a.w * dy);
     return fmaf(b.x * dy, dy, u * dx);
 }
+// [budget: cull]
 // box_may_contribute on a staged entry (the test is homogeneous in the conic, so it runs on k·q directly)
 __device__ __forceinline__ bool staged_box_may_contribute(const float4 a, const float4 b, float kqmax, float x0,
                                                           float y0, float x1, float y1) {

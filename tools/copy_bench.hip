@@ -56,6 +56,28 @@ __global__ void __launch_bounds__(256) write_only(v4f* __restrict__ dst, size_t 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = z;
 }
 
+// K arrays in, K arrays out, one float4 per thread and array (a structure-of-arrays streaming kernel like preprocess_fwd /
+// preprocess_bwd, which read ≈ 6 and write ≈ 7 separate arrays): does the copy rate survive K concurrent streams?
+// `pad4`: extra float4s between consecutive arrays (0: array k starts at k·n — with K a power of two every array starts on
+// the same HBM channel / bank phase; a few KB of padding staggers them)
+template <int K>
+__global__ void __launch_bounds__(256) copy_soa(const v4f* __restrict__ src, v4f* __restrict__ dst, size_t n4_per_array, size_t pad4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4_per_array) return;
+    v4f v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = src[(size_t)k * (n4_per_array + pad4) + i];
+#pragma unroll
+    for (int k = 0; k < K; k++) dst[(size_t)k * (n4_per_array + pad4) + i] = v[k];
+}
+// the same bytes with 4-byte accesses at a 12-byte stride (three scalar loads per "xyz" record, as means3D is read)
+__global__ void __launch_bounds__(256) copy_xyz(const float* __restrict__ src, float* __restrict__ dst, size_t n3) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    const float a = src[3 * i], b = src[3 * i + 1], c = src[3 * i + 2];
+    dst[3 * i] = a; dst[3 * i + 1] = b; dst[3 * i + 2] = c;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 template <class F> float best_ms(F f, int reps = 6) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -67,13 +89,13 @@ template <class F> float best_ms(F f, int reps = 6) {
     return best;
 }
 int main() {
-    for (size_t mb : {64, 256, 512, 1024}) {
+    for (size_t mb : {256, 1024}) {
         const size_t bytes = mb << 20, n4 = bytes / 16;
         v4f *a, *b; float* o;
         CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, 64));
         CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
         printf("== %zu MB per buffer\n", mb);
-        auto rep = [&](const char* name, float ms, double moved) { printf("  %-44s %8.3f ms  %7.1f GB/s\n", name, ms, moved / (ms * 1e-3) / 1e9); };
+        auto rep = [&](const char* name, float ms, double moved) { printf("  %-52s %8.3f ms  %7.1f GB/s\n", name, ms, moved / (ms * 1e-3) / 1e9); };
         rep("hipMemcpyDtoD", best_ms([&] { CK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0)); }), 2.0 * bytes);
         for (int wg : {4, 8, 16, 32, 64}) {
             const int g = 256 * wg; char nm[96];
@@ -99,6 +121,23 @@ int main() {
             rep("chunk u4 plain, 1 trip per WG", best_ms([&] { hipLaunchKernelGGL((copy_chunk<4, false, false>), dim3(g), dim3(256), 0, 0, a, b, n4, (size_t)1024); }), 2.0 * bytes);
             const int g1 = (int)((n4 + 255) / 256);
             rep("chunk u1 plain, 1 float4 per thread", best_ms([&] { hipLaunchKernelGGL((copy_chunk<1, false, false>), dim3(g1), dim3(256), 0, 0, a, b, n4, (size_t)256); }), 2.0 * bytes);
+        }
+        {
+            auto soa = [&](auto kern, int K, const char* nm) {
+                for (size_t pad4 : {(size_t)0, (size_t)(4096 + 64) / 16 * 13, (size_t)1234567 / 16 * 16}) {
+                    const size_t per = ((n4 - pad4 * K) / K) & ~(size_t)255;
+                    const int g = (int)(per / 256);
+                    char nm2[128]; snprintf(nm2, sizeof nm2, "%s pad %zu B", nm, pad4 * 16);
+                    rep(nm2, best_ms([&] { hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, a, b, per, pad4); }), 2.0 * per * K * 16);
+                }
+            };
+            soa(copy_soa<1>, 1, "SoA  1+1");
+            soa(copy_soa<2>, 2, "SoA  2+2");
+            soa(copy_soa<4>, 4, "SoA  4+4");
+            soa(copy_soa<8>, 8, "SoA  8+8");
+            soa(copy_soa<12>, 12, "SoA 12+12");
+            const size_t n3 = bytes / 12;
+            rep("xyz: 3 scalar loads/stores at 12-B stride", best_ms([&] { hipLaunchKernelGGL(copy_xyz, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, 0, (const float*)a, (float*)b, n3); }), 2.0 * n3 * 12);
         }
         rep("read only  u4 16 WG/CU", best_ms([&] { hipLaunchKernelGGL((read_only<4>), dim3(256 * 16), dim3(256), 0, 0, a, o, n4); }), 1.0 * bytes);
         rep("read only  u8 16 WG/CU", best_ms([&] { hipLaunchKernelGGL((read_only<8>), dim3(256 * 16), dim3(256), 0, 0, a, o, n4); }), 1.0 * bytes);
