@@ -205,6 +205,11 @@ class Workload:
                 "achieved_GBps": round(ab[k] / (kernel_ms[k] * 1e-3) / 1e9, 1),
                 "hbm_frac": round(ab[k] / (kernel_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
             for k in ("fwd_preprocess", "bwd_preprocess") if k in kernel_ms}
+        # SURVEY §8(d)'s forward figure counts the INPUTS only; the launch also writes what the later stages read: the 48-B
+        # splat record, packed rect 8, tiles_touched / clamp bits / sort key / sort value / radius 4 each = 76 B per Gaussian
+        out["streaming_kernels"]["fwd_preprocess"]["bytes_in_and_out"] = ab["fwd_preprocess"] + self.P * 76
+        if "bwd_preprocess" in out["streaming_kernels"]:
+            out["streaming_kernels"]["bwd_preprocess"]["bytes_in_and_out"] = ab["bwd_preprocess"]   # (SURVEY's already has both)
         # the kernels furthest below their own roofline: compulsory bytes ÷ HIP-event stage time
         out["binning_kernels"] = {
             name: {"ms": round(stages[key], 4), "compulsory_bytes": ab[ck],
@@ -749,8 +754,20 @@ def main():
             rec["hbm_copy_note"] = ("hbm_copy_GBps_measured: float4 streaming copy of 512 MB by the library's own kernel "
                                     "(csrc/util.hip, read + write counted); hbm_copy_GBps_torch_copy: torch's copy_ of the "
                                     "same size (the ceiling rounds 1-3 quoted)")
+            # what a structure-of-arrays streaming kernel can reach: the copy rate falls with the number of concurrent streams
+            # and depends on how the arrays are spaced (tools/copy_bench.hip, profiles/r04_copy_bench_soa.txt, 1 GB): 1 in +
+            # 1 out 6.15 TB/s, 4 + 4 5.2-5.6, 8 + 8 4.9 (arrays a power-of-two apart) … 5.7 (staggered); preprocess_fwd
+            # reads 5-6 arrays and writes 7, preprocess_bwd reads 7 and writes 5-6
+            rec["hbm_copy_GBps_multi_stream"] = {"8_in_8_out_worst_spacing": 4885.0, "8_in_8_out_staggered": 5680.0,
+                                                 "source": "profiles/r04_copy_bench_soa.txt (tools/copy_bench.hip; not measured in this run)"}
             for k, v in rec.get("streaming_kernels", {}).items():
                 v["frac_of_measured_copy"] = round(v["achieved_GBps"] / rec["hbm_copy_GBps_measured"], 4)
+                if v.get("traffic"):
+                    gbps = v["traffic"] / (v["ms"] * 1e-3) / 1e9
+                    v["traffic_GBps"] = round(gbps, 1)
+                    v["traffic_frac_of_measured_copy"] = round(gbps / rec["hbm_copy_GBps_measured"], 4)
+                    v["traffic_frac_of_multi_stream_copy"] = [round(gbps / 5680.0, 4), round(gbps / 4885.0, 4)]
+                    v["traffic_over_bytes_in_and_out"] = round(v["traffic"] / v["bytes_in_and_out"], 3)
         except Exception as e:
             log(f"copy bandwidth leg skipped: {type(e).__name__}: {e}")
         if valu:
