@@ -702,7 +702,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 //   dL/dcampos(view) −= the same term, summed over the Gaussians                                   (POSE)
 // Inside preprocess_bwd_kernel<·, MULTI> these phases cost that kernel its occupancy (the SH rows in LDS, 25 accumulators
 // + 25 basis values on top of the geometry backward's live state: 216-223 VGPRs, 2 waves per SIMD, 2.4 TB/s where the
-// one-view kernels reach 4.9; C5', 4 views: 438 µs → main kernel without them + this kernel).  Runs BEHIND
+// one-view kernels reach 4.9; C5', 4 views: 438 µs → main kernel without them + this kernel, see NOTES.md, old §8).  Runs BEHIND
 // the main kernel on the same stream: it adds to the dL/dmeans3D and to the camera rows that kernel wrote.
 // Reads per (view, Gaussian) the colour part of the blend's gradient record, the radius and the clamp bits; the SH rows
 // once, through LDS; writes the gradient rows through the same LDS in three row ranges of the block (whole 128-B lines).

@@ -214,7 +214,7 @@ def _rasterize_views(calls, aux=None):
     4 views at 480×352: 2.79 ms serial vs 2.87 ms on 4 streams, 3.44 ms with one host thread per stream —
     because at GGRt's sizes a view is host-bound (≈ 270 µs of launches + the `num_rendered` read-back per
     forward); the multi-stream autograd path also needed stream-lifetime care that is not worth carrying for
-    no gain.  The lever is a sync-free forward with fewer launches)"""
+    no gain.  The lever is a sync-free forward with fewer launches, NOTES.md (old §8).)"""
     outs = []
     for i, (settings, kw) in enumerate(calls):
         mean_gradients = torch.zeros_like(kw["means3D"], requires_grad=True)  # the `means2D` gradient sink

@@ -1,5 +1,5 @@
 // atomic_line_bench.hip — what a wave pays for committing per-record float atomics as 1, 2 or 3 vector
-// instructions (dev tool behind DESIGN.md §4 "atomic line transactions").
+// instructions (dev tool behind NOTES.md "Atomic line transactions").
 //
 // Layout as in blend_bwd: records of 16 floats (one 64-B line); lane l of a wave serves record slot l >> 3 with
 // value index l & 7; a batch = 8 random records.  Modes:

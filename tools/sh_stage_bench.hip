@@ -1,5 +1,5 @@
 // sh_stage_bench.hip — what bounds a preprocess-shaped streaming kernel whose per-Gaussian SH rows go through LDS
-// (dev tool behind DESIGN.md §4, preprocess rows).
+// (dev tool behind NOTES.md, old §4 preprocess rows).
 //
 // Shape of preprocess_fwd: 256 threads per block, one Gaussian per thread; 40 B of own inputs per thread, the block's
 // ROWF-float SH rows copied flat (float4, coalesced) into LDS, a barrier, ROWF LDS reads + FMAs per thread, 68 B
