@@ -286,10 +286,11 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         uint2* rect_sorted = nullptr;
         uint32_t *zero_area = nullptr, zero_words = 0;
         ggr::tile_list_gather_targets(plan, work, tiles, &rect_sorted, &zero_area, &zero_words);
-        // (preprocess already wrote the keys into g.keys_a and the identity permutation into g.vals_a)
+        // (preprocess already wrote the keys into g.keys_a; the values are the identity, formed by the sort's first pass)
         ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, (uint32_t)segs, &dk, &order, s,
                               /*hist_zeroed=*/true /*by preprocess_fwd*/,
                               /*block_max_ready=*/(uint32_t)((P1 + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS) * (uint32_t)vs.sets /*likewise*/,
+                              /*identity_vals=*/true /*preprocess_fwd writes no values: the first pass forms them*/,
                               g.rect, rect_sorted, zero_area, zero_words);
         KCHECK(dbg, s, "depth sort");
     }

@@ -155,10 +155,12 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     const int wave = tid >> 6, lane = tid & 63;
     // segments are dealt round robin to the workgroups, so that all of them progress together
     const uint32_t seg = blockIdx.x % nseg;
+    const bool vals_in_null = vals_in == nullptr;
     if (tid == 0) tile_sh = atomicAdd(&hist[GGR_HIST_TICKETS + pass * GGR_SORT_MAX_SEGMENTS + seg], 1u);
     {
         const size_t so = (size_t)seg * n;
-        keys_in += so; vals_in += so; keys_out += so; vals_out += so;
+        keys_in += so; keys_out += so; vals_out += so;
+        if (!vals_in_null) vals_in += so;
         if (GATHER) gather_dst += so;
     }
     const uint32_t w = hist[GGR_HIST_PARAMS];            // bits per digit (block-uniform)
@@ -188,7 +190,8 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
         const size_t idx = base + r * 64 + lane;
         const bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = valid ? vals_in[idx] : 0u;
+        // (vals_in == nullptr: the first pass of a sort whose values are the identity — the index in the whole array)
+        val[r] = !valid ? 0u : vals_in_null ? (uint32_t)((size_t)seg * n + idx) : vals_in[idx];
     }
     uint2 pay[GATHER ? ITEMS : 1];
     if (GATHER) {
@@ -456,7 +459,7 @@ const uint32_t* radix_sort_fault_word(const uint32_t* hist) { return hist + GGR_
 
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                       uint32_t* hist, size_t n, uint32_t segments, uint32_t** keys_out, uint32_t** vals_out,
-                      hipStream_t s, bool hist_zeroed, uint32_t block_max_ready, const uint2* gather_src, uint2* gather_dst,
+                      hipStream_t s, bool hist_zeroed, uint32_t block_max_ready, bool identity_vals, const uint2* gather_src, uint2* gather_dst,
                       uint32_t* zero_area, uint32_t zero_words) {
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     if (n > 0) {
@@ -480,7 +483,8 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
         hipLaunchKernelGGL(radix_global_hist_kernel, dim3(bps * S), dim3(GGR_HIST_THREADS), 0, s, kin, nseg, bps, hist,
                            block_max, nmax);
 #define GGR_PASS(GATHER_, ITEMS_, SRC_, DST_, ZA_, ZW_)                                                                    \
-    hipLaunchKernelGGL((radix_onesweep_kernel<GATHER_, ITEMS_>), dim3(ntiles * S), dim3(GGR_SORT_THREADS), 0, s, kin, vin,  \
+    hipLaunchKernelGGL((radix_onesweep_kernel<GATHER_, ITEMS_>), dim3(ntiles * S), dim3(GGR_SORT_THREADS), 0, s, kin,       \
+                       (p == 0 && identity_vals) ? (const uint32_t*)nullptr : (const uint32_t*)vin,                               \
                        kout, vout, nseg, p, ntiles, S, tree, hist, SRC_, DST_, ZA_, ZW_)
         for (int p = 0; p < GGR_SORT_PASSES; p++) {
             if (p == GGR_SORT_PASSES - 1 && gather_src) {

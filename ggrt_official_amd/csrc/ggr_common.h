@@ -8,7 +8,6 @@
 //                      fetch is ONE 48-B gather instead of three gathers from three SoA arrays
 //                      (f = view-space z or the caller's aux feature; qmax = 2·ln(255·opacity): the largest
 //                      dᵀ·conic·d at which α still reaches 1/255)
-//     tiles_touched[P] u32
 //     rect[P]          u32×2 packed tile rect (minx | miny<<16, maxx | maxy<<16)
 //     clamped[P]       u32   bit c set ⇔ SH colour channel c was clamped at 0
 //     cov3D[P]         6 × f32 (scale/rot path only; otherwise the caller's cov3D_precomp is used)
@@ -103,7 +102,6 @@ static inline size_t ggr_sort_hist_words(size_t n, size_t S = 1) {
 
 struct GeomLayout {
     float4* splat;
-    uint32_t* tiles_touched;
     uint2* rect;
     uint32_t* clamped;
     float* cov3D;
@@ -124,7 +122,6 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P, size_t segments = 
     size_t Pp = P ? P : 1;
     auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes); return r; };
     L.splat = (float4*)take(Pp * 48);
-    L.tiles_touched = (uint32_t*)take(Pp * 4);
     L.rect = (uint2*)take(Pp * 8);
     L.clamped = (uint32_t*)take(Pp * 4);
     L.cov3D = (float*)take(Pp * 24);
@@ -295,6 +292,7 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
                       uint32_t** vals_out, hipStream_t s,
                       bool hist_zeroed = false /*the caller already cleared ggr_sort_zero_words(n, segments)*/,
                       uint32_t block_max_ready = 0 /*> 0: that many key maxima are already in the work area*/,
+                      bool identity_vals = false /*vals_a holds nothing: the first pass uses val = index in the whole array*/,
                       const uint2* gather_src = nullptr /*last pass also writes gather_dst[pos] = gather_src[val]*/,
                       uint2* gather_dst = nullptr, uint32_t* zero_area = nullptr /*and clears these words*/,
                       uint32_t zero_words = 0);

@@ -98,8 +98,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float scale_modifier, const float* __restrict__ cov3D_precomp,
                       const float* __restrict__ aux_precomp, ViewSet vs, int W, int H,
                       int32_t* __restrict__ radii, float4* __restrict__ splat,
-                      uint32_t* __restrict__ depth_key, uint32_t* __restrict__ sort_vals,
-                      uint32_t* __restrict__ tiles_touched,
+                      uint32_t* __restrict__ depth_key,
                       uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
                       float* __restrict__ cov3D_out, uint32_t* __restrict__ zero_area, uint32_t zero_words,
                       uint32_t* __restrict__ block_max, InputForm inf) {
@@ -120,7 +119,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     if (cov3D_precomp) cov3D_precomp += (size_t)inf.cov_stride * in_off;
     if (scales) { scales += 3 * in_off; rotations += 4 * in_off; }
     if (aux_precomp) aux_precomp += st_off;
-    radii += st_off; splat += 3 * st_off; depth_key += st_off; sort_vals += st_off; tiles_touched += st_off;
+    radii += st_off; splat += 3 * st_off; depth_key += st_off;
     rect += st_off; clamped_out += st_off;
     if (cov3D_out) cov3D_out += 6 * st_off;
     vs.view += 16 * v0; vs.proj += 16 * v0; vs.campos += 3 * v0;
@@ -369,8 +368,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (in_range) {
             radii[o] = rad_out;
             depth_key[o] = key_out;       // written straight into the depth sort's key / value input buffers
-            sort_vals[o] = (uint32_t)(st_off + o);   // global (view, Gaussian) index (saves a device memcpy and an iota launch)
-            tiles_touched[o] = tiles_out;
+            // (no sort VALUES are written: the depth sort's first pass forms the identity — the global (view, Gaussian) index —
+            //  itself; and no tiles_touched: it is the area of the packed rect.  Two output streams and 8 B per Gaussian less)
             rect[o] = rect_out;
             clamped_out[o] = clamp_bits;
             splat[3 * o] = s0;
@@ -410,7 +409,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
 #define GGR_LAUNCH_PFWD(MULTI_, KC_)                                                                                      \
     hipLaunchKernelGGL((preprocess_fwd_kernel<MULTI_, KC_>), dim3(blocks, vs.sets), dim3(threads), lds, s, P, D, M, means3D, shs,  \
                        colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp, aux_precomp, vs, W, H, \
-                       radii, g.splat, g.keys_a, g.vals_a, g.tiles_touched, g.rect, g.clamped, g.cov3D, g.hist,          \
+                       radii, g.splat, g.keys_a, g.rect, g.clamped, g.cov3D, g.hist,          \
                        zero_words, g.hist + zero_words, inf)
     if (vs.vps > 1) GGR_LAUNCH_PFWD(true, 0);
     else if (kc == 16) GGR_LAUNCH_PFWD(false, 16);
@@ -433,7 +432,7 @@ void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, u
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
 }
 
-__global__ void unpack_geom_kernel(int P, const float4* __restrict__ splat, const uint32_t* __restrict__ tt,
+__global__ void unpack_geom_kernel(int P, const float4* __restrict__ splat, const uint2* __restrict__ rect,
                                    const uint32_t* __restrict__ cl, float* depth, float* xy, float* co,
                                    float* rgb, int32_t* tiles, uint8_t* clamped) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,14 +442,17 @@ __global__ void unpack_geom_kernel(int P, const float4* __restrict__ splat, cons
     if (xy) { xy[2 * i] = s0.x; xy[2 * i + 1] = s0.y; }
     if (co) { co[4 * i] = s0.z; co[4 * i + 1] = s0.w; co[4 * i + 2] = s1.x; co[4 * i + 3] = s1.y; }
     if (rgb) { rgb[3 * i] = s1.z; rgb[3 * i + 1] = s1.w; rgb[3 * i + 2] = s2.x; }
-    if (tiles) tiles[i] = (int32_t)tt[i];
+    if (tiles) {   // tiles_touched = area of the packed tile rect (minx | miny << 16, maxx | maxy << 16)
+        const uint2 rc = rect[i];
+        tiles[i] = (int32_t)(((rc.y & 0xFFFFu) - (rc.x & 0xFFFFu)) * ((rc.y >> 16) - (rc.x >> 16)));
+    }
     if (clamped) { const uint32_t c = cl[i]; clamped[3 * i] = c & 1; clamped[3 * i + 1] = (c >> 1) & 1; clamped[3 * i + 2] = (c >> 2) & 1; }
 }
 
 void launch_unpack_geom(GeomLayout g, int P, float* depth, float* xy, float* conic_opacity, float* rgb,
                         int32_t* tiles_touched, uint8_t* clamped, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(unpack_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.splat, g.tiles_touched,
+    hipLaunchKernelGGL(unpack_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.splat, g.rect,
                        g.clamped, depth, xy, conic_opacity, rgb, tiles_touched, clamped);
 }
 
