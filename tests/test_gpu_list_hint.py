@@ -59,10 +59,30 @@ def test_a_guess_that_is_too_small_repeats_the_call():
         want_small, want_big = _run(small, dL), _run(big, dL)
         assert want_big[4] > 1.5 * want_small[4]
         ggrt_official_amd.set_list_hint(True)
+        ggrt_official_amd.clear_list_hints()
+        ggrt_official_amd.list_hint_stats(reset=True)
         _same(want_small, _run(small, dL))       # notes the small N
+        assert ggrt_official_amd.list_hint_stats() == {"hinted": 0, "missed": 0, "exact": 1}
         got_big = _run(big, dL)                  # guess too small → GGR_E_CAPACITY inside → repeated in upstream's order
         _same(want_big, got_big)
+        assert ggrt_official_amd.list_hint_stats() == {"hinted": 0, "missed": 1, "exact": 1}
         _same(want_big, _run(big, dL))           # now guessed from the big N
         _same(want_small, _run(small, dL))       # (an over-sized buffer is fine)
+        assert ggrt_official_amd.list_hint_stats(reset=True) == {"hinted": 2, "missed": 1, "exact": 1}
+        assert ggrt_official_amd.list_hint_stats() == {"hinted": 0, "missed": 0, "exact": 0}
     finally:
         ggrt_official_amd.set_list_hint(prev)
+
+
+def test_streaming_copy_yardstick():
+    """`ggr_debug_copy` (bench.py's HBM ceiling): copies, in both launch forms, and refuses misaligned arguments."""
+    from ggrt_official_amd import _lib
+    lib = _lib.load()
+    a = torch.randn(1 << 20, device=dev)
+    for blocks in (0, 512):
+        b = torch.zeros_like(a)
+        assert lib.ggr_debug_copy(a.data_ptr(), b.data_ptr(), a.numel() * 4, blocks, torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+    assert lib.ggr_debug_copy(a.data_ptr() + 4, b.data_ptr(), 1024, 0, None) == 1      # GGR_E_INVALID
+    assert lib.ggr_debug_copy(a.data_ptr(), b.data_ptr(), 1000, 0, None) == 1
