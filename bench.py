@@ -453,6 +453,10 @@ def main():
     dist_on = world > 1 or args.force_dist   # the exchange runs (a forced one-rank group reduces over itself)
     if args.device is not None:
         local = args.device
+    elif torch.cuda.device_count() and local >= torch.cuda.device_count():
+        # a launcher that narrows every rank's visibility to ONE device (HIP_VISIBLE_DEVICES per rank): that device is index 0
+        # here; the PCI-bus check below still proves that no two ranks share a physical GPU
+        local = local % torch.cuda.device_count()
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     # one process per GPU: this rank's current device is LOCAL_RANK's, and no two ranks of the job share a physical device

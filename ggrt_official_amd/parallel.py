@@ -34,6 +34,8 @@ def init_from_env(expected_world: int | None = None, backend: str | None = None,
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
+            if torch.cuda.device_count() and local >= torch.cuda.device_count():
+                local = local % torch.cuda.device_count()   # (per-rank device visibility: the one visible device is index 0)
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device(f"cuda:{local}")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
