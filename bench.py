@@ -206,8 +206,9 @@ class Workload:
                 "hbm_frac": round(ab[k] / (kernel_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
             for k in ("fwd_preprocess", "bwd_preprocess") if k in kernel_ms}
         # SURVEY §8(d)'s forward figure counts the INPUTS only; the launch also writes what the later stages read: the 48-B
-        # splat record, packed rect 8, tiles_touched / clamp bits / sort key / sort value / radius 4 each = 76 B per Gaussian
-        out["streaming_kernels"]["fwd_preprocess"]["bytes_in_and_out"] = ab["fwd_preprocess"] + self.P * 76
+        # splat record, packed rect 8, clamp bits / sort key / radius 4 each = 68 B per Gaussian (round 4: no tiles_touched
+        # array, no sort values — two streams less)
+        out["streaming_kernels"]["fwd_preprocess"]["bytes_in_and_out"] = ab["fwd_preprocess"] + self.P * 68
         if "bwd_preprocess" in out["streaming_kernels"]:
             out["streaming_kernels"]["bwd_preprocess"]["bytes_in_and_out"] = ab["bwd_preprocess"]   # (SURVEY's already has both)
         # the kernels furthest below their own roofline: compulsory bytes ÷ HIP-event stage time

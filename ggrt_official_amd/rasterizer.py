@@ -239,6 +239,8 @@ def _forward_with_guess(call, fout, holder, lib, dev, W, H, key, user_capacity, 
         fout.capacity_is_hint = 0
     _check(call(), "ggr_forward")
     _note_rendered(key, int(fout.num_rendered))
+    if guess == 0:
+        _hint_stats["exact"] += 1
 
 
 _sh_warned = False
