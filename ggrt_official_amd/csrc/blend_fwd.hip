@@ -25,6 +25,7 @@ namespace ggr {
                        // C3 150 / 150 / 176 µs, C5′ 195 / 173 / 173 — at 8 the compiler keeps all eight records live)
 #endif
 
+// [budget: prologue]  (scripts/valu_budget.py)
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
@@ -90,6 +91,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     if (lane == 0) wave_done[wave] = quad_live ? 0 : 1;
     bool wdone = !quad_live;
 
+    // [budget: stage]
     // the list ids of a batch are requested one batch ahead: id → record is a chain of two global round trips,
     // only the second is left on the batch's critical path
     uint32_t g_next = tid < total ? point_list[range.x + tid] : 0u;
@@ -112,6 +114,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             ck[0] = T; ck[hw] = C0; ck[2 * hw] = C1; ck[3 * hw] = C2; ck[4 * hw] = Dz;
         }
         if (!wdone) {
+            // [budget: cull]
             // ---- cull: this wave's survivors of the whole batch, compacted into a wave-private list of LDS byte
             // offsets (u16: 255·48 < 2^16).  Round 2 walked the ballot mask with s_ff1 / s_and per survivor and
             // combined its per-pixel conditions in scalar mask registers: ≈ 20 SALU per ≈ 22 VALU instructions, and a
@@ -137,6 +140,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             if (lane < SURV_GROUP) my_surv[ns + lane] = (uint16_t)(BATCH * 48);  // pad with the null record (opacity 0)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // [budget: evaluate]
             const char* stage_bytes = reinterpret_cast<const char*>(stage);
             uint32_t hit_off = 0xFFFFFFFFu;   // LDS offset of the pixel's latest contributor in this batch (none yet)
             for (int k0 = 0; k0 < ns; k0 += SURV_GROUP) {
@@ -171,6 +175,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             if (wdone && lane == 0) wave_done[wave] = 1;
         }
     }
+    // [budget: epilogue]
     // the tile's last contributor: the backward replays the list entries before it (and nothing else)
     uint32_t wl = last;
 #pragma unroll

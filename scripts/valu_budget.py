@@ -21,6 +21,7 @@ from valu_mix import COST, ROOT, classify  # noqa: E402
 
 SRC = os.path.join(ROOT, "ggrt_official_amd", "csrc")
 RB = 8
+SURV_GROUP = 4
 
 
 def markers(path):
@@ -35,10 +36,14 @@ def markers(path):
 
 
 def main():
+    fwd = "--fwd" in sys.argv          # the forward blend instead: one trip of its survivor loop = SURV_GROUP (4) survivors
+    if fwd:
+        sys.argv.remove("--fwd")
+    src_name = "blend_fwd.hip" if fwd else "blend_bwd.hip"
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-munsafe-fp-atomics",
-                        "-gline-tables-only", "-S", "--cuda-device-only", "-o", out, os.path.join(SRC, "blend_bwd.hip")],
+                        "-gline-tables-only", "-S", "--cuda-device-only", "-o", out, os.path.join(SRC, src_name)],
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
     files = {}
@@ -46,9 +51,9 @@ def main():
         m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
         if m:
             files[int(m.group(1))] = os.path.basename(m.group(3) or m.group(2))
-    phase_of = {"blend_bwd.hip": markers(os.path.join(SRC, "blend_bwd.hip")),
+    phase_of = {src_name: markers(os.path.join(SRC, src_name)),
                 "blend_common.h": markers(os.path.join(SRC, "blend_common.h"))}
-    start = next(i for i, l in enumerate(text) if re.match(r"^_ZN3ggr16blend_bwd_kernelILb0", l))
+    start = next(i for i, l in enumerate(text) if re.match(r"^_ZN3ggr16blend_fwd_kernel" if fwd else r"^_ZN3ggr16blend_bwd_kernelILb0", l))
     end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))
     body = text[start:end]
     depth, cur, in_label = [], 0, False
@@ -74,7 +79,8 @@ def main():
             continue
         t = table.setdefault(phase, {})
         t[c] = t.get(c, 0) + 1
-    res = {"costs_cycles_per_wave64_inst": COST, "slots_per_reduction_trip": RB, "phases": {}}
+    rb = SURV_GROUP if fwd else RB
+    res = {"kernel": "blend_fwd" if fwd else "blend_bwd", "costs_cycles_per_wave64_inst": COST, "slots_per_trip": rb, "phases": {}}
     tot_i = tot_c = 0
     for ph, mix in sorted(table.items()):
         n = sum(mix.values())
@@ -82,18 +88,18 @@ def main():
         tot_i += n
         tot_c += cyc
         res["phases"][ph] = {"static_valu": mix, "insts": n, "issue_cycles": cyc}
-    per_batch = [p for p in res["phases"] if p not in ("cull", "stage", "prologue")]
+    per_batch = [p for p in res["phases"] if p not in ("cull", "stage", "prologue", "epilogue")]
     bi = sum(res["phases"][p]["insts"] for p in per_batch)
     bc = sum(res["phases"][p]["issue_cycles"] for p in per_batch)
-    res["per_reduction_trip"] = {"insts": bi, "issue_cycles": bc, "insts_per_slot": round(bi / RB, 1),
-                                 "issue_cycles_per_slot": round(bc / RB, 1),
+    res["per_reduction_trip"] = {"insts": bi, "issue_cycles": bc, "insts_per_slot": round(bi / rb, 1),
+                                 "issue_cycles_per_slot": round(bc / rb, 1),
                                  "share_of_cycles": {p: round(res["phases"][p]["issue_cycles"] / bc, 3) for p in per_batch}}
     if "cull" in res["phases"]:
         res["per_cull_trip_64_entries"] = res["phases"]["cull"]
     res["hot_loops_total"] = {"insts": tot_i, "issue_cycles": tot_c}
     if len(sys.argv) >= 5 and sys.argv[1] == "--dynamic":
         slots, staged, insts = (float(x) for x in sys.argv[2:5])
-        trips = slots / RB * 1.045          # (the last trip of a wave's batch is partly filled: ≈ 11.4 trips per wave-batch)
+        trips = slots / rb * (1.02 if fwd else 1.045)   # (the last trip of a wave's batch is partly filled)
         culls = staged / 64.0
         est = trips * bi + culls * res["phases"].get("cull", {}).get("insts", 0)
         res["dynamic_check"] = {"surviving_slots": slots, "staged_wave_entry_pairs": staged, "reduction_trips": round(trips),
