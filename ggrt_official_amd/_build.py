@@ -39,15 +39,42 @@ HASH_MARKER = b"ggr-source-hash:"   # followed by 64 hex digits inside the .so (
 last_build: dict = {}
 
 
+def _code_only(text: str) -> str:
+    """C / C++ source without comments and without insignificant white space (string and character literals kept as they
+    are): what the compiler sees.  A comment edit must neither force a rebuild nor mark a profile as stale."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == "/" and i + 1 < n and text[i + 1] == "/":
+            while i < n and text[i] != "\n":
+                i += 1
+        elif c == "/" and i + 1 < n and text[i + 1] == "*":
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        elif c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    lines = (" ".join(l.split()) for l in "".join(out).split("\n"))
+    return "\n".join(l for l in lines if l)
+
+
 def source_hash() -> str:
-    """sha256 over every translation unit and header of the library (name + contents) and the compiler flags.  The
-    library carries the hash it was built from (``ggr_source_hash()``); ``_lib.load()`` refuses a library whose hash
-    differs from ``csrc/`` as it is now — a stale ``.so`` can neither pass for a build nor be measured by accident."""
+    """sha256 over the CODE of every translation unit and header of the library (name + contents without comments and
+    insignificant white space) and the compiler flags.  The library carries the hash it was built from
+    (``ggr_source_hash()``); ``_lib.load()`` refuses a library whose hash differs from ``csrc/`` as it is now — a stale
+    ``.so`` can neither pass for a build nor be measured by accident."""
     h = hashlib.sha256()
     for name in SOURCES + HEADERS:
         h.update(os.path.basename(name).encode() + b"\0")
-        with open(os.path.join(CSRC, name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(CSRC, name), "r", encoding="utf-8") as f:
+            h.update(_code_only(f.read()).encode("utf-8"))
         h.update(b"\0")
     h.update(" ".join(FLAGS).encode())
     for k in sorted(EXTRA_FLAGS):
