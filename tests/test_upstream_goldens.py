@@ -187,6 +187,23 @@ def test_exporter_and_consumer_round_trip(tmp_path, sh_cap, with_debug, ret_len)
     assert ("out_depth" in z.files) == (ret_len == 3)
 
 
+@pytest.mark.gpu
+def test_hip_consumer_on_stub_exports(tmp_path):
+    """The `-m gpu` consumer (`_check_hip_against`) run on files the exporter wrote from the oracle-served stub: proves that
+    the day real exports appear the HIP comparison itself works (all input forms, the SH-cap detection) — not parity."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import export_upstream_goldens as ex
+    finally:
+        sys.path.pop(0)
+    for cap in (3, 4):
+        out = tmp_path / f"cap{cap}"
+        files = ex.export(str(out), mod=_stub_extension(cap, False, 3), device="cpu")
+        assert len(files) == len(ex.SCENES)
+        for f in files:
+            _check_hip_against(f)
+
+
 def test_exporter_refuses_the_repository_shim():
     """Run from this repository, `import diff_gaussian_rasterization` finds the import-name shim of the HIP build — the
     exporter must not mistake it for the extension."""
