@@ -498,8 +498,11 @@ def main():
             exchange(i, blocking)
 
     log(f"scene {args.config} resident on {dev}; world {world}; warmup {args.warmup}")
+    resident_bytes = torch.cuda.memory_allocated(dev)     # scene + upstream gradient (+ exchange buffers): inputs, not the path's state
+    torch.cuda.reset_peak_memory_stats(dev)
     elapsed, per_step = timed_steps(step, args.steps, args.warmup, dev, barrier=parallel.barrier,
                                     finish=drain if dist_on else None)
+    peak_bytes = torch.cuda.max_memory_allocated(dev)
     elapsed = parallel.max_over_ranks(elapsed, dev)
     log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.3f} ms/step")
 
@@ -745,7 +748,22 @@ def main():
                        "parallelism": f"frames x{world}"},
             "step_ms_hip_events": percentiles(per_step),
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "t_fwd_ms": round(sum(v for k, v in stages.items() if k.startswith("fwd_")), 4),
+            "t_bwd_ms": round(sum(v for k, v in stages.items() if k.startswith("bwd_")), 4),
         }
+        # peak bytes.  What the step holds on the device beyond its resident inputs (the library's caller-owned
+        # buffers by their size queries + the output and gradient tensors), and torch's high-water mark over the timed loop
+        try:
+            from ggrt_official_amd import _lib as _l
+            _lb = _l.load()
+            rec["memory"] = {
+                "peak_allocated_bytes": int(peak_bytes), "resident_inputs_bytes": int(resident_bytes),
+                "step_state_peak_bytes": int(peak_bytes - resident_bytes),
+                "buffers": {"geom": int(_lb.ggr_geom_bytes(P)), "image": int(_lb.ggr_image_bytes(W, H)),
+                            "work": int(_lb.ggr_work_bytes(P, W, H)), "tile_lists": int(_lb.ggr_binning_bytes(N_built, W, H)),
+                            "backward_scratch": int(_lb.ggr_backward_scratch_bytes(P))}}
+        except Exception as e:
+            log(f"memory record skipped: {type(e).__name__}: {e}")
         rec.update(rf)
         # the blend's algorithmic flops, F = 20 · Σ_tiles |list| · 256 forward (× 2.5 backward), against
         # the kernels' HIP-event times (the figures exceed the fp32 vector peak where the exact quadrant cull never
