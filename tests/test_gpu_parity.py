@@ -141,6 +141,29 @@ def test_argument_errors_match_upstream():
           rotations=sc.rotations, cov3D_precomp=sc.cov3D)
 
 
+@pytest.mark.parametrize("scale", [0.5, 2.0])
+def test_scene_scale_invariance(scale):
+    """SURVEY A.6 on the HIP path: (s·means, s²·cov) seen from the origin renders the same image (s a power of two: same radii;
+    the image to the 1e-7 of the rule's unscaled `w + 1e-7`), depth × s — and the `input_scale` form of the ABI, which applies
+    s on load, is bit-identical to scaling the tensors beforehand."""
+    import copy
+    from ggrt_official_amd import GaussianRasterizer
+    sc = make_scene(20000, 160, 112, sh_degree=3, profile="A", seed=13)
+    s = sc.to("cuda:0")
+
+    def render(means, cov, rs):
+        with torch.no_grad():
+            return GaussianRasterizer(rs)(means3D=means, means2D=torch.zeros_like(means), opacities=s.opacities, shs=s.shs,
+                                          cov3D_precomp=cov)
+    c0, r0, d0 = render(s.means3D, s.cov3D, s.settings())
+    c1, r1, d1 = render(s.means3D * scale, s.cov3D * (scale * scale), s.settings())
+    c2, r2, d2 = render(s.means3D, s.cov3D, s.settings()._replace(input_scale=torch.tensor([scale], device="cuda:0")))
+    assert torch.equal(c1, c2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    assert torch.equal(r1, r0)
+    check_image(c1.cpu().numpy(), c0.cpu().numpy(), tag=f"scale-invariance:{scale}")      # (the usual bars: the rule's own
+    check_image((d1 / scale).cpu().numpy(), d0.cpu().numpy(), name="depth", tag=f"scale-invariance:{scale}:depth")  # epsilon does not scale)
+
+
 def test_forward_is_deterministic():
     from ggrt_official_amd import GaussianRasterizer
     sc = make_scene(20000, 200, 120, sh_degree=2, seed=4).to("cuda:0")

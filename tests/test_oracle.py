@@ -125,6 +125,24 @@ def test_principal_point_shift_moves_the_splat():
     np.testing.assert_allclose(b.xy[0] - a.xy[0], [4.0, -2.0], atol=1e-4)
 
 
+@pytest.mark.parametrize("scale", [0.5, 2.0])
+def test_scene_scale_invariance(scale):
+    """rendering (s·means, s²·cov) from a camera at the origin equals the original — what the call site's
+    1/near renormalisation (`cuda_splatting.py:66-73`) relies on.  (Powers of two: the scaling itself is exact in fp32, so radii
+    and lists agree entry for entry; the image to the 1e-7 that the rule's own `p_hom.w + 1e-7` — which does not scale — moves
+    the splat centres; the depth output scales by s.  Depths stay clear of the fixed 0.2 near cull.)"""
+    sc = make_scene(1500, 96, 64, sh_degree=2, profile="A", seed=11)
+    st = oracle_forward(sc)
+    import copy
+    sc2 = copy.copy(sc)
+    sc2.means3D, sc2.cov3D = sc.means3D * scale, sc.cov3D * (scale * scale)
+    st2 = oracle_forward(sc2)
+    assert np.array_equal(st.radii, st2.radii) and st.num_rendered == st2.num_rendered
+    assert np.array_equal(st.point_list, st2.point_list)
+    np.testing.assert_allclose(st2.color, st.color, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(st2.out_depth, st.out_depth * scale, rtol=1e-5, atol=1e-6)
+
+
 def test_sh_dc_and_degree4_stride25():
     sc = make_scene(400, 48, 40, sh_degree=3, seed=3)
     st3 = oracle_forward(sc)
