@@ -143,6 +143,30 @@ class Workload:
         color.backward(self.dL)  # the upstream gradient dL/dcolor goes straight into the rasterizer's backward
         return color
 
+    def fwd_bwd_event_times(self, n: int = 30) -> dict:
+        """Forward and backward of the SAME steps the headline times (default mode, no stage profiling — so no host wait for
+        num_rendered between the tile-list kernels), each bracketed by HIP events on the launch stream: medians in ms."""
+        if self.fwd_only:
+            return {}
+        # (no synchronisation inside the loop: the queue stays full, so that an event interval is device time, not the
+        #  host's launch latency after an idle device)
+        evs = []
+        for i in range(n + 3):
+            for t in self.leaves:
+                t.grad = None
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            color, _, _ = self.rast(means3D=self.means, means2D=self.means2D, opacities=self.op, shs=self.shs,
+                                    cov3D_precomp=self.cov)
+            e1.record()
+            color.backward(self.dL)
+            e2.record()
+            evs.append((e0, e1, e2))
+        torch.cuda.synchronize(self.dev)
+        f = [e0.elapsed_time(e1) for e0, e1, _ in evs[3:]]
+        b = [e1.elapsed_time(e2) for _, e1, e2 in evs[3:]]
+        return {"fwd_ms": percentiles(f)["median"], "bwd_ms": percentiles(b)["median"], "steps": n}
+
     def num_rendered(self, reference: bool = True) -> int:
         """List entries of this frame.  `reference=True`: N_dup of the REFERENCE's emit rule (every tile of the 3σ square,
         SURVEY.md §8d) — the figure the algorithmic bytes are defined with, and what `reference_rects=True` builds;
@@ -751,6 +775,14 @@ def main():
             "t_fwd_ms": round(sum(v for k, v in stages.items() if k.startswith("fwd_")), 4),
             "t_bwd_ms": round(sum(v for k, v in stages.items() if k.startswith("bwd_")), 4),
         }
+        # the same two figures without the stage profiling's synchronisations (the stage sum contains the host's wait for
+        # num_rendered, which the default mode's list-size guess removes): HIP events around forward and backward
+        try:
+            ev_fb = wl.fwd_bwd_event_times()
+            if ev_fb:
+                rec["t_fwd_ms_events"], rec["t_bwd_ms_events"] = ev_fb["fwd_ms"], ev_fb["bwd_ms"]
+        except Exception as e:
+            log(f"forward/backward event leg skipped: {type(e).__name__}: {e}")
         # peak bytes.  What the step holds on the device beyond its resident inputs (the library's caller-owned
         # buffers by their size queries + the output and gradient tensors), and torch's high-water mark over the timed loop
         try:
@@ -765,6 +797,11 @@ def main():
         except Exception as e:
             log(f"memory record skipped: {type(e).__name__}: {e}")
         rec.update(rf)
+        if rec.get("t_fwd_ms_events"):
+            rfw = rec["render_forward"]
+            rfw["ms_events"] = rec["t_fwd_ms_events"]
+            rfw["hbm_frac_events"] = round(rfw["algorithmic_bytes"] / (rfw["ms_events"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            rfw["hbm_frac_built_events"] = round(rfw["algorithmic_bytes_built"] / (rfw["ms_events"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         # the blend's algorithmic flops, F = 20 · Σ_tiles |list| · 256 forward (× 2.5 backward), against
         # the kernels' HIP-event times (the figures exceed the fp32 vector peak where the exact quadrant cull never
         # evaluates most of those pairs), and the streaming ceiling measured on this part
