@@ -135,7 +135,11 @@ def load():
     # and measured).  GGR_SKIP_SOURCE_HASH=1: dev builds only (scripts/build_variants.sh ships several libraries).
     if os.environ.get("GGR_SKIP_SOURCE_HASH", "0") != "1":
         from . import _build
-        built, want = lib.ggr_source_hash().decode("ascii", "replace"), _build.source_hash()
+        built = lib.ggr_source_hash().decode("ascii", "replace")
+        try:
+            want = _build.source_hash()
+        except FileNotFoundError:   # a binary-only installation (no csrc/ next to the library): nothing to compare with
+            want = built
         if built != want:
             raise ImportError(
                 f"{LIB_PATH} was built from other sources than {_build.CSRC} holds now (library {built[:12]}…, tree "

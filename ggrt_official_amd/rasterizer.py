@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import threading
 from typing import NamedTuple, Optional
 
@@ -150,7 +151,7 @@ def _check(rc: int, what: str):
 _GGR_E_CAPACITY = 5
 _hint_lock = threading.Lock()
 _hints: dict = {}
-_HINTS_ON = __import__("os").environ.get("GGR_LIST_HINT", "1") != "0"
+_HINTS_ON = os.environ.get("GGR_LIST_HINT", "1") != "0"
 
 
 def set_list_hint(enabled: bool) -> bool:
@@ -254,7 +255,7 @@ def _sh_cap(rs, M: int) -> int:
     global _sh_warned
     cap = int(getattr(rs, "sh_max_degree", 0) or 0)
     if cap == 0:
-        cap = int(__import__("os").environ.get("GGR_SH_MAX_DEGREE", "0") or 0)
+        cap = int(os.environ.get("GGR_SH_MAX_DEGREE", "0") or 0)
     if cap not in (0, 3, 4):
         raise RuntimeError("sh_max_degree must be 3 or 4 (0 = not chosen)")
     if cap == 0 and not _sh_warned and int(rs.sh_degree) >= 4 and M >= 25:

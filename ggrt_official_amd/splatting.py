@@ -21,6 +21,7 @@ Reference quirks kept on purpose (drop-in parity):
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from math import isqrt
 from typing import Literal, Optional
@@ -36,7 +37,7 @@ DepthRenderingMode = Literal["depth", "disparity", "relative_disparity", "log"]
 # 3: what the rasterizer family behind the reference's live call site does with GGRt's sh_degree = 4 / 25
 # coefficients; 4 if the installed extension being replaced evaluates band 4; 0 = not chosen (3,
 # with one warning from the rasterizer the first time coefficients 16.. go unused).
-SH_MAX_DEGREE = int(__import__("os").environ.get("GGR_SH_MAX_DEGREE", "0") or 0)
+SH_MAX_DEGREE = int(os.environ.get("GGR_SH_MAX_DEGREE", "0") or 0)
 
 
 def set_sh_max_degree(cap: int) -> int:
