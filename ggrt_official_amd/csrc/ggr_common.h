@@ -61,6 +61,43 @@
 #define GGR_MAX_WIDTH_TILES (64 * GGR_COUNT_SLOTS)  // one tile row must fit a wave's slots: 768 tiles = 12 288 px
 #define GGR_COUNT_GROUPS 8 // groups of count workgroups: the prefix over workgroups runs per group (T·groups-way parallel)
 
+// ---- streaming accesses of the two preprocess kernels (round 4) ------------------------------------------------------------
+// What this launch set never reads again — the gradient tensors, radii, clamp bits — is stored NON-TEMPORALLY, and what
+// preprocess_bwd reads exactly once in whole lines — SH rows, gradient records, means, covariances — is loaded so: the lines
+// neither stay in L2 / the Infinity Cache nor linger there dirty.  Measured at C3 (same box, `scripts/run_variants`-style A/B,
+// HIP-event medians of 200 steps): step 0.885 → 0.861 ms; preprocess_bwd 0.129 → 0.118 ms, and preprocess_fwd — whose only
+// change is 8 B per Gaussian of radii / clamp-bit stores — 0.075 → 0.063 ms: 245 MB of plainly stored gradients of the
+// PREVIOUS step were still being written back while it streamed.  What did not help or hurt (NOTES r4): non-temporal loads of
+// the forward's inputs (=), of SH rows read a third at a time (the thirds share lines: +0.022 ms), non-temporal stores of the
+// splat records (re-read by the blend: =), of the image (=), of the scratch clearing (=).  (-DGGR_NT=0: plain accesses.)
+#ifndef GGR_NT
+#define GGR_NT 1
+#endif
+#if defined(__HIPCC__)
+typedef float ggr_v4f __attribute__((ext_vector_type(4)));
+#if GGR_NT
+__device__ __forceinline__ float4 ggr_ld_f4(const float* p) {
+    const ggr_v4f v = __builtin_nontemporal_load(reinterpret_cast<const ggr_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ggr_ld(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void ggr_st_f4(float* p, float4 v) {
+    ggr_v4f w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<ggr_v4f*>(p));
+}
+__device__ __forceinline__ void ggr_st(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void ggr_st(int32_t* p, int32_t v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void ggr_st(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ float4 ggr_ld_f4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float ggr_ld(const float* p) { return *p; }
+__device__ __forceinline__ void ggr_st_f4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void ggr_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void ggr_st(int32_t* p, int32_t v) { *p = v; }
+__device__ __forceinline__ void ggr_st(uint32_t* p, uint32_t v) { *p = v; }
+#endif
+#endif
+
 static inline size_t ggr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static inline size_t ggr_sort_blocks(size_t n) { return (n + GGR_SORT_TILE - 1) / GGR_SORT_TILE; }

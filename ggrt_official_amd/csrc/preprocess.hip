@@ -142,7 +142,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // this thread's own inputs are requested BEFORE the SH staging, so that their round trip overlaps it
     // (clamped index: threads past P load Gaussian P-1 and drop it)
     const size_t il = (size_t)min(i, P - 1);
-    const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];
+    const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];   // (non-temporal: no difference)
     const float opac = opacities[il];
     float cin[6], rin[4] = {0.f, 0.f, 0.f, 0.f};
     if (cov3D_precomp) {
@@ -366,14 +366,14 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             s2 = make_float4(rgb[2], feat, 2.f * logf(255.f * opac), 0.f);  // .z = qmax for the box cull
         }
         if (in_range) {
-            radii[o] = rad_out;
+            ggr_st(radii + o, rad_out);     // (an output tensor and the clamp bits: not read again before the backward)
             depth_key[o] = key_out;       // written straight into the depth sort's key / value input buffers
             // (no sort VALUES are written: the depth sort's first pass forms the identity — the global (view, Gaussian) index —
             //  itself; and no tiles_touched: it is the area of the packed rect.  Two output streams and 8 B per Gaussian less)
             rect[o] = rect_out;
-            clamped_out[o] = clamp_bits;
-            splat[3 * o] = s0;
-            splat[3 * o + 1] = s1;
+            ggr_st(clamped_out + o, clamp_bits);
+            splat[3 * o] = s0;          // (plain stores: the records, keys and rects are read again within the forward —
+            splat[3 * o + 1] = s1;      //  non-temporal they measured the same or worse)
             splat[3 * o + 2] = s2;
         }
         km = max(km, key_out);

@@ -193,7 +193,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? (sh_compact ? sh_rowf / 3 : M) : 1;
     // this thread's own inputs are requested BEFORE the SH staging, so that their round trip overlaps it
     const size_t il = (size_t)min(i, P - 1);
-    const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];
+    const float m0 = ggr_ld(means3D + 3 * il), m1 = ggr_ld(means3D + 3 * il + 1), m2 = ggr_ld(means3D + 3 * il + 2);
     float cin_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (cov_is_input) {   // the caller's covariances, in the caller's form; the scale / rotation path reads the
         if (inf.cov_stride == 9) {  // per-view ones preprocess_fwd stored (already scaled) inside the view loop
@@ -201,7 +201,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             cin_in[0] = c9[0]; cin_in[1] = c9[1]; cin_in[2] = c9[2]; cin_in[3] = c9[4]; cin_in[4] = c9[5]; cin_in[5] = c9[8];
         } else {
 #pragma unroll
-            for (int k = 0; k < 6; k++) cin_in[k] = cov3D[6 * il + k];
+            for (int k = 0; k < 6; k++) cin_in[k] = ggr_ld(cov3D + 6 * il + k);
         }
     }
     if (use_sh && KC == 0) {
@@ -225,7 +225,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     int nrad = 0;
     {
         const float4* rec = recs + (GGR_G2D_STRIDE / 4) * il;
-        n0 = rec[0]; n1 = rec[1]; n2 = *reinterpret_cast<const float2*>(rec + 2); nrad = radii[il];
+        n0 = ggr_ld_f4(reinterpret_cast<const float*>(rec)); n1 = ggr_ld_f4(reinterpret_cast<const float*>(rec + 1));
+        n2 = *reinterpret_cast<const float2*>(rec + 2); nrad = radii[il];
     }
 #pragma clang loop unroll(disable)
     for (int v = 0; v < NV; v++) {
@@ -245,7 +246,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
         const float g_z = r2.y;
         if (in_range) {
-            dL_dmeans2D[3 * o] = r0.w; dL_dmeans2D[3 * o + 1] = r1.x; dL_dmeans2D[3 * o + 2] = 0.f;
+            ggr_st(dL_dmeans2D + 3 * o, r0.w); ggr_st(dL_dmeans2D + 3 * o + 1, r1.x); ggr_st(dL_dmeans2D + 3 * o + 2, 0.f);
             dop += r2.x;
         }
         float V[16], PM[16];
@@ -549,8 +550,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 const int total = nrow * rowlen, n4 = total >> 2;
                 float* dst = dL_dsh + (g0 + r0) * sh_row;
                 for (int j = threadIdx.x; j < n4; j += 256)
-                    reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(sh_lds)[j];
-                for (int j = (n4 << 2) + threadIdx.x; j < total; j += 256) dst[j] = sh_lds[j];
+                    ggr_st_f4(dst + 4 * (size_t)j, reinterpret_cast<const float4*>(sh_lds)[j]);
+                for (int j = (n4 << 2) + threadIdx.x; j < total; j += 256) ggr_st(dst + j, sh_lds[j]);
             }
         }
     } else if (use_sh) {
@@ -652,8 +653,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             float* dst = dL_dsh + g0 * sh_row;
             const int n4 = (int)(total >> 2);
             for (int j = threadIdx.x; j < n4; j += blockDim.x)
-                reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(sh_lds)[j];
-            for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) dst[j] = sh_lds[j];
+                ggr_st_f4(dst + 4 * (size_t)j, reinterpret_cast<const float4*>(sh_lds)[j]);
+            for (int j = (n4 << 2) + threadIdx.x; j < (int)total; j += blockDim.x) ggr_st(dst + j, sh_lds[j]);
         } else if ((sh_row & 3) == 0 && (sh_rowf & 3) == 0) {
             const int q_row = (int)(sh_row >> 2), q_used = copy_row >> 2;
             for (int j = threadIdx.x; j < nG * q_row; j += blockDim.x) {
@@ -663,20 +664,20 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     const float* d = sh_lds + g * sh_stride + 4 * q;
                     v4 = make_float4(d[0], d[1], d[2], d[3]);
                 }
-                *reinterpret_cast<float4*>(dL_dsh + (g0 + g) * sh_row + 4 * q) = v4;
+                ggr_st_f4(dL_dsh + (g0 + g) * sh_row + 4 * q, v4);
             }
         } else {
             const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;
 #pragma unroll 8
             for (int g = wv; g < nG; g += nw)
                 for (int k = ln; k < (int)sh_row; k += 64)
-                    dL_dsh[(g0 + g) * sh_row + k] = k < copy_row ? sh_lds[g * sh_stride + k] : 0.f;
+                    ggr_st(dL_dsh + (g0 + g) * sh_row + k, k < copy_row ? sh_lds[g * sh_stride + k] : 0.f);
         }
     }
     if (in_range) {
-        dL_dopacity[i] = dop;
-        dL_dmeans3D[3 * i] = dmean[0]; dL_dmeans3D[3 * i + 1] = dmean[1]; dL_dmeans3D[3 * i + 2] = dmean[2];
-        if (has_colors_precomp) { dL_dcolors_precomp[3 * i] = dcp[0]; dL_dcolors_precomp[3 * i + 1] = dcp[1]; dL_dcolors_precomp[3 * i + 2] = dcp[2]; }
+        ggr_st(dL_dopacity + i, dop);
+        ggr_st(dL_dmeans3D + 3 * i, dmean[0]); ggr_st(dL_dmeans3D + 3 * i + 1, dmean[1]); ggr_st(dL_dmeans3D + 3 * i + 2, dmean[2]);
+        if (has_colors_precomp) { ggr_st(dL_dcolors_precomp + 3 * i, dcp[0]); ggr_st(dL_dcolors_precomp + 3 * i + 1, dcp[1]); ggr_st(dL_dcolors_precomp + 3 * i + 2, dcp[2]); }
         if (scales && dL_dscales) {
             dL_dscales[3 * i] = dsc[0]; dL_dscales[3 * i + 1] = dsc[1]; dL_dscales[3 * i + 2] = dsc[2];
             dL_drotations[4 * i] = drot[0]; dL_drotations[4 * i + 1] = drot[1]; dL_drotations[4 * i + 2] = drot[2];
@@ -691,7 +692,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             d9[6] = 0.f;     d9[7] = 0.f;     d9[8] = dcov[5];
         } else {
 #pragma unroll
-            for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+            for (int k = 0; k < 6; k++) ggr_st(dL_dcov3D + 6 * (size_t)i + k, dcov[k]);
         }
     }
 }
@@ -848,10 +849,10 @@ preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ 
             if (inf.sh_aligned) {   // (g0 + r0 is a multiple of 4 rows: every range starts 16-B aligned)
                 const int n4 = total >> 2;
                 for (int j = threadIdx.x; j < n4; j += 256)
-                    reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(sh_lds)[j];
-                for (int j = (n4 << 2) + threadIdx.x; j < total; j += 256) dst[j] = sh_lds[j];
+                    ggr_st_f4(dst + 4 * (size_t)j, reinterpret_cast<const float4*>(sh_lds)[j]);
+                for (int j = (n4 << 2) + threadIdx.x; j < total; j += 256) ggr_st(dst + j, sh_lds[j]);
             } else {
-                for (int j = threadIdx.x; j < total; j += 256) dst[j] = sh_lds[j];
+                for (int j = threadIdx.x; j < total; j += 256) ggr_st(dst + j, sh_lds[j]);
             }
         }
     }

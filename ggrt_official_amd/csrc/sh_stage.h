@@ -29,14 +29,14 @@ __device__ __forceinline__ void stage_sh_rows(float* __restrict__ sh_lds, const 
         for (int j0 = 0; j0 < n4; j0 += U * 256) {
             float4 v[U];
 #pragma unroll
-            for (int it = 0; it < U; it++) v[it] = reinterpret_cast<const float4*>(src)[min(j0 + it * 256 + tid, n4 - 1)];
+            for (int it = 0; it < U; it++) v[it] = ggr_ld_f4(src + 4 * (size_t)min(j0 + it * 256 + tid, n4 - 1));
 #pragma unroll
             for (int it = 0; it < U; it++) {
                 const int j = j0 + it * 256 + tid;
                 if (j < n4) reinterpret_cast<float4*>(sh_lds)[j] = v[it];
             }
         }
-        for (int j = (n4 << 2) + tid; j < (int)total; j += 256) sh_lds[j] = src[j];
+        for (int j = (n4 << 2) + tid; j < (int)total; j += 256) sh_lds[j] = ggr_ld(src + j);
     } else if ((row & 3) == 0 && (copy_row & 3) == 0) {
         // 16-B aligned rows: float4 loads, repacked to the odd LDS stride with scalar stores
         const int q_per = copy_row >> 2;
@@ -49,7 +49,7 @@ __device__ __forceinline__ void stage_sh_rows(float* __restrict__ sh_lds, const 
                 const int j = min(j0 + it * 256 + tid, total4 - 1);
                 gg[it] = j / q_per;
                 qq[it] = j - gg[it] * q_per;
-                v[it] = *reinterpret_cast<const float4*>(shs + (g0 + gg[it]) * row + 4 * qq[it]);
+                v[it] = ggr_ld_f4(shs + (g0 + gg[it]) * row + 4 * qq[it]);
             }
 #pragma unroll
             for (int it = 0; it < 12; it++) {
@@ -65,7 +65,7 @@ __device__ __forceinline__ void stage_sh_rows(float* __restrict__ sh_lds, const 
         const int wv = tid >> 6, ln = tid & 63;
 #pragma unroll 8
         for (int g = wv; g < nG; g += 4)
-            for (int k = ln; k < copy_row; k += 64) sh_lds[g * stride + k] = shs[(g0 + g) * row + k];
+            for (int k = ln; k < copy_row; k += 64) sh_lds[g * stride + k] = ggr_ld(shs + (g0 + g) * row + k);
     }
 }
 
@@ -91,8 +91,8 @@ __device__ __forceinline__ void stage_sh_rows_compact(float* __restrict__ sh_lds
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const size_t g = g0 + (size_t)min(gb + r, nG - 1);
-            v[2 * r] = shs[g * row + c0];
-            v[2 * r + 1] = shs[g * row + c1];
+            v[2 * r] = ggr_ld(shs + g * row + c0);
+            v[2 * r + 1] = ggr_ld(shs + g * row + c1);
         }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void write_sh_rows_compact(float* __restrict__ dL_dsh
         else dst = col < 3 * K ? col : -1;
 #pragma unroll 8
         for (int g = wv; g < nG; g += 4)
-            dL_dsh[(g0 + g) * row + col] = dst >= 0 ? sh_lds[g * stride + dst] : 0.f;
+            ggr_st(dL_dsh + (g0 + g) * row + col, dst >= 0 ? sh_lds[g * stride + dst] : 0.f);
     }
 }
 
@@ -144,6 +144,8 @@ struct ShThirds {
     __device__ __forceinline__ void load(float (&v)[ITS], int J) const {
         const float* s = src + J * step;
 #pragma unroll
+        // (plain loads on purpose: the three thirds of a row share cache lines — loaded non-temporally, every third
+        //  fetched its lines from HBM again: preprocess_fwd 0.063 → 0.085 ms at C3)
         for (int it = 0; it < ITS; it++) v[it] = s[(uint32_t)min(g + it * RPI, last) * row + (uint32_t)k];
     }
     // the loaded third into LDS, row r at r·STRIDE
