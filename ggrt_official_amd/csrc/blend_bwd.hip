@@ -41,12 +41,18 @@ __device__ __forceinline__ float dpp_mov(float v) {
 // Transposing reduction of v[0..7] over the 8 pixel ROWS of the quadrant (lane = 8·row + column).  Returns,
 // in lane l, the sum over the 8 lanes {column (l & 7) of every row} of v[l >> 3].
 __device__ __forceinline__ float transpose_rows8(float (&v)[RB], int lane) {
-    // level 32: lanes 0-31 keep slots 0-3, lanes 32-63 keep slots 4-7
+    // level 32: lanes 0-31 keep slots 0-3, lanes 32-63 keep slots 4-7.  The exchange goes through the LDS crossbar
+    // (ds_bpermute: no vector-issue slot, two selects + one add = 6 issue cycles) instead of v_permlane32_swap + add
+    // (8 + 2) — the kernel is bound by vector issue, its five waves per SIMD hide the round trip: 364 → 347 µs at C3.
+    // Measured beside it (NOTES r4): level 16 the same way 375 µs (a second DEPENDENT round trip), two or three of the
+    // four pairs 349, all exchanges of three / six arrays requested before the first use 352 / 366, the whole row
+    // reduction through a transposing LDS tile (8 stores + two 16-B loads per array) 359-368.
     float w4[4];
+    const bool h32 = (lane & 32) != 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
-        w4[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        const float keep = h32 ? v[i + 4] : v[i], send = h32 ? v[i] : v[i + 4];
+        w4[i] = keep + __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(send)));
     }
     // level 16: even 16-lane rows keep the lower half of their slots, odd rows the upper half
     float w2[2];
