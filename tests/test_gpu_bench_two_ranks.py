@@ -70,3 +70,7 @@ def test_bench_one_rank_over_rccl():
     assert mg["allreduce_ms"] > 0 and mg["overlapped_ms_per_step"] > 0 and mg["serial_ms_per_step"] > 0
     assert rec["n_gpus"] == 1 and rec["value"] > 0
     assert rec["ranks"][0]["rank"] == 0 and rec["ranks"][0]["index"] == 0 and rec["allreduce_over_raster"] > 0
+    # the record says how the device was brought to its sustained power state and carries the from-idle figure beside it
+    ds = rec["device_state"]
+    assert ds["prewarm_ms"] >= 60 and ds["prewarm_steps"] >= 1 and rec["warmup"] == 1
+    assert ds["from_idle"]["steps"] == 2 and ds["from_idle"]["ms_per_step"] > 0
