@@ -34,7 +34,9 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  int ckpt_slots, uint32_t* __restrict__ tile_top, int views, int interleaved, float4* __restrict__ zero4,
                  size_t zero4_n) {
     __shared__ StagedSplat stage[BATCH + 1];   // + the null record that pads a wave's survivor list
-    __shared__ __attribute__((aligned(16))) uint16_t surv[4][BATCH + SURV_GROUP];  // per wave: LDS byte offsets of its survivors
+    typedef uint32_t surv_t;   // (u32, not u16: four offsets are one 16-B broadcast read and need no unpacking — one vector
+                               //  instruction per survivor less in a loop bound by vector issue: 152.0 → 150.2 µs at C3)
+    __shared__ __attribute__((aligned(16))) surv_t surv[4][BATCH + SURV_GROUP];  // per wave: LDS byte offsets of its survivors
     __shared__ int wave_done[4];
     __shared__ uint32_t wave_last[4];
 
@@ -116,7 +118,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         if (!wdone) {
             // [budget: cull]
             // ---- cull: this wave's survivors of the whole batch, compacted into a wave-private list of LDS byte
-            // offsets (u16: 255·48 < 2^16).  Round 2 walked the ballot mask with s_ff1 / s_and per survivor and
+            // offsets.  Round 2 walked the ballot mask with s_ff1 / s_and per survivor and
             // combined its per-pixel conditions in scalar mask registers: ≈ 20 SALU per ≈ 22 VALU instructions, and a
             // CU has ONE scalar unit for its four SIMDs — the kernel ran at the scalar unit's pace (85 M SALU against
             // 105 M VALU per launch at C3).  Now the WALK costs no scalar instruction: a survivor's offset arrives in a
@@ -124,7 +126,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             // scalar ANDs per survivor, 38 M SALU per launch): as float factors and one select per condition they cost
             // more vector issue cycles than they saved scalar ones (see `live` above).
             int ns = 0;
-            uint16_t* my_surv = surv[wave];
+            surv_t* my_surv = surv[wave];
             for (int s0 = 0; s0 < nb; s0 += 64) {
                 const int e = s0 + lane;
                 bool keep = false;
@@ -134,21 +136,21 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                     keep = staged_box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
                 }
                 const uint64_t mk = __ballot(keep);
-                if (keep) my_surv[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)(e * 48);
+                if (keep) my_surv[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (surv_t)(e * 48);
                 ns += __popcll(mk);
             }
-            if (lane < SURV_GROUP) my_surv[ns + lane] = (uint16_t)(BATCH * 48);  // pad with the null record (opacity 0)
+            if (lane < SURV_GROUP) my_surv[ns + lane] = (surv_t)(BATCH * 48);  // pad with the null record (opacity 0)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // [budget: evaluate]
             const char* stage_bytes = reinterpret_cast<const char*>(stage);
             uint32_t hit_off = 0xFFFFFFFFu;   // LDS offset of the pixel's latest contributor in this batch (none yet)
             for (int k0 = 0; k0 < ns; k0 += SURV_GROUP) {
-                uint32_t pkw[SURV_GROUP / 2];   // the group's offsets, one broadcast read
+                uint32_t pkw[SURV_GROUP];       // the group's offsets, one broadcast read
                 __builtin_memcpy(pkw, my_surv + k0, sizeof pkw);
 #pragma unroll
                 for (int u = 0; u < SURV_GROUP; u++) {
-                    const uint32_t off = (pkw[u >> 1] >> (16 * (u & 1))) & 0xffffu;   // (VGPR, uniform)
+                    const uint32_t off = pkw[u];   // (VGPR, uniform)
                     const StagedSplat* rec = reinterpret_cast<const StagedSplat*>(stage_bytes + off);
                     const float4 a = rec->a, rb = rec->b;
                     const float2 rc = *reinterpret_cast<const float2*>(&rec->c);   // (blue, z)
