@@ -92,7 +92,8 @@ def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int, N_built: i
 def percentiles(ms: list) -> dict:
     s = sorted(ms)
     q = lambda f: s[min(len(s) - 1, max(0, int(round(f * (len(s) - 1)))))]
-    return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "n": len(s)}
+    return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "max": round(s[-1], 4),
+            "mean": round(sum(s) / len(s), 4), "n": len(s)}
 
 
 def newest_profile(pattern: str):
@@ -314,12 +315,19 @@ def profile_stamp(path: str) -> dict:
 def timed_steps(fn, steps: int, warmup: int, dev, barrier=None, finish=None):
     """`warmup` untimed calls, then EXACTLY `steps` calls bracketed by barrier + synchronize on both sides.
     Returns (wall seconds of the bracket, per-step ms from HIP events recorded on the launch stream)."""
+    import gc
     for i in range(warmup):
         fn(i)
     if finish:
         finish()
     torch.cuda.synchronize(dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # the collector does not run inside the bracket (the default mode has the host in the loop once per forward — it waits
+    # for num_rendered — so a collection pause of a few ms is a few ms of idle device; a trainer that cares does the same)
+    # (no gc.collect() here: a full collection with torch loaded takes tens of ms, the device idles meanwhile and the
+    #  bracket would start on its power-state ramp again — main() collects before the prewarm)
+    gc_was_on = gc.isenabled()
+    gc.disable()
     if barrier:
         barrier()
     torch.cuda.synchronize(dev)
@@ -334,6 +342,8 @@ def timed_steps(fn, steps: int, warmup: int, dev, barrier=None, finish=None):
     if barrier:
         barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     return elapsed, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
 
@@ -529,6 +539,8 @@ def main():
     log(f"scene {args.config} resident on {dev}; world {world}; warmup {args.warmup}")
     resident_bytes = torch.cuda.memory_allocated(dev)     # scene + upstream gradient (+ exchange buffers): inputs, not the path's state
     torch.cuda.reset_peak_memory_stats(dev)
+    import gc
+    gc.collect()
     wl.step()                       # (first call: allocations, lazy initialisation — not part of the prewarm clock)
     torch.cuda.synchronize(dev)
     prewarm_steps, t_pre = 0, time.perf_counter()
@@ -570,6 +582,7 @@ def main():
     # informational: the same K steps + W warm-up started from an IDLE device (0.5 s of sleep) — what a caller who renders
     # one burst now and then gets, and what this bench reported before `--prewarm-ms` existed
     device_state = {"prewarm_ms": round(prewarm_ms, 1), "prewarm_steps": prewarm_steps,
+                    "python_gc": "paused inside every timed bracket (collected before the prewarm)",
                     "note": "the timed region is W warm-up + K steps as the contract says; before it the step ran for "
                             "`prewarm_ms` so that the device is in its sustained power state (from idle the first ~22 ms "
                             "of ANY work run 3-10 % slower: tools/ramp_probe.py, profiles/r04_ramp_probe.txt)"}
