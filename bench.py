@@ -543,6 +543,8 @@ def main():
     gc.collect()
     wl.step()                       # (first call: allocations, lazy initialisation — not part of the prewarm clock)
     torch.cuda.synchronize(dev)
+    parallel.barrier()              # (N > 1: the ranks prewarm TOGETHER — a rank that finished early would idle, and cool
+                                    #  down, at the timed bracket's barrier while the others catch up)
     prewarm_steps, t_pre = 0, time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:   # (the default mode's forward waits for num_rendered:
         wl.step()                                                  #  the host is paced by the device)
