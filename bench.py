@@ -312,10 +312,22 @@ def profile_stamp(path: str) -> dict:
     return out
 
 
-def timed_steps(fn, steps: int, warmup: int, dev, barrier=None, finish=None):
+LEG_PREWARM_MS = 0.0   # informational legs: run their own step this long before their warm-up steps (set by main())
+
+
+def timed_steps(fn, steps: int, warmup: int, dev, barrier=None, finish=None, prewarm_ms: float = 0.0):
     """`warmup` untimed calls, then EXACTLY `steps` calls bracketed by barrier + synchronize on both sides.
-    Returns (wall seconds of the bracket, per-step ms from HIP events recorded on the launch stream)."""
+    Returns (wall seconds of the bracket, per-step ms from HIP events recorded on the launch stream).
+    `prewarm_ms` (informational legs only): the leg's own step for that long first — whatever the host did to set the
+    leg up left the device idle, and an idle device is 3-10 % slower for ~22 ms (main() does the same for the headline)."""
     import gc
+    if prewarm_ms > 0:
+        t_pre, k = time.perf_counter(), 0
+        while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+            fn(k)
+            k += 1
+            if k % 8 == 0:
+                torch.cuda.synchronize(dev)   # (sync-free legs: keep the host from queueing seconds of work)
     for i in range(warmup):
         fn(i)
     if finish:
@@ -430,7 +442,7 @@ def secondary_record(name: str, cfg: dict, dev, steps: int, warmup: int, fwd_onl
     """Another BASELINE shape measured like the headline one: per-step HIP events (median / p10 / p90), stage times,
     the dominant kernel's roofline and the render-forward / -backward HBM fractions of THIS shape."""
     wl = Workload(name, cfg, dev, seed=0, fwd_only=fwd_only, pose=not fwd_only)
-    _, per_step = timed_steps(lambda i: wl.step(), steps, warmup, dev)
+    _, per_step = timed_steps(lambda i: wl.step(), steps, warmup, dev, prewarm_ms=LEG_PREWARM_MS)
     stages = wl.stage_times(3)
     N = wl.num_rendered()
     N_built = wl.num_rendered(reference=False)
@@ -539,6 +551,8 @@ def main():
     log(f"scene {args.config} resident on {dev}; world {world}; warmup {args.warmup}")
     resident_bytes = torch.cuda.memory_allocated(dev)     # scene + upstream gradient (+ exchange buffers): inputs, not the path's state
     torch.cuda.reset_peak_memory_stats(dev)
+    global LEG_PREWARM_MS
+    LEG_PREWARM_MS = 0.67 * args.prewarm_ms
     import gc
     gc.collect()
     wl.step()                       # (first call: allocations, lazy initialisation — not part of the prewarm clock)
@@ -561,6 +575,8 @@ def main():
     multi = None
     if dist_on:
         def leg(fn, fin=None):
+            # (no time-based prewarm here: the legs contain collectives, every rank must issue the same number of them —
+            #  and they follow the timed loop back to back, the device is warm)
             t, _ = timed_steps(fn, args.steps, 2, dev, barrier=parallel.barrier, finish=fin)
             return parallel.max_over_ranks(t, dev) / args.steps * 1e3
 
@@ -621,7 +637,7 @@ def main():
                 with torch.cuda.stream(lanes[i & 1]):
                     pair[i & 1].step()
 
-            el2, _ = timed_steps(step2, args.steps, args.warmup, dev)
+            el2, _ = timed_steps(step2, args.steps, args.warmup, dev, prewarm_ms=LEG_PREWARM_MS)
             for st_ in lanes:
                 torch.cuda.current_stream(dev).wait_stream(st_)
             ms2 = el2 / args.steps * 1e3
@@ -660,6 +676,12 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 step_g()
+            t_pre, k = time.perf_counter(), 0
+            while (time.perf_counter() - t_pre) * 1e3 < LEG_PREWARM_MS:   # (the capture left the device idle)
+                graph.replay()
+                k += 1
+                if k % 8 == 0:
+                    torch.cuda.synchronize(dev)
             for _ in range(args.warmup):
                 graph.replay()
             torch.cuda.synchronize(dev)
@@ -694,7 +716,7 @@ def main():
             n_leg = max(20, min(args.steps, 100))
             prev = _r.set_list_hint(False)
             try:
-                el_off, ev_off = timed_steps(lambda i: wl.step(), n_leg, 5, dev)
+                el_off, ev_off = timed_steps(lambda i: wl.step(), n_leg, 5, dev, prewarm_ms=LEG_PREWARM_MS)
             finally:
                 _r.set_list_hint(prev)
             hint_rec = {"hint_off_upstream_order": {"ms_per_step": round(el_off / n_leg * 1e3, 4),
@@ -707,7 +729,7 @@ def main():
             pair = (wl, wl_b)
             _r.clear_list_hints()
             _r.list_hint_stats(reset=True)
-            el_alt, ev_alt = timed_steps(lambda i: pair[i & 1].step(), n_leg, 4, dev)
+            el_alt, ev_alt = timed_steps(lambda i: pair[i & 1].step(), n_leg, 4, dev, prewarm_ms=LEG_PREWARM_MS)
             st_alt = _r.list_hint_stats(reset=True)
             hint_rec["alternating_scenes"] = {
                 "num_rendered_built": [n_a, n_b], "ratio": round(n_b / max(n_a, 1), 3),
