@@ -368,8 +368,8 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // 5. blend (clears the caller's backward scratch on the side; an image without tiles launches nothing)
     if (out->backward_scratch && tiles == 0)
         HIP_TRY(hipMemsetAsync(out->backward_scratch, 0, ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s));
-    ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, vs.bg, out->out_color, im.final_T, im.n_contrib,
-                          out->out_depth, out->no_backward ? nullptr : im.ckpt, im.ckpt_slots, im.tile_top, NV,
+    ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, vs.bg, out->out_color, out->no_backward ? nullptr : im.final_T,
+                          im.n_contrib, out->out_depth, out->no_backward ? nullptr : im.ckpt, im.ckpt_slots, im.tile_top, NV,
                           (st->scissor[0] | st->scissor[1] | st->scissor[2] | st->scissor[3]) != 0, out->backward_scratch,
                           ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s);
     KCHECK(dbg, s, "blend_fwd");

@@ -25,7 +25,10 @@ namespace ggr {
                        // C3 150 / 150 / 176 µs, C5′ 195 / 173 / 173 — at 8 the compiler keeps all eight records live)
 #endif
 
+// TRAIN = false (GgrForwardOut.no_backward: inference, torch.no_grad()): nothing is kept for a backward — no last contributor
+// per pixel (one select per survivor in a loop bound by vector issue: 150.6 → 142.0 µs at C3), no final T, no tile_top.
 // [budget: prologue]  (scripts/valu_budget.py)
+template <bool TRAIN>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
@@ -168,30 +171,34 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                     T -= w;
                     // (which entry: its LDS offset, already in a register — the list position follows from it after the
                     //  batch; reading it from the record was a fourth LDS read per survivor, 2 of 12 LDS cycles)
-                    hit_off = take ? off : hit_off;
+                    if (TRAIN) hit_off = take ? off : hit_off;
                 }
                 if (!__any(live)) { wdone = true; break; }
             }
             // list position + 1 of entry e = offset / 48 of this batch: what n_contrib records
-            if (hit_off != 0xFFFFFFFFu) last = (uint32_t)b0 + 1u + (((hit_off >> 4) * 0xAAABu) >> 17);
+            if (TRAIN && hit_off != 0xFFFFFFFFu) last = (uint32_t)b0 + 1u + (((hit_off >> 4) * 0xAAABu) >> 17);
             if (wdone && lane == 0) wave_done[wave] = 1;
         }
     }
     // [budget: epilogue]
     // the tile's last contributor: the backward replays the list entries before it (and nothing else)
-    uint32_t wl = last;
+    if (TRAIN) {
+        uint32_t wl = last;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, off));
-    if (lane == 0) wave_last[wave] = wl;
-    __syncthreads();
-    if (tid == 0) tile_top[vtile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
+        for (int off = 32; off > 0; off >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, off));
+        if (lane == 0) wave_last[wave] = wl;
+        __syncthreads();
+        if (tid == 0) tile_top[vtile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
+    }
     if (inside) {
-        if (ckpt) {  // slot 0: the final sums (what lies behind a checkpoint = final − checkpoint)
-            float* ck = ckpt + pid;
-            ck[hw] = C0; ck[2 * hw] = C1; ck[3 * hw] = C2; ck[4 * hw] = Dz;
+        if (TRAIN) {
+            if (ckpt) {  // slot 0: the final sums (what lies behind a checkpoint = final − checkpoint)
+                float* ck = ckpt + pid;
+                ck[hw] = C0; ck[2 * hw] = C1; ck[3 * hw] = C2; ck[4 * hw] = Dz;
+            }
+            final_T[pid] = T;
+            n_contrib[pid] = last;
         }
-        final_T[pid] = T;
-        n_contrib[pid] = last;
         out_color[pid] = C0 + T * bg[0];
         out_color[hw + pid] = C1 + T * bg[1];
         out_color[2 * hw + pid] = C2 + T * bg[2];
@@ -205,10 +212,15 @@ void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_l
                       void* zero_area, size_t zero_bytes, hipStream_t s) {
     const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
     if (gx * gy * views == 0) return;
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(xcd_grid(gx * gy * views)), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg,
-                       out_color, final_T, n_contrib, out_depth, ckpt, ckpt_slots, tile_top, views,
-                       xcd_forward_interleaved(gx * gy * views, scissored != 0) ? 1 : 0, (float4*)zero_area,
-                       zero_area ? zero_bytes / 16 : 0);
+    // (final_T == nullptr: the caller keeps nothing for a backward)
+#define GGR_LAUNCH_BFWD(TRAIN_)                                                                                              \
+    hipLaunchKernelGGL(blend_fwd_kernel<TRAIN_>, dim3(xcd_grid(gx * gy * views)), dim3(256), 0, s, W, H, gx, ranges, point_list,  \
+                       splat, bg, out_color, final_T, n_contrib, out_depth, ckpt, ckpt_slots, tile_top, views,               \
+                       xcd_forward_interleaved(gx * gy * views, scissored != 0) ? 1 : 0, (float4*)zero_area,                 \
+                       zero_area ? zero_bytes / 16 : 0)
+    if (final_T) GGR_LAUNCH_BFWD(true);
+    else GGR_LAUNCH_BFWD(false);
+#undef GGR_LAUNCH_BFWD
 }
 
 }  // namespace ggr

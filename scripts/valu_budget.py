@@ -53,7 +53,7 @@ def main():
             files[int(m.group(1))] = os.path.basename(m.group(3) or m.group(2))
     phase_of = {src_name: markers(os.path.join(SRC, src_name)),
                 "blend_common.h": markers(os.path.join(SRC, "blend_common.h"))}
-    start = next(i for i, l in enumerate(text) if re.match(r"^_ZN3ggr16blend_fwd_kernel" if fwd else r"^_ZN3ggr16blend_bwd_kernelILb0", l))
+    start = next(i for i, l in enumerate(text) if re.match(r"^_ZN3ggr16blend_fwd_kernelILb1" if fwd else r"^_ZN3ggr16blend_bwd_kernelILb0", l))
     end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))
     body = text[start:end]
     depth, cur, in_label = [], 0, False

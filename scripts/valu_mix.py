@@ -76,7 +76,7 @@ def kernel_mix(src: str, symbol_re: str):
 
 if __name__ == "__main__":
     res = {"costs_cycles_per_wave64_inst": COST, "cost_source": "profiles/r03_valu_peak.txt, profiles/r03_valu_peak2.txt (tools/valu_peak_bench.hip)",
-           "blend_fwd_kernel": kernel_mix("blend_fwd.hip", r"^_ZN3ggr16blend_fwd_kernel"),
+           "blend_fwd_kernel": kernel_mix("blend_fwd.hip", r"^_ZN3ggr16blend_fwd_kernelILb1"),
            "blend_bwd_kernel": kernel_mix("blend_bwd.hip", r"^_ZN3ggr16blend_bwd_kernelILb0")}
     json.dump(res, sys.stdout, indent=1)
     print()
