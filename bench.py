@@ -340,22 +340,24 @@ def timed_steps(fn, steps: int, warmup: int, dev, barrier=None, finish=None, pre
     #  bracket would start on its power-state ramp again — main() collects before the prewarm)
     gc_was_on = gc.isenabled()
     gc.disable()
-    if barrier:
-        barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(steps):
-        fn(warmup + i)
-        ev[i + 1].record()
-    if finish:
-        finish()
-    torch.cuda.synchronize(dev)
-    if barrier:
-        barrier()
-    elapsed = time.perf_counter() - t0
-    if gc_was_on:
-        gc.enable()
+    try:
+        if barrier:
+            barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            fn(warmup + i)
+            ev[i + 1].record()
+        if finish:
+            finish()
+        torch.cuda.synchronize(dev)
+        if barrier:
+            barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        if gc_was_on:
+            gc.enable()
     return elapsed, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
 
