@@ -80,3 +80,37 @@ def test_random_case(i):
     assert out["num_rendered"] == st.num_rendered
     assert np.array_equal(out["point_list"].cpu().numpy().astype(np.uint32), st.point_list)
     assert np.array_equal(out["ranges"].cpu().numpy(), st.ranges)
+
+
+# One-off soak at sizes between the sweep above (≤ 6 000 Gaussians: one or two depth-sort tiles) and the full-size frames:
+# random P up to 700 k, random image sizes up to ≈ 1 400 × 1 000, both profiles — the depth sort's tree and walking look-back,
+# several count bands, 16 … 32 scatter bands.  GGR_SOAK_MID=N runs N cases (default 2: a smoke of the harness itself).
+def _mid_case(i):
+    r = np.random.default_rng(5000 + i)
+    W, H = int(r.integers(200, 1400)), int(r.integers(150, 1000))
+    P = int(10 ** r.uniform(4.0, 5.85))
+    D = int(r.integers(0, 4))
+    sc = make_scene(P, W, H, sh_degree=D, profile="AB"[i % 2], seed=900 + i)
+    k = float(r.uniform(0.6, 2.0)) ** 2
+    sc.cov3D.mul_(k)
+    return sc
+
+
+@pytest.mark.parametrize("i", range(int(os.environ.get("GGR_SOAK_MID", "2"))))
+def test_midsize_case(i):
+    from ggrt_official_amd.rasterizer import debug_forward_state
+    sc = _mid_case(i)
+    st = oracle_forward(sc)
+    s = sc.to("cuda:0")
+    out = debug_forward_state(s.means3D, s.opacities, s.settings(), shs=s.shs, cov3D_precomp=s.cov3D)
+    assert out["num_rendered"] == st.num_rendered
+    assert np.array_equal(out["radii"].cpu().numpy(), st.radii)
+    assert np.array_equal(out["point_list"].cpu().numpy().astype(np.uint32), st.point_list)
+    assert np.array_equal(out["ranges"].cpu().numpy(), st.ranges)
+    color = out["color"].cpu().numpy()
+    flips = threshold_flips(st, color)
+    assert all(f[4] < 1e-5 for f in flips), [f[:5] for f in flips]
+    mask = np.zeros((sc.height, sc.width), bool)
+    for y, x, *_ in flips:
+        mask[y, x] = True
+    check_image(color, st.color, exclude=mask)
