@@ -114,3 +114,10 @@ def test_midsize_case(i):
     for y, x, *_ in flips:
         mask[y, x] = True
     check_image(color, st.color, exclude=mask)
+    # … and the gradients of the same case (contributors of explained flips set aside, as in the sweep above)
+    dL = upstream_gradient(sc.width, sc.height, seed=700 + i)
+    ref = c_oracle.backward(st, dL.numpy())
+    _, _, _, grads = hip_forward_backward(sc, dL)
+    small = [f for f in threshold_flips(st, color, atol=3e-6) if f[4] < 1e-5]
+    check_grads(grads, ref, ["means3D", "means2D", "shs", "opacities", "cov3D_precomp"],
+                exclude_rows=sorted({g for f in flips + small for g in f[5]}))
