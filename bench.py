@@ -558,6 +558,10 @@ def main():
     import gc
     gc.collect()
     wl.step()                       # (first call: allocations, lazy initialisation — not part of the prewarm clock)
+    if dist_on:                     # (… and RCCL's: the first collective of each size sets up channels and buffers, which
+        exchange(0, True)           #  can take far longer than the W warm-up steps and would leave the device idle — and
+        exchange(1, True)           #  cold — right in front of the timed bracket; every rank issues the same two)
+        drain()
     torch.cuda.synchronize(dev)
     parallel.barrier()              # (N > 1: the ranks prewarm TOGETHER — a rank that finished early would idle, and cool
                                     #  down, at the timed bracket's barrier while the others catch up)
