@@ -102,4 +102,17 @@ __device__ __forceinline__ bool staged_box_may_contribute(const float4 a, const 
     return qmin * 0.999f <= kqmax + 1e-3f;
 }
 
+// Bounding box of the ACTIVE pixels of a quadrant (lane = 8·row + column; `act` = ballot of the lanes that can still take an
+// entry of the batch): entries that reach no active pixel are culled as well — exact, an inactive pixel takes nothing.
+// Scalar bit arithmetic on the 64-bit mask (≈ 20 scalar instructions per batch and wave).
+__device__ __forceinline__ void active_box(uint64_t act, float qx0, float qy0, float& x0, float& y0, float& x1, float& y1) {
+    uint32_t cols = (uint32_t)(act | (act >> 32));
+    cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
+    uint64_t rows = act;
+    rows |= rows >> 1; rows |= rows >> 2; rows |= rows >> 4; rows &= 0x0101010101010101ull;
+    const int c0 = __builtin_ctz(cols), c1 = 31 - __builtin_clz(cols);
+    const int r0 = __builtin_ctzll(rows) >> 3, r1 = (63 - __builtin_clzll(rows)) >> 3;
+    x0 = qx0 + (float)c0; x1 = qx0 + (float)c1; y0 = qy0 + (float)r0; y1 = qy0 + (float)r1;
+}
+
 }  // namespace ggr

@@ -130,13 +130,18 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             // more vector issue cycles than they saved scalar ones (see `live` above).
             int ns = 0;
             surv_t* my_surv = surv[wave];
+            float bx0 = rx0, by0 = ry0, bx1 = rx1, by1 = ry1;   // the pixels that are not saturated yet
+            {
+                const uint64_t act = __ballot(live);
+                if (act) active_box(act, rx0, ry0, bx0, by0, bx1, by1);
+            }
             for (int s0 = 0; s0 < nb; s0 += 64) {
                 const int e = s0 + lane;
                 bool keep = false;
                 if (e < nb) {
                     const float4 a = stage[e].a;
                     const float4 b = stage[e].b;
-                    keep = staged_box_may_contribute(a, b, stage[e].c.z, rx0, ry0, rx1, ry1);
+                    keep = staged_box_may_contribute(a, b, stage[e].c.z, bx0, by0, bx1, by1);
                 }
                 const uint64_t mk = __ballot(keep);
                 if (keep) my_surv[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (surv_t)(e * 48);
