@@ -9,9 +9,12 @@ normalisation + write):
 ``export_ply`` follows the reference's semantics: shift by the per-axis median, divide by the largest
 per-axis 95 % quantile of |means| (scales too), rotate into the viewer frame
 (45° about −z ∘ axis swizzle ∘ w2c rotation), compose that rotation onto every Gaussian's quaternion,
-export the SH DC band only, store log-scales, opacities as given.  The reference needs ``plyfile`` and
-``scipy``; neither is needed here (``plyfile`` is not in this image, so the byte layout is pinned by the
-PLY 1.0 spec and by a committed header fixture, not by the reference's writer).
+export the SH DC band only, store log-scales, opacities as given — in the reference's order of float32 / float64
+operations and with its quaternion sign convention, so that the vertex table is the reference's byte for byte
+(``tests/golden/ply_export_scene.npz`` holds the table the reference's own ``export_ply`` handed to ``plyfile`` for a
+seeded scene, ``tests/test_ply_io.py``).  The reference needs ``plyfile`` and ``scipy``; neither is needed here: the two
+scipy conversions are restated in numpy (``quat_xyzw_to_matrix``, ``matrix_to_quat_xyzw_markley``), the container
+format (header text + little-endian rows) is the PLY 1.0 binary layout.
 
 ``import_ply`` / ``load_gaussians`` read such a file back into rasterizer-boundary tensors
 (``means3D, scales, rotations, opacities, shs[P,1+rest,3]``) so a scene can travel as a golden fixture.
@@ -99,49 +102,99 @@ def quat_wxyz_to_matrix(q: np.ndarray) -> np.ndarray:
 def matrix_to_quat_wxyz(m: np.ndarray) -> np.ndarray:
     """Rotation matrices [...,3,3] → unit quaternions (w,x,y,z), w ≥ 0; branch on the largest of
     (trace, m00, m11, m22) for numerical safety."""
-    m = np.asarray(m, dtype=np.float64)
-    m00, m11, m22 = m[..., 0, 0], m[..., 1, 1], m[..., 2, 2]
-    cand = np.stack([
-        np.stack([1 + m00 + m11 + m22, m[..., 2, 1] - m[..., 1, 2], m[..., 0, 2] - m[..., 2, 0], m[..., 1, 0] - m[..., 0, 1]], -1),
-        np.stack([m[..., 2, 1] - m[..., 1, 2], 1 + m00 - m11 - m22, m[..., 0, 1] + m[..., 1, 0], m[..., 0, 2] + m[..., 2, 0]], -1),
-        np.stack([m[..., 0, 2] - m[..., 2, 0], m[..., 0, 1] + m[..., 1, 0], 1 - m00 + m11 - m22, m[..., 1, 2] + m[..., 2, 1]], -1),
-        np.stack([m[..., 1, 0] - m[..., 0, 1], m[..., 0, 2] + m[..., 2, 0], m[..., 1, 2] + m[..., 2, 1], 1 - m00 - m11 + m22], -1),
-    ], -2)                                                        # [...,4 candidates,4]
-    pick = np.argmax(np.stack([m00 + m11 + m22, m00, m11, m22], -1), -1)
-    q = np.take_along_axis(cand, pick[..., None, None], -2)[..., 0, :]
-    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    q = matrix_to_quat_xyzw_markley(np.asarray(m, dtype=np.float64).reshape(-1, 3, 3), orthogonalize=False)
+    q = q[:, [3, 0, 1, 2]].reshape(*np.shape(m)[:-2], 4)
     return np.where(q[..., :1] < 0, -q, q)
+
+
+def matrix_to_quat_xyzw_markley(m: np.ndarray, orthogonalize: bool = True) -> np.ndarray:
+    """[N,3,3] float64 → (x,y,z,w) with the conventions of the function the reference calls at
+    ``ply_export.py:69`` (``scipy.spatial.transform.Rotation.from_matrix(...).as_quat()``): a matrix whose Gramian is not
+    the identity to 1e-12 (here: every one, the viewer rotation is float32) is first replaced by the nearest orthogonal
+    matrix U·Vᵀ of its SVD, then Markley's 2008 rule picks the largest of (m00, m11, m22, trace) and builds the
+    quaternion around it; the SIGN is whatever that rule yields (no w ≥ 0 canonicalisation) — q and −q are the same
+    rotation, but a byte-identical file needs the same one."""
+    m = np.array(m, dtype=np.float64, copy=True)
+    if orthogonalize and len(m):
+        bad = ~np.all(np.isclose(m @ np.swapaxes(m, 1, 2), np.eye(3), atol=1e-12), axis=(1, 2))
+        if bad.any():
+            u, _, vt = np.linalg.svd(m[bad])
+            m[bad] = u @ vt
+    n = len(m)
+    dec = np.empty((n, 4))
+    dec[:, 0], dec[:, 1], dec[:, 2] = m[:, 0, 0], m[:, 1, 1], m[:, 2, 2]
+    dec[:, 3] = m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2]
+    choice = dec.argmax(axis=1)
+    q = np.empty((n, 4))
+    idx = np.nonzero(choice != 3)[0]
+    i = choice[idx]
+    j = (i + 1) % 3
+    k = (j + 1) % 3
+    q[idx, i] = 1 - dec[idx, 3] + 2 * m[idx, i, i]
+    q[idx, j] = m[idx, j, i] + m[idx, i, j]
+    q[idx, k] = m[idx, k, i] + m[idx, i, k]
+    q[idx, 3] = m[idx, k, j] - m[idx, j, k]
+    idx = np.nonzero(choice == 3)[0]
+    q[idx, 0] = m[idx, 2, 1] - m[idx, 1, 2]
+    q[idx, 1] = m[idx, 0, 2] - m[idx, 2, 0]
+    q[idx, 2] = m[idx, 1, 0] - m[idx, 0, 1]
+    q[idx, 3] = 1 + dec[idx, 3]
+    return q / np.linalg.norm(q, axis=1)[:, None]
+
+
+def quat_xyzw_to_matrix(q: np.ndarray) -> np.ndarray:
+    """(x,y,z,w) [N,4] float64 → [N,3,3]: normalise, then the products in the order the function the reference calls at
+    ``ply_export.py:67`` (``Rotation.from_quat(...).as_matrix()``) forms them."""
+    q = np.asarray(q, dtype=np.float64)
+    q = q / np.linalg.norm(q, axis=1)[:, None]
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    x2, y2, z2, w2 = x * x, y * y, z * z, w * w
+    xy, zw, xz, yw, yz, xw = x * y, z * w, x * z, y * w, y * z, x * w
+    m = np.empty((len(q), 3, 3))
+    m[:, 0, 0] = x2 - y2 - z2 + w2
+    m[:, 1, 0] = 2 * (xy + zw)
+    m[:, 2, 0] = 2 * (xz - yw)
+    m[:, 0, 1] = 2 * (xy - zw)
+    m[:, 1, 1] = -x2 + y2 - z2 + w2
+    m[:, 2, 1] = 2 * (yz + xw)
+    m[:, 0, 2] = 2 * (xz + yw)
+    m[:, 1, 2] = 2 * (yz - xw)
+    m[:, 2, 2] = -x2 - y2 + z2 + w2
+    return m
 
 
 def viewer_rotation(extrinsics: torch.Tensor) -> torch.Tensor:
     """3×3 world→viewer rotation of the export (reference ``ply_export.py:43-63``): +Z up swizzle, a −45°
-    turn about z for the viewer's start pose, then the camera-to-world rotation undone."""
-    swizzle = torch.tensor([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]], dtype=torch.float64)
+    turn about z for the viewer's start pose, then the camera-to-world rotation undone — formed in float32 in the
+    reference's order of products, so the table comes out bit for bit."""
+    swizzle = torch.tensor([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]], dtype=torch.float32)
+    # rotation vector (0, 0, −45°) → quaternion (0, 0, sin(a/2), cos(a/2)) → matrix, in float64, then float32
     a = math.radians(-45.0)
-    turn = torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]],
-                        dtype=torch.float64)
-    return (turn @ swizzle @ torch.linalg.inv(extrinsics[:3, :3].double().cpu())).float()
+    turn = torch.tensor(quat_xyzw_to_matrix(np.array([[0.0, 0.0, math.sin(a / 2), math.cos(a / 2)]]))[0],
+                        dtype=torch.float32)
+    return (turn @ swizzle) @ extrinsics[:3, :3].detach().float().cpu().inverse()
 
 
 def export_ply(extrinsics: torch.Tensor, means: torch.Tensor, scales: torch.Tensor, rotations: torch.Tensor,
                harmonics: torch.Tensor, opacities: torch.Tensor, path) -> None:
     """Same arguments as the reference's ``export_ply`` (``ply_export.py:26-34``): ``rotations`` are
     (x,y,z,w) quaternions (scipy order, as the reference feeds ``R.from_quat``), ``harmonics`` is
-    ``[G,3,d_sh]`` and only its DC band is written; the file stores (w,x,y,z)."""
+    ``[G,3,d_sh]`` and only its DC band is written; the file stores (w,x,y,z) with the sign the reference's
+    conversion yields.  The vertex table equals the one the reference hands to ``plyfile`` byte for byte
+    (``tests/golden/ply_export_scene.npz``, recorded from the reference's own function)."""
     means = means.detach().float().cpu()
     scales = scales.detach().float().cpu()
     means = means - means.median(dim=0).values
     factor = means.abs().quantile(0.95, dim=0).max()
     means, scales = means / factor, scales / factor
     rot = viewer_rotation(extrinsics)
-    means = means @ rot.T
-    q_xyzw = rotations.detach().double().cpu().numpy()
-    local = quat_wxyz_to_matrix(q_xyzw[:, [3, 0, 1, 2]])
-    q_out = matrix_to_quat_wxyz(rot.double().numpy() @ local)
+    means = torch.einsum("ij,gj->gi", rot, means)
+    local = quat_xyzw_to_matrix(rotations.detach().cpu().numpy())
+    q = matrix_to_quat_xyzw_markley(rot.numpy() @ local)
     dc = harmonics.detach().float().cpu()[..., 0]
     table = np.concatenate([means.numpy(), np.zeros_like(means.numpy()), dc.contiguous().numpy(),
                             opacities.detach().float().cpu().numpy()[:, None], scales.log().numpy(),
-                            q_out.astype(np.float32)], axis=1)
+                            q[:, [3, 0, 1, 2]]], axis=1).astype(np.float32)
     write_vertex_table(path, table, construct_list_of_attributes(0))
 
 

@@ -1,5 +1,7 @@
 """`.ply` interchange: byte layout, round trips, and the export's scene normalisation
 (reference ``ply_export.py:12-23,26-92``) checked against scipy's rotation conversions."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -106,6 +108,48 @@ def test_export_normalises_like_the_reference(tmp_path):
     assert np.allclose(ply_io.quat_wxyz_to_matrix(t[:, 13:17].astype(np.float64)), want_rot, atol=2e-6)
     # most of the scene ends up in [-1, 1]
     assert (np.abs(t[:, 0:3]) <= 1.0 + 1e-6).mean() > 0.9
+
+
+GOLDEN_EXPORT = os.path.join(os.path.dirname(__file__), "golden", "ply_export_scene.npz")
+
+
+def test_export_payload_is_byte_identical_to_the_reference(tmp_path):
+    """`tests/golden/ply_export_scene.npz` (tests/golden/make_decoder_golden.py::ply_golden): the structured vertex array
+    the REFERENCE's own `export_ply` (ply_export.py:26-92, imported in the build container with a recording `plyfile`
+    stub) handed to `PlyElement.describe(..., "vertex")` for a seeded scene.  The build's exporter must write exactly
+    those bytes after its header, and name the columns as the reference's dtype does."""
+    z = np.load(GOLDEN_EXPORT, allow_pickle=False)
+    t = lambda k: torch.from_numpy(z["in_" + k])
+    p = tmp_path / "sub" / "scene.ply"
+    ply_io.export_ply(t("extrinsics"), t("means"), t("scales"), t("rotations"), t("harmonics"), t("opacities"), p)
+    blob = p.read_bytes()
+    cut = blob.index(b"end_header\n") + len(b"end_header\n")
+    ref = z["table"]
+    assert str(z["element_name"]) == "vertex" and all(f == "<f4" for f in z["formats"].tolist())
+    header = blob[:cut].decode().splitlines()
+    assert header[:3] == ["ply", "format binary_little_endian 1.0", f"element vertex {len(ref)}"]
+    assert [ln.split()[-1] for ln in header[3:-1]] == z["columns"].tolist()
+    assert all(ln.split()[:2] == ["property", "float"] for ln in header[3:-1])
+    assert blob[cut:] == ref.astype("<f4").tobytes()
+    # the signs the reference's conversion produced are not all w >= 0: a canonicalising exporter would differ
+    assert (ref[:, 13] < 0).any()
+    assert ply_io.construct_list_of_attributes(2) == z["attributes_rest2"].tolist()
+
+
+def test_quaternion_conversions_follow_scipy_conventions():
+    """The two numpy restatements behind the byte-identical export against the scipy functions the reference calls
+    (scipy is in this image; the product does not import it): sign included, non-orthogonal (float32) inputs included."""
+    from scipy.spatial.transform import Rotation as R
+    g = np.random.default_rng(4)
+    q = g.normal(size=(400, 4)).astype(np.float32)
+    q[:4] = np.eye(4)
+    m = ply_io.quat_xyzw_to_matrix(q)
+    assert np.array_equal(m, R.from_quat(q).as_matrix())
+    rot = R.from_rotvec([0.3, -1.1, 0.4]).as_matrix().astype(np.float32).astype(np.float64)  # not orthogonal to 1e-12
+    got = ply_io.matrix_to_quat_xyzw_markley(rot @ m)
+    want = R.from_matrix(rot @ m).as_quat()
+    assert np.array_equal(np.sign(got), np.sign(want)) and np.abs(got - want).max() < 1e-14
+    assert (want[:, 3] < 0).any()
 
 
 @pytest.mark.gpu
