@@ -79,6 +79,11 @@ def source_hash() -> str:
     h.update(" ".join(FLAGS).encode())
     for k in sorted(EXTRA_FLAGS):
         h.update((k + " " + " ".join(EXTRA_FLAGS[k])).encode())
+    # dev variants (GGR_EXTRA_HIPCC_FLAGS, scripts/build_variants.sh) are OTHER libraries: they carry another hash than
+    # the default build, so that one of them cannot pass for the tree's build (GGR_SKIP_SOURCE_HASH=1 loads it knowingly)
+    extra = " ".join(os.environ.get("GGR_EXTRA_HIPCC_FLAGS", "").split())
+    if extra:
+        h.update(b"\0extra " + extra.encode())
     return h.hexdigest()
 
 

@@ -127,18 +127,29 @@ ReadbackSlot* readback_slot() {
 // of the tile-list kernels, or NULL: at once) reports completion: work that was queued on the stream ahead of this
 // forward — a long evaluation queue, a device shared with another process — is not this forward's hang.
 // The bound itself is GGR_READBACK_TIMEOUT_S seconds (environment, default 30; ≤ 0 = wait for as long as the event
-// query keeps answering "not ready").  The device-side spins are bounded the same way — nothing in a forward can wait
-// forever on a GPU that makes progress.
+// query keeps answering "not ready").  Work queued AHEAD of the forward has its own, generous bound from this function's
+// entry (GGR_READBACK_QUEUE_TIMEOUT_S, default 600 s, ≤ 0 = none): a device hung in earlier work never starts the first
+// clock.  The device-side spins are bounded the same way — with both bounds at their defaults nothing in a forward waits
+// forever, on a GPU that makes progress or on one that does not.
 typedef hipError_t (*ReadbackQueryFn)(void*);
 double readback_timeout_s() {
     const char* e = getenv("GGR_READBACK_TIMEOUT_S");
     if (e && *e) { char* end = nullptr; const double v = strtod(e, &end); if (end != e) return v; }
     return 30.0;
 }
+// bound on the wait for work queued on the stream BEFORE this forward (the per-forward bound above only runs from the
+// tile-list kernels' turn): generous, since a caller may legitimately have minutes of work in front; <= 0 disables
+double readback_queue_timeout_s() {
+    const char* e = getenv("GGR_READBACK_QUEUE_TIMEOUT_S");
+    if (e && *e) { char* end = nullptr; const double v = strtod(e, &end); if (end != e) return v; }
+    return 600.0;
+}
 int wait_readback(volatile uint32_t* hw, ReadbackQueryFn query, void* ctx, double timeout_s, uint32_t* value,
                   ReadbackQueryFn query_start = nullptr, void* ctx_start = nullptr) {
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    const timespec t_entry = t0;
+    const double queue_timeout_s = readback_queue_timeout_s();
     bool started = query_start == nullptr;
     uint32_t v = *hw;
     for (uint32_t spins = 0; v == GGR_READBACK_ARMED; v = *hw) {
@@ -152,6 +163,15 @@ int wait_readback(volatile uint32_t* hw, ReadbackQueryFn query, void* ctx, doubl
                 if (qs == hipSuccess) { started = true; clock_gettime(CLOCK_MONOTONIC, &t0); }
                 else if (qs != hipErrorNotReady)
                     return fail(GGR_E_HIP, "num_rendered read-back: the stream is in error (%s); frame not rendered", hipGetErrorString(qs));
+                else {   // a device hung in work queued BEFORE this forward never starts the clock above: second, absolute bound
+                    timespec t1;
+                    clock_gettime(CLOCK_MONOTONIC, &t1);
+                    if (queue_timeout_s > 0.0 &&
+                        (double)(t1.tv_sec - t_entry.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t_entry.tv_nsec) > queue_timeout_s)
+                        return fail(GGR_E_HIP, "num_rendered read-back: the stream's earlier work has not finished within %.0f s "
+                                               "(GGR_READBACK_QUEUE_TIMEOUT_S); frame not rendered", queue_timeout_s);
+                }
+                __builtin_ia32_pause();
                 continue;
             }
             timespec t1;

@@ -26,7 +26,7 @@ namespace ggr {
 #endif
 
 // TRAIN = false (GgrForwardOut.no_backward: inference, torch.no_grad()): nothing is kept for a backward — no last contributor
-// per pixel (one select per survivor in a loop bound by vector issue: 150.6 → 142.0 µs at C3), no final T, no tile_top.
+// per pixel (one select per survivor in a loop bound by vector issue: 150.6 → 142.0 µs at C3), no final T; tile_top = 0.
 // [budget: prologue]  (scripts/valu_budget.py)
 template <bool TRAIN>
 __global__ void __launch_bounds__(256)
@@ -75,7 +75,8 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const int ck_every = ckpt ? ckpt_stride(total, ckpt_slots, ntiles) : 0;
     {   // this view's slices
         const size_t vo = (size_t)view * hw;
-        out_color += 3 * vo; final_T += vo; n_contrib += vo; bg += 3 * view;
+        out_color += 3 * vo; n_contrib += vo; bg += 3 * view;
+        if (TRAIN) final_T += vo;   // (null without TRAIN)
         if (out_depth) out_depth += vo;
         if (ckpt) ckpt += (size_t)ckpt_slots * GGR_CKPT_FLOATS * vo;
     }
@@ -194,6 +195,10 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         if (lane == 0) wave_last[wave] = wl;
         __syncthreads();
         if (tid == 0) tile_top[vtile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
+    } else if (tid == 0) {
+        // nothing was kept: a ggr_backward handed this image_buffer by mistake replays NO list entry (all-zero blend
+        // gradients) instead of walking lists with an uninitialised final T; one 4-B store per tile
+        tile_top[vtile] = 0u;
     }
     if (inside) {
         if (TRAIN) {

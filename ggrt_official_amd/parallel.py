@@ -34,8 +34,14 @@ def init_from_env(expected_world: int | None = None, backend: str | None = None,
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
-            if torch.cuda.device_count() and local >= torch.cuda.device_count():
-                local = local % torch.cuda.device_count()   # (per-rank device visibility: the one visible device is index 0)
+            n_dev = torch.cuda.device_count()
+            if n_dev == 1 and local >= 1:
+                local = 0   # per-rank device visibility (HIP_VISIBLE_DEVICES set per rank): the one visible device is index 0
+            elif n_dev and local >= n_dev:
+                # folding ranks onto shared GPUs silently would turn a launch mistake into a wrong scaling figure
+                # (the reference fails the same way: `cuda:{local_rank}`, ggrt/base/trainer.py)
+                raise RuntimeError(f"LOCAL_RANK {local} but only {n_dev} GPUs are visible to this rank: launch one rank "
+                                   "per visible GPU (or give every rank exactly one device)")
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device(f"cuda:{local}")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)

@@ -15,9 +15,12 @@ Reference quirks kept on purpose (drop-in parity):
   * the depth pass feeds depth as a degree-0 SH coefficient, so the rasterizer returns
     ``0.5 + C0·z`` per channel and the result is the channel mean (:256-269);
   * ``sh_degree = isqrt(d_sh) - 1`` (GGRt: d_sh = 25 → 4); bands 0..min(sh_degree, ``SH_MAX_DEGREE``) are
-    evaluated — ``SH_MAX_DEGREE`` (``set_sh_max_degree`` / ``DecoderSplattingCUDA(sh_max_degree=…)`` /
-    ``GGR_SH_MAX_DEGREE``) is an explicit choice of 3 or 4; left at 0 it means 3 and the rasterizer warns once
-    (INTEGRATION.md §7).
+    evaluated.  ``SH_MAX_DEGREE`` (``set_sh_max_degree`` / ``DecoderSplattingCUDA(sh_max_degree=…)`` /
+    ``GGR_SH_MAX_DEGREE``) is 4 for THIS layer unless chosen otherwise: the package GGRt's README installs is
+    pixelSplat's rasterizer fork, GGRt's encoder emits, masks and Wigner-rotates all of bands 0..4
+    (``encoder/common/gaussian_adapter.py:45-46,90``) and passes ``sh_degree = 4`` on purpose; 3 reproduces the
+    graphdeco / w-depth family (coefficients 16.. ignored); the raw ``GaussianRasterizer`` keeps "not chosen → 3 with
+    one warning".  What the choice moves on a GGRt-like scene is measured in INTEGRATION.md §7.
 """
 from __future__ import annotations
 
@@ -34,15 +37,15 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 DepthRenderingMode = Literal["depth", "disparity", "relative_disparity", "log"]
 
 # Highest SH band the rasterizer evaluates for this call site (GaussianRasterizationSettings.sh_max_degree).
-# 3: what the rasterizer family behind the reference's live call site does with GGRt's sh_degree = 4 / 25
-# coefficients; 4 if the installed extension being replaced evaluates band 4; 0 = not chosen (3,
-# with one warning from the rasterizer the first time coefficients 16.. go unused).
-SH_MAX_DEGREE = int(os.environ.get("GGR_SH_MAX_DEGREE", "0") or 0)
+# 4 (this layer's default): band 4 is evaluated and differentiated when the call passes sh_degree >= 4
+# with >= 25 coefficients, as GGRt does; 3: coefficients 16.. are ignored (graphdeco / w-depth family); 0 hands the
+# decision to the raw rasterizer ("not chosen": 3, with one warning the first time coefficients 16.. go unused).
+SH_MAX_DEGREE = int(os.environ.get("GGR_SH_MAX_DEGREE", "4") or 4)
 
 
 def set_sh_max_degree(cap: int) -> int:
-    """Chooses (process-wide, for this call-site layer) the highest SH band the rasterizer evaluates: 3 or 4 (0 = back to
-    "not chosen").  Returns the previous setting."""
+    """Chooses (process-wide, for this call-site layer) the highest SH band the rasterizer evaluates: 3 or 4 (0 = leave it
+    to the raw rasterizer: "not chosen", 3 with one warning).  Returns the previous setting."""
     global SH_MAX_DEGREE
     if int(cap) not in (0, 3, 4):
         raise ValueError("sh_max_degree must be 3 or 4")

@@ -143,8 +143,10 @@ typedef struct GgrForwardOut {
                               the per-pixel checkpoints of the segmented backward (images below 4096 tiles: 320 B per
                               pixel) are neither written nor needed, and image_buffer may be the smaller
                               ggr_image_bytes_inference() bytes; the per-pixel final transmittance / last contributor and
-                              the per-tile replay bound are not produced either (the blend kernel runs without the
-                              bookkeeping a backward needs).  0: as before. */
+                              last contributor are not produced either (the blend kernel runs without the bookkeeping
+                              a backward needs) and the per-tile replay bound is written as 0: a ggr_backward handed
+                              such an image_buffer by mistake replays no list entry (zero blend gradients) rather than
+                              reading uninitialised state.  0: as before. */
     void* backward_scratch; /* IN, optional.  The ggr_backward_scratch_bytes() buffer the caller will hand to this frame's
                               ggr_backward: the forward clears it on the side (inside the forward blend kernel, whose
                               memory pipe is idle) and the backward, told so by GgrBackwardIn.scratch_zeroed, skips its own

@@ -3,6 +3,7 @@
 # usage: scripts/run_variants.sh [kernel-name-pattern]
 PAT=${1:-bin_}
 R=$GRAFT_REPO_ROOT
+export GGR_SKIP_SOURCE_HASH=1   # variants carry the hash of their own flags (_build.source_hash)
 cp $R/ggrt_official_amd/libggr_raster.so /tmp/base.so
 for d in $R/gpurun_variants/*/; do
   n=$(basename $d)

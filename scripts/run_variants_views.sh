@@ -2,6 +2,7 @@
 # dev: on the GPU box, time every library variant under gpurun_variants/<name>/ with the kernel trace of the 4-view call site
 PAT=${1:-preprocess}
 R=$GRAFT_REPO_ROOT
+export GGR_SKIP_SOURCE_HASH=1   # variants carry the hash of their own flags (_build.source_hash)
 cp $R/ggrt_official_amd/libggr_raster.so /tmp/base.so
 for d in $R/gpurun_variants/*/; do
   n=$(basename $d)

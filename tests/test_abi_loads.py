@@ -188,6 +188,12 @@ def test_sh_cap_is_an_explicit_choice(monkeypatch):
         monkeypatch.setenv("GGR_SH_MAX_DEGREE", "4")
         assert rasterizer._sh_cap(rs, 25) == 4
         assert not w
+    # the call-site layer's own default is 4; 0 hands the decision back to the raw rasterizer
+    import importlib
+    import os
+    if "GGR_SH_MAX_DEGREE" not in os.environ or os.environ["GGR_SH_MAX_DEGREE"] == "4":
+        monkeypatch.delenv("GGR_SH_MAX_DEGREE", raising=False)
+        assert importlib.reload(splatting).SH_MAX_DEGREE == 4
     prev = splatting.set_sh_max_degree(4)
     try:
         assert splatting.SH_MAX_DEGREE == 4

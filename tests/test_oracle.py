@@ -309,3 +309,21 @@ def test_tight_rects_change_no_output():
             power = -0.5 * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
             alpha = np.minimum(0.99, co[:, 3, None, None] * np.exp(power))
             assert float(alpha[power <= 0].max(initial=0.0)) < 1.0 / 255.0, f"tile {t}: a dropped pair could contribute"
+
+
+def test_sh_cap_delta_on_ggrt_like_scene():
+    """INTEGRATION.md §7 quotes what `sh_max_degree` 3 vs 4 moves on a profile-B scene whose band-l coefficients carry
+    GGRt's 0.1·0.25^l mask (tests/tools/sh_cap_delta.py, P = 337 920 at 480×352: image 3.5e-4, geometry gradients 1.2e-3).
+    The same measurement on a scene the CPU suite can afford must stay in that decade — the choice sits AT the north-star's
+    tolerances (1e-4 image / 1e-3 rel-L2), neither far below nor far above."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "sh_cap_delta", os.path.join(os.path.dirname(__file__), "tools", "sh_cap_delta.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.measure(P=42_240, W=240, H=176)
+    assert 5e-5 < r["image_max_abs"] < 2e-3, r
+    for k in ("means3D", "means2D", "opacities", "cov3D_precomp"):
+        assert 2e-4 < r[f"grad_rel_l2_{k}"] < 5e-3, (k, r)
+    assert 0.4 < r["grad_shs_band4_share_of_norm"] < 0.8 and r["grad_rel_l2_shs_rows_0_15"] < 0.05, r
