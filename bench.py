@@ -460,6 +460,25 @@ def secondary_record(name: str, cfg: dict, dev, steps: int, warmup: int, fwd_onl
     return rec
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE / RANK unset): start the N ranks here, the way the
+    contract's external form does — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <the same arguments>` — and hand its exit code back; rank 0's JSON line goes to this process's
+    stdout unchanged.  Under an external launcher this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:       # a free port (two benches on one host must not meet at 29500)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))   # (silences the launcher's warning)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -497,6 +516,8 @@ def main():
                     help="create the process group and run the exchange legs even with ONE rank — executes the "
                          "RCCL code path (backend nccl, ReduceOp.AVG, device_id) on a 1-GPU box")
     args = ap.parse_args()
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     from ggrt_official_amd import GaussianRasterizer
     from ggrt_official_amd.synthetic import CONFIGS
@@ -507,10 +528,11 @@ def main():
     dist_on = world > 1 or args.force_dist   # the exchange runs (a forced one-rank group reduces over itself)
     if args.device is not None:
         local = args.device
-    elif torch.cuda.device_count() and local >= torch.cuda.device_count():
+    elif torch.cuda.device_count() == 1 and local >= 1:
         # a launcher that narrows every rank's visibility to ONE device (HIP_VISIBLE_DEVICES per rank): that device is index 0
-        # here; the PCI-bus check below still proves that no two ranks share a physical GPU
-        local = local % torch.cuda.device_count()
+        # here; the PCI-bus check below still proves that no two ranks share a physical GPU.  (More ranks than visible
+        # devices otherwise: set_device fails loudly — no silent sharing.)
+        local = 0
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     # one process per GPU: this rank's current device is LOCAL_RANK's, and no two ranks of the job share a physical device
@@ -530,11 +552,13 @@ def main():
         bufs = [torch.zeros(G + 35, device=dev) for _ in range(2)]
         reducers = [parallel.ChunkedMeanAllReduce(args.exchange_chunks) for _ in range(2)]
 
-    def exchange(i: int, blocking: bool):
+    def exchange(i: int, blocking: bool, g: int = None):
+        """`g`: stand-in floats of this exchange (default: all G) — the sweep below exchanges a prefix of the same buffers"""
+        g = G if g is None else g
         k = i & 1
         reducers[k].wait()               # the all-reduce issued two steps ago on this buffer
-        buf = bufs[k]
-        torch.cat([wl.view.grad.reshape(-1), wl.proj.grad.reshape(-1), wl.campos.grad.reshape(-1)], out=buf[G:])
+        buf = bufs[k][:g + 35]
+        torch.cat([wl.view.grad.reshape(-1), wl.proj.grad.reshape(-1), wl.campos.grad.reshape(-1)], out=buf[g:])
         reducers[k].issue(buf)
         if blocking:
             reducers[k].wait()
@@ -601,6 +625,20 @@ def main():
                  "overlapped_ms_per_step": round(overlap_ms, 4),
                  "allreduce_busbw_GBps": round(2 * (world - 1) / world * nbytes / (max(allreduce_ms, 1e-6) * 1e-3) / 1e9, 1),
                  "raster_only_mpix_s": round(world * W * H / raster_ms / 1e3, 1)}
+        # where the step turns exchange-bound: the serial and the overlapped step with 0 / 38 M / G
+        # stand-in floats (38 M ≈ the path-bound limit DESIGN §7 derives for N = 8), after the timed region
+        sweep = []
+        n_sw = max(10, min(args.steps, 50))
+        for g in sorted({0, min(38_000_000, G), G}):
+            def leg_n(fn, fin=None):
+                t, _ = timed_steps(fn, n_sw, 2, dev, barrier=parallel.barrier, finish=fin)
+                return parallel.max_over_ranks(t, dev) / n_sw * 1e3
+            ar = leg_n(lambda i: exchange(i, True, g))
+            ov = leg_n(lambda i: (wl.step(), exchange(i, False, g)), drain)
+            sweep.append({"floats": g, "MB": round((g + 35) * 4 / 1e6, 1), "allreduce_ms": round(ar, 4),
+                          "overlapped_ms_per_step": round(ov, 4), "mpix_s": round(world * W * H / ov / 1e3, 1),
+                          "exchange_bound": bool(ov > 1.1 * raster_ms)})
+        multi["grad_buffer_sweep"] = sweep
         log(f"multi-GPU legs: {multi}")
 
     # informational: the same K steps + W warm-up started from an IDLE device (0.5 s of sleep) — what a caller who renders

@@ -1,0 +1,44 @@
+"""bench.py's launch convention on CPU: `python bench.py --gpus N` with no launcher around it starts its own N ranks through
+`torch.distributed.run` (the contract's external form, same arguments); under a launcher (RANK / WORLD_SIZE set) it never
+re-launches.  The launched path itself runs on the GPU box (tests/test_gpu_bench_two_ranks.py)."""
+import importlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_gpus_without_launcher_starts_ranks(monkeypatch):
+    bench = _bench()
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: (calls.append((cmd, env)), 7)[1])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                      # the launcher's exit code is handed back
+    (cmd, env), = calls
+    assert cmd[1:5] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_under_a_launcher_no_relaunch(monkeypatch):
+    bench = _bench()
+    monkeypatch.setattr(subprocess, "call", lambda *a, **k: pytest.fail("re-launched under a launcher"))
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    # WORLD_SIZE = 1 under a launcher but --gpus 2: the old, explicit error — not a silent re-launch, not a wrong n_gpus
+    with pytest.raises(RuntimeError, match="torch.distributed.run"):
+        bench.main()

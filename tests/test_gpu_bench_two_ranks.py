@@ -74,3 +74,23 @@ def test_bench_one_rank_over_rccl():
     ds = rec["device_state"]
     assert ds["prewarm_ms"] >= 60 and ds["prewarm_steps"] >= 1 and rec["warmup"] == 1
     assert ds["from_idle"]["steps"] == 2 and ds["from_idle"]["ms_per_step"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks():
+    """plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE / RANK unset — the form the driver used
+    for N = 1) starts its two ranks itself and prints ONE contract line with n_gpus == 2; the record carries the
+    grad-buffer sweep that shows where the step turns exchange-bound."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--steps",
+           "2", "--warmup", "1", "--config", "C2", "--grad-buffer-floats", "300000", "--profile-steps", "1"]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and [r["rank"] for r in rec["ranks"]] == [0, 1]
+    sweep = rec["multi_gpu"]["grad_buffer_sweep"]
+    assert [e["floats"] for e in sweep] == [0, 300000] and all(e["overlapped_ms_per_step"] > 0 for e in sweep)
