@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libggr_raster.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -68,7 +68,7 @@ class GgrBackwardOut(C.Structure):
         ("dL_dprojmatrix", C.c_void_p), ("dL_dcampos", C.c_void_p), ("stage_ms", C.c_void_p),
     ]
 
-FWD_STAGES = ["preprocess", "depth_sort", "tile_count", "tile_scatter", "blend"]
+FWD_STAGES = ["preprocess", "depth_sort", "tile_count", "tile_scatter", "blend", "colour_side_stream"]
 BWD_STAGES = ["clear", "blend", "preprocess"]
 
 

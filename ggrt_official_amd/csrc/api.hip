@@ -118,6 +118,61 @@ ReadbackSlot* readback_slot() {
     return &r;
 }
 
+// The forward's side stream (forward_impl): the SH colour half of the per-Gaussian stage runs on it beside the depth sort and
+// the tile-list kernels.  One per (host thread, device), like the read-back slot: created on first use, lowest priority (the
+// kernels of the caller's stream — the critical path — win the CUs whenever both have workgroups to place), ordered against
+// the caller's stream by two events per forward (fork behind the geometry kernel, join in front of the blend).  Holds no
+// state between calls; two forwards of one thread on two streams share it and merely serialise their colour kernels.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;   // timing brackets of the colour kernel (stage profiling only)
+    bool failed = false;
+};
+SideStream* side_stream() {
+    static thread_local SideStream slots[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    SideStream& r = slots[dev];
+    if (r.failed) return nullptr;
+    if (!r.stream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority (numerically greatest)
+        bool ok = hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&r.join, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreate(&r.t0) == hipSuccess && hipEventCreate(&r.t1) == hipSuccess;
+        if (!ok) { r.failed = true; r.stream = nullptr; (void)hipGetLastError(); return nullptr; }
+    }
+    return &r;
+}
+// GGR_SPLIT_COLOUR=0: the per-Gaussian stage as ONE kernel on the caller's stream (dev / A-B measurements)
+bool split_colour_enabled() {
+    static const int v = [] { const char* e = getenv("GGR_SPLIT_COLOUR"); return (e && *e == '0') ? 0 : 1; }();
+    return v != 0;
+}
+
+// Blocks of the colour kernel's launch (per Gaussian set): GGR_COLOUR_BLOCKS_PER_CU persistent blocks per CU (default 1;
+// 0 = one block per 256-Gaussian chunk, unthrottled).  Unthrottled the kernel finishes in 50 µs at C3 and DOUBLES the
+// duration of the depth-sort passes it runs beside (a sort tile waits for a CU's wave slots and LDS, and every later
+// tile waits for its look-back): forward +13 µs instead of −30.  It has ≈ 150 µs until the blend needs the colours.
+int colour_fork_point() {
+    static const int v = [] { const char* e = getenv("GGR_COLOUR_FORK"); return (e && *e) ? atoi(e) : 0; }();
+    return v;
+}
+int colour_grid_blocks() {
+    static const int v = [] {
+        const char* e = getenv("GGR_COLOUR_BLOCKS_PER_CU");
+        const int per_cu = (e && *e) ? atoi(e) : 1;
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        return per_cu <= 0 ? 0 : per_cu * cus;
+    }();
+    return v;
+}
+
 // The exact mode's wait for num_rendered: the host watches the pinned word (armed with a sentinel no count can take)
 // and, every 1024 polls, asks `query` (hipEventQuery of the event behind the kernel that writes the word) whether the
 // kernel has ended.  Leaves on: the word changed; the query says "done" (the word is then re-read once — a
@@ -289,11 +344,46 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     ImageLayout im = ggr_carve_image(out->image_buffer, W, H, NV);
     StageTimer tm(s, out->stage_ms, GGR_FWD_STAGES);
 
-    // 1. per-Gaussian projection
+    // 1. per-Gaussian projection.  With SH colours the stage is split (preprocess.hip PART): the geometry half runs here, in
+    //    front of the depth sort; the colour half — the SH rows, 4/5 of the stage's bytes, needed by the blend only — runs on
+    //    the side stream beside the latency-bound sort / tile-list kernels (which leave HBM and most CUs idle) and is joined
+    //    in front of the blend.  Not while the caller's stream is being captured into a graph (a thread-local side stream
+    //    would be pulled into the capture), not in debug mode (one kernel at a time), not for precomputed colours.
+    const InputForm inf = input_form(st, in, vs.sets);
+    SideStream* side = nullptr;
+    if (in->shs && P1 > 0 && !dbg && split_colour_enabled()) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) side = side_stream();
+        else (void)hipGetLastError();
+    }
     ggr::launch_preprocess_fwd(P1, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
                                in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
-                               in->aux_precomp, vs, W, H, out->radii, g, input_form(st, in, vs.sets), s);
+                               in->aux_precomp, vs, W, H, out->radii, g, inf, s, side ? GGR_PRE_GEOMETRY : GGR_PRE_ALL, 0,
+                               out->no_backward ? 0 : 1);
     KCHECK(dbg, s, "preprocess_fwd");
+    bool colour_pending = side != nullptr;
+    auto fork_colour = [&]() -> int {   // the colour kernel behind everything queued on `s` so far, on the side stream
+        if (!colour_pending) return GGR_OK;
+        colour_pending = false;
+        HIP_TRY(hipEventRecord(side->fork, s));
+        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        if (out->stage_ms) (void)hipEventRecord(side->t0, side->stream);
+        ggr::launch_preprocess_fwd(P1, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
+                                   in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
+                                   in->aux_precomp, vs, W, H, out->radii, g, inf, side->stream, GGR_PRE_COLOUR,
+                                   colour_grid_blocks(), out->no_backward ? 0 : 1);
+        if (out->stage_ms) (void)hipEventRecord(side->t1, side->stream);
+        HIP_TRY(hipEventRecord(side->join, side->stream));
+        return GGR_OK;
+    };
+    const int fork_at = colour_fork_point();   // 0: beside the depth sort onwards, 1: behind the sort, 2: behind the tile counts
+    if (fork_at == 0) { const int rc = fork_colour(); if (rc != GGR_OK) return rc; }
+    // (every return below this point must leave the caller's stream ordered behind the side stream: JoinGuard)
+    struct JoinGuard {
+        SideStream* sd; hipStream_t s; bool done = false;
+        void join() { if (sd && !done) { (void)hipStreamWaitEvent(s, sd->join, 0); done = true; } }
+        ~JoinGuard() { join(); }
+    } joiner{side, s};
     tm.mark();
 
     // 2. stable sort of the Gaussians by depth bits (ties keep ascending id).  Its last pass also drops every
@@ -314,6 +404,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
                               g.rect, rect_sorted, zero_area, zero_words);
         KCHECK(dbg, s, "depth sort");
     }
+    if (fork_at <= 1) { const int rc = fork_colour(); if (rc != GGR_OK) return rc; }
     tm.mark();
 
     // 3. per-(chunk, tile) counts → list positions, tile ranges, num_rendered
@@ -341,6 +432,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         HIP_TRY(hipMemsetAsync(g.counters, 0, 8, s));
     }
     KCHECK(dbg, s, "tile_list_count");
+    { const int rc = fork_colour(); if (rc != GGR_OK) return rc; }
     if (dbg && sync_free && P > 0) {  // debug mode may sync: check the sort's fault bit right here
         uint32_t two[2] = {0u, 0u};
         HIP_TRY(hipMemcpy(two, g.counters, 8, hipMemcpyDeviceToHost));
@@ -388,7 +480,8 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // 5. blend (clears the caller's backward scratch on the side; an image without tiles launches nothing)
     if (out->backward_scratch && tiles == 0)
         HIP_TRY(hipMemsetAsync(out->backward_scratch, 0, ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s));
-    ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, vs.bg, out->out_color, out->no_backward ? nullptr : im.final_T,
+    joiner.join();   // the colour records (side stream) are complete before the blend reads them
+    ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, g.colour, vs.bg, out->out_color, out->no_backward ? nullptr : im.final_T,
                           im.n_contrib, out->out_depth, out->no_backward ? nullptr : im.ckpt, im.ckpt_slots, im.tile_top, NV,
                           (st->scissor[0] | st->scissor[1] | st->scissor[2] | st->scissor[3]) != 0, out->backward_scratch,
                           ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s);
@@ -414,6 +507,11 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
             return fail(GGR_E_CAPACITY, "num_rendered %u exceeds the hinted capacity %u", num_rendered, capacity);
     }
     tm.finish();
+    if (out->stage_ms && side) {   // the colour kernel's own duration (it ran BESIDE stages 1-3, not in addition to them)
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, side->t0, side->t1) == hipSuccess) out->stage_ms[GGR_FWD_COLOUR] += ms;
+        else (void)hipGetLastError();
+    }
     return GGR_OK;
 }
 
@@ -454,14 +552,14 @@ int backward_impl(const GgrSettings* st, const ViewSet& vs, const GgrBackwardIn*
     tm.mark();
 
     if (in->num_rendered != 0) {  // (-1: sync-free forward, count known on the device only)
-        ggr::launch_blend_bwd(W, H, im.ranges, point_list, g.splat, vs.bg, im.final_T, im.n_contrib,
+        ggr::launch_blend_bwd(W, H, im.ranges, point_list, g.splat, g.colour, vs.bg, im.final_T, im.n_contrib,
                               in->dL_dout_color, in->dL_dout_depth, sc.grad2d, im.tile_top, im.ckpt,
                               im.ckpt_slots, im.bwd_segments, NV, s);
         KCHECK(dbg, s, "blend_bwd");
     }
     tm.mark();
     const float* cov = in->fwd.cov3D_precomp ? in->fwd.cov3D_precomp : g.cov3D;
-    ggr::launch_preprocess_bwd(P, st->sh_degree, st->sh_stride, in->fwd.means3D, in->fwd.shs, has_cp ? 1 : 0,
+    ggr::launch_preprocess_bwd(P, st->sh_degree, st->sh_stride, in->fwd.means3D, in->fwd.shs, g.sh_jac, has_cp ? 1 : 0,
                                in->fwd.scales, in->fwd.rotations, st->scale_modifier, cov, vs, W, H, in->radii, g.clamped,
                                sc.grad2d, in->dL_dout_depth ? 1 : 0, out->dL_dmeans3D, out->dL_dmeans2D,
                                out->dL_dopacities, out->dL_dshs, out->dL_dcolors_precomp, out->dL_dcov3D,

@@ -109,6 +109,7 @@ template <bool HAS_DEPTH>
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
+                 const float4* __restrict__ colour,
                  const float* __restrict__ bg, const float* __restrict__ final_T,
                  const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                  const float* __restrict__ dL_ddepth, float* __restrict__ grad2d,
@@ -223,8 +224,9 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         const uint32_t g = g_next;
         if (hi_ - BATCH - 1 - tid >= seg_lo) g_next = point_list[range.x + hi_ - BATCH - 1 - tid];
         if (tid < nb) {
-            float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1];
-            float4 c = splat[3 * (size_t)g + 2];
+            float4 a = splat[2 * (size_t)g];
+            const float4 ge = splat[2 * (size_t)g + 1], co = colour[g];   // (as blend_fwd.hip)
+            float4 b = make_float4(ge.x, ge.y, co.x, co.y), c = make_float4(co.z, ge.z, ge.w, 0.f);
             stage_scale_conic(a, b, c);  // (blend_common.h: the pixel loop works on k·q, k = log2(e)/2)
             c.w = __uint_as_float(g);
             stage[tid].a = a;
@@ -398,6 +400,7 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 }
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
+                      const float4* colour,
                       const float* bg, const float* final_T, const uint32_t* n_contrib,
                       const float* dL_dpix, const float* dL_ddepth, float* grad2d, const uint32_t* tile_top,
                       const float* ckpt, int ckpt_slots, int segments, int views, hipStream_t s) {
@@ -408,11 +411,11 @@ void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_l
     segments = (ckpt && ckpt_slots >= 2) ? ckpt_slots : 1;
     if (dL_ddepth)
         hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(xcd_grid(nt) * segments), dim3(256), 0, s, W, H, gx, ranges,
-                           point_list, splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d, tile_top, ckpt,
+                           point_list, splat, colour, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d, tile_top, ckpt,
                            ckpt_slots, segments, views);
     else
         hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(xcd_grid(nt) * segments), dim3(256), 0, s, W, H, gx, ranges,
-                           point_list, splat, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d, tile_top, ckpt,
+                           point_list, splat, colour, bg, final_T, n_contrib, dL_dpix, dL_ddepth, grad2d, tile_top, ckpt,
                            ckpt_slots, segments, views);
 }
 

@@ -32,6 +32,7 @@ template <bool TRAIN>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
+                 const float4* __restrict__ colour,
                  const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ out_depth, float* __restrict__ ckpt,
                  int ckpt_slots, uint32_t* __restrict__ tile_top, int views, int interleaved, float4* __restrict__ zero4,
@@ -108,7 +109,11 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         const uint32_t g = g_next;
         if (b0 + BATCH + tid < total) g_next = point_list[range.x + b0 + BATCH + tid];
         if (tid < nb) {
-            float4 a = splat[3 * (size_t)g], b = splat[3 * (size_t)g + 1], c = splat[3 * (size_t)g + 2];
+            // the entry's 32-B geometry record and 16-B colour record (ggr_common.h), into the staged layout {x, y, cxx, cxy |
+            // cyy, opacity, r, g | b, z, qmax, –}
+            float4 a = splat[2 * (size_t)g];
+            const float4 ge = splat[2 * (size_t)g + 1], co = colour[g];
+            float4 b = make_float4(ge.x, ge.y, co.x, co.y), c = make_float4(co.z, ge.z, ge.w, 0.f);
             stage_scale_conic(a, b, c);  // (blend_common.h: the pixel loop works on k·q, k = log2(e)/2)
             stage[tid].a = a;
             stage[tid].b = b;
@@ -217,6 +222,7 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 }
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
+                      const float4* colour,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
                       float* out_depth, float* ckpt, int ckpt_slots, uint32_t* tile_top, int views, int scissored,
                       void* zero_area, size_t zero_bytes, hipStream_t s) {
@@ -225,7 +231,7 @@ void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_l
     // (final_T == nullptr: the caller keeps nothing for a backward)
 #define GGR_LAUNCH_BFWD(TRAIN_)                                                                                              \
     hipLaunchKernelGGL(blend_fwd_kernel<TRAIN_>, dim3(xcd_grid(gx * gy * views)), dim3(256), 0, s, W, H, gx, ranges, point_list,  \
-                       splat, bg, out_color, final_T, n_contrib, out_depth, ckpt, ckpt_slots, tile_top, views,               \
+                       splat, colour, bg, out_color, final_T, n_contrib, out_depth, ckpt, ckpt_slots, tile_top, views,               \
                        xcd_forward_interleaved(gx * gy * views, scissored != 0) ? 1 : 0, (float4*)zero_area,                 \
                        zero_area ? zero_bytes / 16 : 0)
     if (final_T) GGR_LAUNCH_BFWD(true);

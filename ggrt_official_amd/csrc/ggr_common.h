@@ -3,11 +3,19 @@
 // Data layout in HBM (all caller-owned, carved out of opaque buffers; 256-B aligned sections)
 //
 //   geom buffer   (per Gaussian, P entries; kept for backward)
-//     splat[P]         3 × float4 = 48 B  {x, y, conic.xx, conic.xy | conic.yy, opacity, r, g | b, f, qmax, 0}
-//                      one record = everything the blend kernels need for a list entry, so a tile-list
-//                      fetch is ONE 48-B gather instead of three gathers from three SoA arrays
-//                      (f = view-space z or the caller's aux feature; qmax = 2·ln(255·opacity): the largest
-//                      dᵀ·conic·d at which α still reaches 1/255)
+//     splat[P]         2 × float4 = 32 B  {x, y, conic.xx, conic.xy | conic.yy, opacity, f, qmax}
+//     colour[P]        1 × float4 = 16 B  {r, g, b, 0}
+//                      together everything the blend kernels need for a list entry (f = view-space z or the
+//                      caller's aux feature; qmax = 2·ln(255·opacity): the largest dᵀ·conic·d at which α still
+//                      reaches 1/255): a tile-list fetch is a 32-B and a 16-B gather, both sector-aligned.  Two
+//                      arrays because two kernels write them: the geometry half of preprocess_fwd sits on the
+//                      forward's critical path in front of the depth sort, the colour half (the SH rows: 4/5 of
+//                      the stage's bytes) runs on a side stream BESIDE the latency-bound sort and tile-list
+//                      kernels and is only needed by the blend (preprocess.hip, api.hip forward_impl)
+//     sh_jac[3][P]     float4 per channel c = r, g, b (three planes): {∂colour_c/∂dir.x, ∂colour_c/∂dir.y, ∂colour_c/∂dir.z, 0}, the Jacobian of the
+//                      (unclamped) SH colour w.r.t. the unit view direction, left by the forward's colour evaluation while
+//                      the SH row is in LDS anyway — the backward's view-direction term is then Jᵀ·dL/dcolour and it does
+//                      not read the SH rows again (192 B per Gaussian at 16 coefficients, 300 B at GGRt's 25)
 //     rect[P]          u32×2 packed tile rect (minx | miny<<16, maxx | maxy<<16)
 //     clamped[P]       u32   bit c set ⇔ SH colour channel c was clamped at 0
 //     cov3D[P]         6 × f32 (scale/rot path only; otherwise the caller's cov3D_precomp is used)
@@ -138,7 +146,9 @@ static inline size_t ggr_sort_hist_words(size_t n, size_t S = 1) {
 }
 
 struct GeomLayout {
-    float4* splat;
+    float4* splat;    // [P][2]
+    float4* colour;   // [P]
+    float4* sh_jac;   // [3][P]
     uint2* rect;
     uint32_t* clamped;
     float* cov3D;
@@ -158,7 +168,9 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P, size_t segments = 
     size_t o = 0;
     size_t Pp = P ? P : 1;
     auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes); return r; };
-    L.splat = (float4*)take(Pp * 48);
+    L.splat = (float4*)take(Pp * 32);
+    L.colour = (float4*)take(Pp * 16);
+    L.sh_jac = (float4*)take(Pp * 48);
     L.rect = (uint2*)take(Pp * 8);
     L.clamped = (uint32_t*)take(Pp * 4);
     L.cov3D = (float*)take(Pp * 24);
@@ -318,7 +330,13 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
                            const float* aux_precomp, ViewSet vs, int W, int H, int32_t* radii,
-                           GeomLayout g, InputForm inf, hipStream_t s);
+                           GeomLayout g, InputForm inf, hipStream_t s,
+                           int part = 0 /*GGR_PRE_ALL, GGR_PRE_GEOMETRY, GGR_PRE_COLOUR (preprocess.hip)*/,
+                           int colour_grid = 0 /*COLOUR: persistent blocks walking the chunks; 0 = one block per chunk*/,
+                           int keep_jacobian = 1 /*0: no backward will follow (inference) — sh_jac is not written*/);
+#define GGR_PRE_ALL 0
+#define GGR_PRE_GEOMETRY 1
+#define GGR_PRE_COLOUR 2
 
 // stable LSD radix sort of (u32 key, u32 val) pairs, keys in the depth-sort form above (< 2^30, else the fault word
 // is raised); three passes; returns the buffers that hold the result (b after three passes).  The key maxima of the
@@ -362,6 +380,7 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
                               hipStream_t s);
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
+                      const float4* colour,
                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib,
                       float* out_depth, float* ckpt /*or null*/, int ckpt_slots, uint32_t* tile_top, int views,
                       int scissored /*the lists are confined to a window of the frame (GgrSettings.scissor)*/,
@@ -369,6 +388,7 @@ void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_l
                       hipStream_t s);
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
+                      const float4* colour,
                       const float* bg, const float* final_T, const uint32_t* n_contrib,
                       const float* dL_dpix, const float* dL_ddepth /*or null*/, float* grad2d /*[P][16], zeroed*/,
                       const uint32_t* tile_top, const float* ckpt /*or null*/, int ckpt_slots, int segments, int views,
@@ -376,7 +396,8 @@ void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_l
 
 // radii / clamped / grad2d / dL_dmeans2D / dL_daux are per view ([V,P,…]); the other gradients are summed over the
 // views; pose_acc holds V·blocks rows of 64 floats; dL_dview/dL_dproj [V,16], dL_dcampos [V,3]
-void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs,
+void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs /*only says: SH path*/,
+                           const float4* sh_jac /*the forward's ∂colour/∂direction (GeomLayout.sh_jac)*/,
                            int has_colors_precomp, const float* scales, const float* rotations,
                            float scale_modifier, const float* cov3D, ViewSet vs, int W, int H, const int32_t* radii,
                            const uint32_t* clamped,

@@ -9,6 +9,8 @@
 // CPU restatement; gfx950 fp32 divide/sqrt are correctly rounded under hipcc's defaults.
 #include "ggr_common.h"
 #include "sh_stage.h"
+#include "sh_terms.h"
+#include <algorithm>
 
 #pragma clang fp contract(off)
 
@@ -90,24 +92,35 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 // is 25.6 KB (tools/sh_stage_bench.hip: the bare access pattern 0.105 → 0.082 ms at 1 M × 75 floats, 0.063 → 0.050 at
 // 48; the rows' lines are fetched three times, L2 hits after the first).  Every channel still sums its coefficients in
 // ascending k, so the colours stay bit-identical to the whole-row path.
-template <bool MULTI, int KC>
+//
+// PART (GGR_PRE_*): ALL = the whole stage in one launch.  GEOMETRY = everything but the SH colour: projection, 2-D
+// covariance, radius, tile rect, sort key, the 32-B geometry record — ≈ 90 B per Gaussian, the only part the depth
+// sort and the tile lists wait for.  COLOUR = the SH evaluation alone (the rows: 192 / 300 B per Gaussian, 4/5 of the
+// stage's bytes) for the Gaussians GEOMETRY found visible (radii > 0), into the 16-B colour record and the clamp bits —
+// only the blend needs it, so the forward runs it on a side stream beside the latency-bound sort / tile-list kernels
+// (api.hip forward_impl).  Same arithmetic in the same order in every PART: the outputs are bit-identical.
+// JAC: also leave the Jacobian ∂colour/∂direction of every visible Gaussian (ggr_common.h sh_jac) for the backward — nine
+// more sums over the coefficients the colour evaluation has in LDS anyway, and 48 B written per Gaussian, against the
+// backward re-reading the whole SH row (192 / 300 B per Gaussian) for its view-direction term.
+template <bool MULTI, int KC, int PART, bool JAC>
 __global__ void __launch_bounds__(GGR_PRE_THREADS)
 preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       float scale_modifier, const float* __restrict__ cov3D_precomp,
                       const float* __restrict__ aux_precomp, ViewSet vs, int W, int H,
-                      int32_t* __restrict__ radii, float4* __restrict__ splat,
+                      int32_t* __restrict__ radii, float4* __restrict__ splat, float4* __restrict__ colour,
+                      float4* __restrict__ sh_jac, size_t jac_plane,
                       uint32_t* __restrict__ depth_key,
                       uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
                       float* __restrict__ cov3D_out, uint32_t* __restrict__ zero_area, uint32_t zero_words,
                       uint32_t* __restrict__ block_max, InputForm inf) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_row_stride]
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // zero the depth sort's histogram / ticket / look-back words here instead of with a separate fill launch
-    for (uint32_t wz = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; wz < zero_words;
-         wz += gridDim.x * gridDim.y * blockDim.x)
-        zero_area[wz] = 0u;
+    if (PART != GGR_PRE_COLOUR)
+        for (uint32_t wz = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; wz < zero_words;
+             wz += gridDim.x * gridDim.y * blockDim.x)
+            zero_area[wz] = 0u;
     // ---- Gaussian set blockIdx.y of the launch set (ViewSet.sets; one set: nothing moves) ----------------------------
     // The set's inputs are rows [set·P, (set+1)·P) of the caller's arrays, its views are views [v0, v0 + vps): every
     // pointer is rebased once, here, so that the rest of the kernel indexes (view, Gaussian) relative to the set.
@@ -119,7 +132,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     if (cov3D_precomp) cov3D_precomp += (size_t)inf.cov_stride * in_off;
     if (scales) { scales += 3 * in_off; rotations += 4 * in_off; }
     if (aux_precomp) aux_precomp += st_off;
-    radii += st_off; splat += 3 * st_off; depth_key += st_off;
+    radii += st_off; splat += 2 * st_off; colour += st_off; depth_key += st_off;
+    if (JAC) sh_jac += st_off;   // (three planes of V·P float4s: channel c of pair o at c·jac_plane + o)
     rect += st_off; clamped_out += st_off;
     if (cov3D_out) cov3D_out += 6 * st_off;
     vs.view += 16 * v0; vs.proj += 16 * v0; vs.campos += 3 * v0;
@@ -139,13 +153,22 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const bool sh_compact = M * 3 > sh_rowf && M * 3 <= 128 && (sh_flat || inf.sh_channel_major);
     const int sh_stride = sh_compact ? (sh_rowf | 1) : sh_flat ? M * 3 : (copy_row | 1);
     const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? (sh_compact ? sh_rowf / 3 : M) : 1;
+    // A block works on the 256-Gaussian chunks bx = blockIdx.x, blockIdx.x + gridDim.x, …: one chunk per block (gridDim.x =
+    // the number of chunks) everywhere except for a THROTTLED colour launch — a few persistent blocks per CU, so that the
+    // kernel leaves the CUs' wave slots, LDS and most of the HBM queue to the depth sort it runs beside (api.hip)
+    const int nchunks = (P + (int)blockDim.x - 1) / (int)blockDim.x;
+#pragma clang loop unroll(disable)
+    for (int bx = blockIdx.x; bx < nchunks; bx += gridDim.x) {
+    if (bx != (int)blockIdx.x) __syncthreads();   // the previous chunk's rows in LDS have been consumed
+    const int i = bx * blockDim.x + threadIdx.x;
     // this thread's own inputs are requested BEFORE the SH staging, so that their round trip overlaps it
     // (clamped index: threads past P load Gaussian P-1 and drop it)
     const size_t il = (size_t)min(i, P - 1);
     const float m0 = means3D[3 * il], m1 = means3D[3 * il + 1], m2 = means3D[3 * il + 2];   // (non-temporal: no difference)
-    const float opac = opacities[il];
-    float cin[6], rin[4] = {0.f, 0.f, 0.f, 0.f};
-    if (cov3D_precomp) {
+    const float opac = PART != GGR_PRE_COLOUR ? opacities[il] : 0.f;
+    float cin[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rin[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PART == GGR_PRE_COLOUR) {
+    } else if (cov3D_precomp) {
         if (inf.cov_stride == 9) {
             const float* c9 = cov3D_precomp + 9 * il;
             cin[0] = c9[0]; cin[1] = c9[1]; cin[2] = c9[2]; cin[3] = c9[4]; cin[4] = c9[5]; cin[5] = c9[8];
@@ -165,8 +188,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     constexpr int KCN = KC > 0 ? KC : 1, KC_STRIDE = KC | 1;
     ShThirds<KCN> thirds;
     float ch_v[ShThirds<KCN>::ITS];
-    if (shs) {
-        const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+    if (shs && PART != GGR_PRE_GEOMETRY) {
+        const size_t g0 = (size_t)bx * blockDim.x;
         const int nG = (int)min((size_t)blockDim.x, (size_t)P - g0);
         const size_t row = (size_t)M * 3;
         if (KC == 0) {
@@ -193,7 +216,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float tanfovy = vs.tanfov ? vs.tanfov[2 * v + 1] : vs.tanfovy;
         const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;
         const size_t o = (size_t)v * P + (size_t)il;  // per-view index of this Gaussian's state
-        const float aux_in = aux_precomp ? aux_precomp[o] : 0.f;
+        const float aux_in = (aux_precomp && PART != GGR_PRE_COLOUR) ? aux_precomp[o] : 0.f;
+        // COLOUR: what GEOMETRY decided (a visible Gaussian has radius >= 1)
+        const int rad_seen = PART == GGR_PRE_COLOUR ? radii[o] : 0;
 
         // defaults for a culled Gaussian
         int rad_out = 0;
@@ -205,8 +230,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         // 66-73) and its upper-triangle gather out of [P,3,3] covariances (:116,124) happen on load.  One fp32
         // multiply per value, exactly what the torch ops of the unfused call site do.
         const float p0 = in_s * m0, p1 = in_s * m1, p2 = in_s * m2;
-        float cov6[6];
-        if (cov3D_precomp) {
+        float cov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (PART == GGR_PRE_COLOUR) {
+        } else if (cov3D_precomp) {
             const float s2 = in_s * in_s;
 #pragma unroll
             for (int k = 0; k < 6; k++) cov6[k] = cin[k] * s2;
@@ -220,12 +246,12 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
 
         // ---- geometry: visible (in front of the near plane, invertible 2D covariance, touches a tile) or culled ----
-        bool vis = false;
+        bool vis = PART == GGR_PRE_COLOUR && in_range && rad_seen > 0;
         float px = 0.f, py = 0.f, con0 = 0.f, con1 = 0.f, con2 = 0.f;
         float t0 = V[0] * p0 + V[4] * p1 + V[8] * p2 + V[12];
         float t1 = V[1] * p0 + V[5] * p1 + V[9] * p2 + V[13];
         const float t2 = V[2] * p0 + V[6] * p1 + V[10] * p2 + V[14];
-        if (t2 > GGR_NEAR_CULL && in_range) {
+        if (PART != GGR_PRE_COLOUR && t2 > GGR_NEAR_CULL && in_range) {
             const float ph0 = PM[0] * p0 + PM[4] * p1 + PM[8] * p2 + PM[12];
             const float ph1 = PM[1] * p0 + PM[5] * p1 + PM[9] * p2 + PM[13];
             const float ph3 = PM[3] * p0 + PM[7] * p1 + PM[11] * p2 + PM[15];
@@ -310,7 +336,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         float rgb[3] = {0.f, 0.f, 0.f};
         if (colors_precomp) {
             rgb[0] = cp_in[0]; rgb[1] = cp_in[1]; rgb[2] = cp_in[2];
-        } else if (KC > 0 || vis) {
+        } else if (PART != GGR_PRE_GEOMETRY && (KC > 0 || vis)) {
             // (chunked staging: every thread walks the thirds — the barriers between them are block-wide; a culled
             //  Gaussian's sums are dropped below)
             const int deg = KC == 16 ? 3 : KC == 25 ? 4 : sh_deg;
@@ -320,11 +346,31 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             float B[25];
             sh_basis(deg, d0, d1, d2, B);
             float r[3] = {0.f, 0.f, 0.f};
+            float jac[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // [channel][x, y, z]
             if (KC == 0) {
                 const int K = (deg + 1) * (deg + 1);
                 const float* sh = sh_lds + threadIdx.x * sh_stride;
-                for (int k = 0; k < K; k++) {
-                    r[0] += B[k] * sh[k * sh_ks]; r[1] += B[k] * sh[k * sh_ks + sh_cs]; r[2] += B[k] * sh[k * sh_ks + 2 * sh_cs];
+                if (!JAC) {
+                    for (int k = 0; k < K; k++) {
+                        r[0] += B[k] * sh[k * sh_ks]; r[1] += B[k] * sh[k * sh_ks + sh_cs]; r[2] += B[k] * sh[k * sh_ks + 2 * sh_cs];
+                    }
+                } else {
+                    // colour and Jacobian in ONE walk over the row (the term generator's basis values are sh_basis's,
+                    // expression for expression, and the colour sums keep their order and their unfused multiply-add: the
+                    // colours stay bit-identical; the Jacobian sums are fused multiply-adds)
+                    float x = d0, y = d1, z = d2;
+#define SH_JAC(k, Bk, bx, by, bz)                                                                                          \
+    {                                                                                                                     \
+        const float b_ = (Bk), s0 = sh[(k) * sh_ks], s1 = sh[(k) * sh_ks + sh_cs], s2 = sh[(k) * sh_ks + 2 * sh_cs];         \
+        r[0] += b_ * s0; r[1] += b_ * s1; r[2] += b_ * s2;                                                                \
+        jac[0] = fmaf((bx), s0, jac[0]); jac[1] = fmaf((by), s0, jac[1]); jac[2] = fmaf((bz), s0, jac[2]);                \
+        jac[3] = fmaf((bx), s1, jac[3]); jac[4] = fmaf((by), s1, jac[4]); jac[5] = fmaf((bz), s1, jac[5]);                \
+        jac[6] = fmaf((bx), s2, jac[6]); jac[7] = fmaf((by), s2, jac[7]); jac[8] = fmaf((bz), s2, jac[8]);                \
+    }
+#define SH_FENCE __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(xx), "+v"(yy), "+v"(zz), "+v"(xy), "+v"(yz), "+v"(xz) :: "memory");
+                    GGR_SH_TERMS(SH_JAC, deg, SH_FENCE)
+#undef SH_FENCE
+#undef SH_JAC
                 }
             } else {
                 const float* seg = sh_lds + threadIdx.x * KC_STRIDE;
@@ -339,17 +385,53 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     thirds.store(sh_lds, ch_v);
                     if (J < 2) thirds.load(ch_v, J + 1);
                     __syncthreads();
-                    if (cm) {   // third J = channel J, coefficients 0 … KC-1
+                    if (!JAC) {
+                        if (cm) {   // third J = channel J, coefficients 0 … KC-1
 #pragma unroll
-                        for (int k = 0; k < KCN; k++) r[J] += B[k] * seg[k];
-                    } else {    // third J = floats [J·KC, (J+1)·KC) of the k-major row: float f = coefficient f / 3, channel f mod 3
+                            for (int k = 0; k < KCN; k++) r[J] += B[k] * seg[k];
+                        } else {    // third J = floats [J·KC, (J+1)·KC) of the k-major row: float f = coefficient f / 3, channel f mod 3
 #pragma unroll
-                        for (int e = 0; e < KCN; e++) {
-                            const int f = J * KCN + e;
-                            r[f % 3] += B[f / 3] * seg[e];
+                            for (int e = 0; e < KCN; e++) {
+                                const int f = J * KCN + e;
+                                r[f % 3] += B[f / 3] * seg[e];
+                            }
                         }
+                    } else {
+                        // colour and Jacobian in one walk over the third (see the whole-row form above); the basis and its
+                        // gradient are formed anew in every third, band by band behind compiler fences — shared across the
+                        // three unrolled copies they are ≈ 100 live values
+                        float x = d0, y = d1, z = d2;
+                        __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z));
+#define SH_JAC_CM(k, Bk, bx, by, bz)                                                                   \
+    {                                                                                                  \
+        const float s_ = seg[k];                                                                       \
+        r[J] += (Bk) * s_;                                                                             \
+        jac[3 * J] = fmaf((bx), s_, jac[3 * J]); jac[3 * J + 1] = fmaf((by), s_, jac[3 * J + 1]);      \
+        jac[3 * J + 2] = fmaf((bz), s_, jac[3 * J + 2]);                                               \
+    }
+#define SH_JAC_KM(k, Bk, bx, by, bz)                                                                   \
+    _Pragma("unroll") for (int c = 0; c < 3; c++)                                                      \
+        if ((3 * (k) + c) / KCN == J) {                                                                \
+            const float s_ = seg[3 * (k) + c - J * KCN];                                               \
+            r[c] += (Bk) * s_;                                                                         \
+            jac[3 * c] = fmaf((bx), s_, jac[3 * c]); jac[3 * c + 1] = fmaf((by), s_, jac[3 * c + 1]);  \
+            jac[3 * c + 2] = fmaf((bz), s_, jac[3 * c + 2]);                                           \
+        }
+#define SH_FENCE __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(xx), "+v"(yy), "+v"(zz), "+v"(xy), "+v"(yz), "+v"(xz) :: "memory");
+                        if (cm) GGR_SH_TERMS(SH_JAC_CM, (KC == 16 ? 3 : 4), SH_FENCE)
+                        if (!cm) GGR_SH_TERMS(SH_JAC_KM, (KC == 16 ? 3 : 4), SH_FENCE)
+#undef SH_FENCE
+#undef SH_JAC_CM
+#undef SH_JAC_KM
                     }
                 }
+            }
+            if (JAC && vis && in_range) {
+                // (one plane per channel: a wave's store covers 1 KB of whole lines — as one 48-B record per Gaussian the
+                //  three partial-line stores cost the kernel 16 µs at C3 on top of the bytes)
+                ggr_st_f4(reinterpret_cast<float*>(sh_jac + o), make_float4(jac[0], jac[1], jac[2], 0.f));
+                ggr_st_f4(reinterpret_cast<float*>(sh_jac + jac_plane + o), make_float4(jac[3], jac[4], jac[5], 0.f));
+                ggr_st_f4(reinterpret_cast<float*>(sh_jac + 2 * jac_plane + o), make_float4(jac[6], jac[7], jac[8], 0.f));
             }
             r[0] += 0.5f; r[1] += 0.5f; r[2] += 0.5f;
             if (vis) clamp_bits = (r[0] < 0.f ? 1u : 0u) | (r[1] < 0.f ? 2u : 0u) | (r[2] < 0.f ? 4u : 0u);
@@ -357,46 +439,57 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
         if (vis) {
             s0 = make_float4(px, py, con0, con1);
-            s1 = make_float4(con2, opac, rgb[0], rgb[1]);
             // 4th blended feature: the caller's aux value, or view z, or (fused GGRt depth pass, :240-269)
             // max(a + b·z_unscaled, 0) with z_unscaled = z / s
             float feat = t2;
             if (aux_precomp) feat = aux_in;
             else if (inf.aux_affine) feat = fmaxf(inf.aux_a + inf.aux_b * (t2 / in_s), 0.f);
-            s2 = make_float4(rgb[2], feat, 2.f * logf(255.f * opac), 0.f);  // .z = qmax for the box cull
+            s1 = make_float4(con2, opac, feat, 2.f * logf(255.f * opac));  // .w = qmax for the box cull
+            s2 = make_float4(rgb[0], rgb[1], rgb[2], 0.f);
         }
         if (in_range) {
-            ggr_st(radii + o, rad_out);     // (an output tensor and the clamp bits: not read again before the backward)
-            depth_key[o] = key_out;       // written straight into the depth sort's key / value input buffers
-            // (no sort VALUES are written: the depth sort's first pass forms the identity — the global (view, Gaussian) index —
-            //  itself; and no tiles_touched: it is the area of the packed rect.  Two output streams and 8 B per Gaussian less)
-            rect[o] = rect_out;
-            ggr_st(clamped_out + o, clamp_bits);
-            splat[3 * o] = s0;          // (plain stores: the records, keys and rects are read again within the forward —
-            splat[3 * o + 1] = s1;      //  non-temporal they measured the same or worse)
-            splat[3 * o + 2] = s2;
+            if (PART != GGR_PRE_COLOUR) {
+                ggr_st(radii + o, rad_out);   // (an output tensor: not read again before the backward — or, split, by COLOUR)
+                depth_key[o] = key_out;       // written straight into the depth sort's key / value input buffers
+                // (no sort VALUES are written: the depth sort's first pass forms the identity — the global (view, Gaussian)
+                //  index — itself; and no tiles_touched: it is the area of the packed rect.  Two output streams and 8 B per
+                //  Gaussian less)
+                rect[o] = rect_out;
+                splat[2 * o] = s0;          // (plain stores: the records, keys and rects are read again within the forward —
+                splat[2 * o + 1] = s1;      //  non-temporal they measured the same or worse)
+            }
+            // the colour record and the clamp bits: by whoever evaluates the colour (precomputed colours: GEOMETRY)
+            if (PART != GGR_PRE_GEOMETRY || colors_precomp) {
+                colour[o] = s2;
+                ggr_st(clamped_out + o, clamp_bits);   // (not read again before the backward)
+            }
         }
         km = max(km, key_out);
     }
     // the largest sort key of this block: the depth sort derives its digit width from these (binning.hip)
+    if (PART == GGR_PRE_COLOUR) continue;
     __shared__ uint32_t kmax[GGR_PRE_THREADS / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, off));
     if ((threadIdx.x & 63) == 0) kmax[threadIdx.x >> 6] = km;
     __syncthreads();
-    if (threadIdx.x == 0) block_max[blockIdx.y * gridDim.x + blockIdx.x] = max(max(kmax[0], kmax[1]), max(kmax[2], kmax[3]));
+    if (threadIdx.x == 0) block_max[blockIdx.y * nchunks + bx] = max(max(kmax[0], kmax[1]), max(kmax[2], kmax[3]));
+    }   // chunks
 }
 
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
                            const float* aux_precomp, ViewSet vs, int W, int H, int32_t* radii,
-                           GeomLayout g, InputForm inf, hipStream_t s) {
+                           GeomLayout g, InputForm inf, hipStream_t s, int part, int colour_grid, int keep_jacobian) {
     if (P <= 0) return;
+    if (part == GGR_PRE_COLOUR && !shs) return;   // precomputed colours: GEOMETRY has written the colour records
     // the depth sort's work area (binning.hip), sized for the V·P keys of all views
     const uint32_t zero_words = (uint32_t)ggr_sort_zero_words((size_t)P * vs.V, ggr_sort_segments((size_t)vs.V));
     const int threads = GGR_PRE_THREADS;
-    const int blocks = (P + threads - 1) / threads;
+    const int chunks = (P + threads - 1) / threads;
+    // (colour_grid > 0, COLOUR only: that many persistent blocks walk the chunks — see the kernel)
+    const int blocks = (part == GGR_PRE_COLOUR && colour_grid > 0) ? std::min(chunks, colour_grid) : chunks;
     const int deg = ggr_sh_degree(D, shs ? M : 25, inf.sh_cap);
     const bool flat = ((3 * M) & 1) && inf.sh_aligned;  // same predicate as the kernel
     const size_t copy_row = inf.sh_channel_major ? (size_t)(3 * M) : (size_t)(3 * (deg + 1) * (deg + 1));
@@ -405,16 +498,31 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     const size_t row_stride = compact ? (rowf | 1) : flat ? (size_t)(3 * M) : (copy_row | 1);
     // one view at degree 3 / 4: the rows go through LDS a third at a time (see the kernel's header)
     const int kc = (shs && vs.vps == 1 && (deg == 3 || deg == 4)) ? (deg + 1) * (deg + 1) : 0;
-    const size_t lds = !shs ? 0 : kc ? (size_t)threads * (kc | 1) * sizeof(float) : (size_t)threads * row_stride * sizeof(float);
-#define GGR_LAUNCH_PFWD(MULTI_, KC_)                                                                                      \
-    hipLaunchKernelGGL((preprocess_fwd_kernel<MULTI_, KC_>), dim3(blocks, vs.sets), dim3(threads), lds, s, P, D, M, means3D, shs,  \
-                       colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp, aux_precomp, vs, W, H, \
-                       radii, g.splat, g.keys_a, g.rect, g.clamped, g.cov3D, g.hist,          \
-                       zero_words, g.hist + zero_words, inf)
-    if (vs.vps > 1) GGR_LAUNCH_PFWD(true, 0);
-    else if (kc == 16) GGR_LAUNCH_PFWD(false, 16);
-    else if (kc == 25) GGR_LAUNCH_PFWD(false, 25);
-    else GGR_LAUNCH_PFWD(false, 0);
+    const size_t lds = (!shs || part == GGR_PRE_GEOMETRY) ? 0 : kc ? (size_t)threads * (kc | 1) * sizeof(float)
+                                                                   : (size_t)threads * row_stride * sizeof(float);
+#define GGR_LAUNCH_PFWD_J(MULTI_, KC_, PART_, JAC_)                                                                       \
+    hipLaunchKernelGGL((preprocess_fwd_kernel<MULTI_, KC_, PART_, JAC_>), dim3(blocks, vs.sets), dim3(threads), lds, s, P, D, \
+                       M, means3D, shs, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,       \
+                       aux_precomp, vs, W, H, radii, g.splat, g.colour, g.sh_jac, (size_t)P * vs.V, g.keys_a, g.rect, g.clamped, g.cov3D,    \
+                       g.hist, zero_words, g.hist + zero_words, inf)
+    const bool jac = keep_jacobian != 0 && shs != nullptr;
+#define GGR_LAUNCH_PFWD(MULTI_, KC_, PART_)                                                                               \
+    do { if (jac) GGR_LAUNCH_PFWD_J(MULTI_, KC_, PART_, true); else GGR_LAUNCH_PFWD_J(MULTI_, KC_, PART_, false); } while (0)
+    if (part == GGR_PRE_GEOMETRY) {   // (no SH rows: no staging variant, no Jacobian)
+        if (vs.vps > 1) GGR_LAUNCH_PFWD_J(true, 0, GGR_PRE_GEOMETRY, false);
+        else GGR_LAUNCH_PFWD_J(false, 0, GGR_PRE_GEOMETRY, false);
+    } else if (part == GGR_PRE_COLOUR) {
+        if (vs.vps > 1) GGR_LAUNCH_PFWD(true, 0, GGR_PRE_COLOUR);
+        else if (kc == 16) GGR_LAUNCH_PFWD(false, 16, GGR_PRE_COLOUR);
+        else if (kc == 25) GGR_LAUNCH_PFWD(false, 25, GGR_PRE_COLOUR);
+        else GGR_LAUNCH_PFWD(false, 0, GGR_PRE_COLOUR);
+    } else {
+        if (vs.vps > 1) GGR_LAUNCH_PFWD(true, 0, GGR_PRE_ALL);
+        else if (kc == 16) GGR_LAUNCH_PFWD(false, 16, GGR_PRE_ALL);
+        else if (kc == 25) GGR_LAUNCH_PFWD(false, 25, GGR_PRE_ALL);
+        else GGR_LAUNCH_PFWD(false, 0, GGR_PRE_ALL);
+    }
+#undef GGR_LAUNCH_PFWD_J
 #undef GGR_LAUNCH_PFWD
 }
 
@@ -432,16 +540,17 @@ void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, u
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
 }
 
-__global__ void unpack_geom_kernel(int P, const float4* __restrict__ splat, const uint2* __restrict__ rect,
+__global__ void unpack_geom_kernel(int P, const float4* __restrict__ splat, const float4* __restrict__ colour,
+                                   const uint2* __restrict__ rect,
                                    const uint32_t* __restrict__ cl, float* depth, float* xy, float* co,
                                    float* rgb, int32_t* tiles, uint8_t* clamped) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const float4 s0 = splat[3 * (size_t)i], s1 = splat[3 * (size_t)i + 1], s2 = splat[3 * (size_t)i + 2];
-    if (depth) depth[i] = s2.y;
+    const float4 s0 = splat[2 * (size_t)i], s1 = splat[2 * (size_t)i + 1], s2 = colour[i];
+    if (depth) depth[i] = s1.z;
     if (xy) { xy[2 * i] = s0.x; xy[2 * i + 1] = s0.y; }
     if (co) { co[4 * i] = s0.z; co[4 * i + 1] = s0.w; co[4 * i + 2] = s1.x; co[4 * i + 3] = s1.y; }
-    if (rgb) { rgb[3 * i] = s1.z; rgb[3 * i + 1] = s1.w; rgb[3 * i + 2] = s2.x; }
+    if (rgb) { rgb[3 * i] = s2.x; rgb[3 * i + 1] = s2.y; rgb[3 * i + 2] = s2.z; }
     if (tiles) {   // tiles_touched = area of the packed tile rect (minx | miny << 16, maxx | maxy << 16)
         const uint2 rc = rect[i];
         tiles[i] = (int32_t)(((rc.y & 0xFFFFu) - (rc.x & 0xFFFFu)) * ((rc.y >> 16) - (rc.x >> 16)));
@@ -452,7 +561,7 @@ __global__ void unpack_geom_kernel(int P, const float4* __restrict__ splat, cons
 void launch_unpack_geom(GeomLayout g, int P, float* depth, float* xy, float* conic_opacity, float* rgb,
                         int32_t* tiles_touched, uint8_t* clamped, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(unpack_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.splat, g.rect,
+    hipLaunchKernelGGL(unpack_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.splat, g.colour, g.rect,
                        g.clamped, depth, xy, conic_opacity, rgb, tiles_touched, clamped);
 }
 

@@ -8,21 +8,10 @@
 // campos) — an extension beyond the reference.
 #include "ggr_common.h"
 #include "sh_stage.h"
+#include "sh_terms.h"
 #include <algorithm>
 
 namespace ggr {
-
-#define SH_C0 0.28209479177387814f
-#define SH_C1 0.4886025119029199f
-__device__ __constant__ float bSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                           -1.0925484305920792f, 0.5462742152960396f};
-__device__ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                                           0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
-                                           -0.5900435899266435f};
-
-__device__ __constant__ float bSH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f,
-                                           -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f,
-                                           0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
 
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_take(float v) {
@@ -74,58 +63,6 @@ __device__ __forceinline__ void sh_basis25(int deg, float x, float y, float z, f
     }
 }
 
-// The SH terms of a direction (x, y, z): T(k, B_k, ∂B_k/∂x, ∂B_k/∂y, ∂B_k/∂z) for every coefficient k of degree ≤ deg, in
-// the rasterizer's sign convention (band 4: oracle/ggr_oracle.c header, plain polynomial derivatives).  Needs x, y, z
-// in scope; unused values fold away.  F: statement placed in front of every band (a scheduling fence, or nothing).
-#define GGR_SH_TERMS(T, deg, F)                                                                                            \
-    {                                                                                                                     \
-        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;                                    \
-        T(0, SH_C0, 0.f, 0.f, 0.f)                                                                                        \
-        if ((deg) > 0) {                                                                                                  \
-            F                                                                                                             \
-            T(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)                                                                            \
-            T(2, SH_C1 * z, 0.f, 0.f, SH_C1)                                                                              \
-            T(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)                                                                            \
-            if ((deg) > 1) {                                                                                              \
-                F                                                                                                         \
-                T(4, bSH_C2[0] * xy, bSH_C2[0] * y, bSH_C2[0] * x, 0.f)                                                   \
-                T(5, bSH_C2[1] * yz, 0.f, bSH_C2[1] * z, bSH_C2[1] * y)                                                   \
-                T(6, bSH_C2[2] * (2.f * zz - xx - yy), bSH_C2[2] * -2.f * x, bSH_C2[2] * -2.f * y, bSH_C2[2] * 4.f * z)  \
-                T(7, bSH_C2[3] * xz, bSH_C2[3] * z, 0.f, bSH_C2[3] * x)                                                   \
-                T(8, bSH_C2[4] * (xx - yy), bSH_C2[4] * 2.f * x, bSH_C2[4] * -2.f * y, 0.f)                               \
-                if ((deg) > 2) {                                                                                          \
-                    F                                                                                                     \
-                    T(9, bSH_C3[0] * y * (3.f * xx - yy), bSH_C3[0] * 6.f * xy, bSH_C3[0] * 3.f * (xx - yy), 0.f)         \
-                    T(10, bSH_C3[1] * xy * z, bSH_C3[1] * yz, bSH_C3[1] * xz, bSH_C3[1] * xy)                             \
-                    T(11, bSH_C3[2] * y * (4.f * zz - xx - yy), bSH_C3[2] * -2.f * xy,                                    \
-                      bSH_C3[2] * (-3.f * yy + 4.f * zz - xx), bSH_C3[2] * 8.f * yz)                                      \
-                    T(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), bSH_C3[3] * -6.f * xz,                        \
-                      bSH_C3[3] * -6.f * yz, bSH_C3[3] * 3.f * (2.f * zz - xx - yy))                                      \
-                    F                                                                                                     \
-                    T(13, bSH_C3[4] * x * (4.f * zz - xx - yy), bSH_C3[4] * (-3.f * xx + 4.f * zz - yy),                  \
-                      bSH_C3[4] * -2.f * xy, bSH_C3[4] * 8.f * xz)                                                        \
-                    T(14, bSH_C3[5] * z * (xx - yy), bSH_C3[5] * 2.f * xz, bSH_C3[5] * -2.f * yz, bSH_C3[5] * (xx - yy))  \
-                    T(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)       \
-                    if ((deg) > 3) {                                                                                      \
-                        F                                                                                                 \
-                        const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f, c21 = 21.f * zz - 3.f;                      \
-                        const float xmy = xx - yy, x3y = xx - 3.f * yy, y3x = 3.f * xx - yy;                              \
-                        T(16, bSH_C4[0] * xy * xmy, bSH_C4[0] * y * y3x, bSH_C4[0] * x * x3y, 0.f)                        \
-                        T(17, bSH_C4[1] * yz * y3x, bSH_C4[1] * 6.f * xy * z, bSH_C4[1] * 3.f * z * xmy, bSH_C4[1] * y * y3x) \
-                        T(18, bSH_C4[2] * xy * a7, bSH_C4[2] * y * a7, bSH_C4[2] * x * a7, bSH_C4[2] * 14.f * xy * z)     \
-                        T(19, bSH_C4[3] * yz * b7, 0.f, bSH_C4[3] * z * b7, bSH_C4[3] * y * c21)                          \
-                        T(20, bSH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f), 0.f, 0.f, bSH_C4[4] * z * (140.f * zz - 60.f)) \
-                        F                                                                                                 \
-                        T(21, bSH_C4[5] * xz * b7, bSH_C4[5] * z * b7, 0.f, bSH_C4[5] * x * c21)                          \
-                        T(22, bSH_C4[6] * xmy * a7, bSH_C4[6] * 2.f * x * a7, bSH_C4[6] * -2.f * y * a7, bSH_C4[6] * 14.f * z * xmy) \
-                        T(23, bSH_C4[7] * xz * x3y, bSH_C4[7] * 3.f * z * xmy, bSH_C4[7] * -6.f * xy * z, bSH_C4[7] * x * x3y) \
-                        T(24, bSH_C4[8] * (xx * x3y - yy * y3x), bSH_C4[8] * 4.f * x * x3y, bSH_C4[8] * -4.f * y * y3x, 0.f) \
-                    }                                                                                                     \
-                }                                                                                                         \
-            }                                                                                                             \
-        }                                                                                                                 \
-    }
-
 // MULTI = false: one view, the loop over views folds away at compile time (the reference's backward, and its register
 // budget); MULTI = true: the launch set's views in a run-time loop
 // KC = 16 / 25 (one view, degree 3 / 4, rows of more than 64 floats): the SH rows never sit whole in LDS (76.8 KB per
@@ -138,7 +75,7 @@ __device__ __forceinline__ void sh_basis25(int deg, float x, float y, float z, f
 template <bool POSE, bool MULTI, int KC, bool CM>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
-                      int has_colors_precomp, const float* __restrict__ scales,
+                      const float4* __restrict__ sh_jac, size_t jac_plane, int has_colors_precomp, const float* __restrict__ scales,
                       const float* __restrict__ rotations, float scale_modifier,
                       const float* __restrict__ cov3D, ViewSet vs, int W, int H,
                       const int32_t* __restrict__ radii,
@@ -161,7 +98,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (shs) shs += in_off * (size_t)M * 3;
         if (scales) { scales += 3 * in_off; rotations += 4 * in_off; }
         if (cov3D) cov3D += cov_is_input ? (size_t)inf.cov_stride * in_off : 6 * st_off;
-        radii += st_off; clamped += st_off; grad2d += GGR_G2D_STRIDE * st_off;
+        radii += st_off; clamped += st_off; grad2d += GGR_G2D_STRIDE * st_off; sh_jac += st_off;
         dL_dmeans2D += 3 * st_off;
         if (dL_daux) dL_daux += st_off;
         dL_dmeans3D += 3 * in_off; dL_dopacity += in_off;
@@ -204,11 +141,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             for (int k = 0; k < 6; k++) cin_in[k] = ggr_ld(cov3D + 6 * il + k);
         }
     }
-    if (use_sh && KC == 0) {
-        if (sh_compact) stage_sh_rows_compact(sh_lds, shs, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
-        else stage_sh_rows(sh_lds, shs, g0, nG, sh_row, copy_row, sh_stride, sh_flat);
-        __syncthreads();
-    }
+    // (the SH rows are NOT read: the forward left ∂colour/∂direction per (view, Gaussian) — sh_jac — and the gradient rows
+    //  are rank one, basis × dL/dcolour; the LDS rows below only carry the gradient out in whole lines)
 
     // sums over the views of this launch set (one view: the reference's backward)
     float dmean[3] = {0.f, 0.f, 0.f};      // w.r.t. the caller's (unscaled) means
@@ -461,51 +395,24 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // ---- outputs: sums over the views -------------------------------------------------------------------------
     if (use_sh && KC > 0) {
         constexpr int KCN = KC > 0 ? KC : 1, DEG = KC == 16 ? 3 : 4;
-        // ---- (1) view-direction term: dL/dmean += (∂dir/∂mean)ᵀ Σ_k ∇B_k(dir) · (sh_k · dL/dcolour), rows read by thirds ----
-        ShThirds<KCN> thirds;
-        float ch_v[ShThirds<KCN>::ITS];
-        thirds.init(shs + g0 * sh_row, nG, (int)sh_row, inf.sh_channel_major ? M : KC);
-        thirds.load(ch_v, 0);
+        // ---- (1) view-direction term: dL/dmean += (∂dir/∂mean)ᵀ Jᵀ·dL/dcolour, J = ∂colour/∂dir from the forward ----
         const float4 c0 = recs[(GGR_G2D_STRIDE / 4) * il];  // r, g, b, –
         const bool live = in_range && radii[il] > 0;
         const uint32_t cl = clamped[il];
-        // a culled Gaussian walks the thirds too (block-wide barriers) with a zero colour gradient and a fixed direction
+        const float4 j0 = ggr_ld_f4(reinterpret_cast<const float*>(sh_jac + il)),
+                     j1 = ggr_ld_f4(reinterpret_cast<const float*>(sh_jac + jac_plane + il)),
+                     j2 = ggr_ld_f4(reinterpret_cast<const float*>(sh_jac + 2 * jac_plane + il));
         float dc[3] = {live && !(cl & 1u) ? c0.x : 0.f, live && !(cl & 2u) ? c0.y : 0.f, live && !(cl & 4u) ? c0.z : 0.f};
         const float in_s = vs.input_scale ? vs.input_scale[0] : 1.0f;
         const float vx = live ? in_s * m0 - vs.campos[0] : 0.f, vy = live ? in_s * m1 - vs.campos[1] : 0.f,
                     vz = live ? in_s * m2 - vs.campos[2] : 1.f;
         const float len = sqrtf(vx * vx + vy * vy + vz * vz);
         float x = vx / len, y = vy / len, z = vz / len;
-        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        // (a culled Gaussian's Jacobian record is not written by the forward: masked here)
+        const float ddx = live ? j0.x * dc[0] + j1.x * dc[1] + j2.x * dc[2] : 0.f;
+        const float ddy = live ? j0.y * dc[0] + j1.y * dc[1] + j2.y * dc[2] : 0.f;
+        const float ddz = live ? j0.z * dc[0] + j1.z * dc[1] + j2.z * dc[2] : 0.f;
         constexpr bool cm = CM;
-        const float* seg = sh_lds + threadIdx.x * ShThirds<KCN>::STRIDE;
-#pragma unroll
-        for (int J = 0; J < 3; J++) {
-            if (J) __syncthreads();  // the previous third has been consumed
-            thirds.store(sh_lds, ch_v);
-            if (J < 2) thirds.load(ch_v, J + 1);
-            __syncthreads();
-            // (the basis gradients are formed anew in every third: shared across the three unrolled copies they are
-            //  ≈ 100 live values next to the 26 in flight — 240 VGPRs instead of ≈ 130)
-            __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z));
-            // third J: channel J of channel-major rows (coefficient k at k), floats [J·KC, (J+1)·KC) of k-major ones
-            // (coefficient k, channel c at 3k + c − J·KC)
-#define SH_DIR_CM(k, Bk, bx, by, bz) { const float sd = seg[k] * dc[J]; ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd; }
-#define SH_DIR_KM(k, Bk, bx, by, bz)                                                                   \
-    _Pragma("unroll") for (int c = 0; c < 3; c++)                                                      \
-        if ((3 * (k) + c) / KCN == J) {                                                                \
-            const float sd = seg[3 * (k) + c - J * KCN] * dc[c];                                       \
-            ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                      \
-        }
-            // (band by band: a compiler fence between the bands keeps the third's 25 LDS reads and the bands' basis
-            //  gradients from all being live at once)
-#define SH_FENCE __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(xx), "+v"(yy), "+v"(zz), "+v"(xy), "+v"(yz), "+v"(xz), "+v"(ddx), "+v"(ddy), "+v"(ddz) :: "memory");
-            if (cm) GGR_SH_TERMS(SH_DIR_CM, DEG, SH_FENCE)
-            if (!cm) GGR_SH_TERMS(SH_DIR_KM, DEG, SH_FENCE)
-#undef SH_FENCE
-#undef SH_DIR_CM
-#undef SH_DIR_KM
-        }
         float dcam[3] = {0.f, 0.f, 0.f};
         if (live) {
             const float sum2 = vx * vx + vy * vy + vz * vz;
@@ -586,20 +493,21 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             const float vx = p0 - campos[0], vy = p1 - campos[1], vz = p2 - campos[2];
             const float len = sqrtf(vx * vx + vy * vy + vz * vz);
             const float x = vx / len, y = vy / len, z = vz / len;
-            const float* sh = sh_lds + threadIdx.x * sh_stride;
-            float* dsh1 = sh_lds + threadIdx.x * sh_stride;  // one view: read the coefficient, then overwrite it with
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;           // its gradient (written out below)
-            // helper: coefficient k with basis value Bk and basis gradient (bx,by,bz).  Several views: the direction
-            // term only; dL/dSH (Σ over views of basis × colour gradient) is formed afterwards, channel by channel
+            float* dsh1 = sh_lds + threadIdx.x * sh_stride;  // one view: the Gaussian's gradient row (written out below)
+            // the direction term from the forward's Jacobian (no SH row is read) …
+            const float4 j0 = ggr_ld_f4(reinterpret_cast<const float*>(sh_jac + o)),
+                         j1 = ggr_ld_f4(reinterpret_cast<const float*>(sh_jac + jac_plane + o)),
+                         j2 = ggr_ld_f4(reinterpret_cast<const float*>(sh_jac + 2 * jac_plane + o));
+            const float ddx = j0.x * dc0 + j1.x * dc1 + j2.x * dc2;
+            const float ddy = j0.y * dc0 + j1.y * dc1 + j2.y * dc2;
+            const float ddz = j0.z * dc0 + j1.z * dc1 + j2.z * dc2;
+            // … and the gradient row: coefficient k, channel c = B_k(direction) · dL/dcolour_c
 #define SH_TERM(k, Bk, bx, by, bz)                                                                     \
 {                                                                                                  \
     const int o0 = (k) * sh_ks, o1 = o0 + sh_cs, o2 = o1 + sh_cs;                                  \
-    const float s0 = sh[o0], s1 = sh[o1], s2 = sh[o2];                                             \
-    if (!MULTI) { dsh1[o0] = (Bk) * dc0; dsh1[o1] = (Bk) * dc1; dsh1[o2] = (Bk) * dc2; }           \
-    const float sd = s0 * dc0 + s1 * dc1 + s2 * dc2;                                               \
-    ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                          \
+    dsh1[o0] = (Bk) * dc0; dsh1[o1] = (Bk) * dc1; dsh1[o2] = (Bk) * dc2;                           \
 }
-            GGR_SH_TERMS(SH_TERM, deg, )
+            if (!MULTI) GGR_SH_TERMS(SH_TERM, deg, )
 #undef SH_TERM
             const float sum2 = vx * vx + vy * vy + vz * vz;
             const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
@@ -713,7 +621,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 template <int KMAX, bool POSE>
 __global__ void __launch_bounds__(256, GGR_SHV_WAVES)
 preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ means3D, const float* __restrict__ shs,
-                               ViewSet vs, const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped,
+                               const float4* __restrict__ sh_jac, size_t jac_plane, ViewSet vs, const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped,
                                const float* __restrict__ grad2d, float* __restrict__ dL_dmeans3D,
                                float* __restrict__ dL_dsh, float* __restrict__ pose_acc, InputForm inf) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // the block's SH rows, then [88][3M] gradient rows
@@ -725,7 +633,7 @@ preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ 
         const size_t in_off = (size_t)set * (size_t)P, st_off = (size_t)v0 * (size_t)P;
         means3D += 3 * in_off; shs += in_off * (size_t)M * 3;
         dL_dmeans3D += 3 * in_off; dL_dsh += in_off * (size_t)M * 3;
-        radii += st_off; clamped += st_off; grad2d += GGR_G2D_STRIDE * st_off;
+        radii += st_off; clamped += st_off; grad2d += GGR_G2D_STRIDE * st_off; sh_jac += st_off;
         if (POSE) pose_acc += (size_t)v0 * gridDim.x * 64;
         vs.campos += 3 * v0;
         if (vs.input_scale) vs.input_scale += v0;
@@ -742,10 +650,9 @@ preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ 
     const bool sh_compact = (int)sh_row > sh_rowf && sh_row <= 128 && (sh_flat || inf.sh_channel_major);
     const int sh_stride = sh_compact ? (sh_rowf | 1) : sh_flat ? (int)sh_row : (copy_row | 1);
     const int sh_ks = inf.sh_channel_major ? 1 : 3, sh_cs = inf.sh_channel_major ? (sh_compact ? sh_rowf / 3 : M) : 1;
-    if (sh_compact) stage_sh_rows_compact(sh_lds, shs, g0, nG, M, sh_rowf / 3, sh_stride, inf.sh_channel_major != 0);
-    else stage_sh_rows(sh_lds, shs, g0, nG, sh_row, copy_row, sh_stride, sh_flat);
-    __syncthreads();
-    const float* sh = sh_lds + threadIdx.x * sh_stride;
+    // (no SH row is read: the direction term comes from the forward's Jacobian, the gradient rows are basis × dL/dcolour;
+    //  the LDS only carries the gradient rows out)
+    (void)sh_stride; (void)sh_ks; (void)sh_cs; (void)copy_row; (void)sh_compact; (void)sh_flat;
 
     float acc[3][KMAX];
 #pragma unroll
@@ -757,16 +664,18 @@ preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ 
     float4 q0 = recs[(GGR_G2D_STRIDE / 4) * il];
     int qrad = radii[il];
     uint32_t qcl = clamped[il];
+    float4 qj0 = sh_jac[il], qj1 = sh_jac[jac_plane + il], qj2 = sh_jac[2 * jac_plane + il];
 #pragma clang loop unroll(disable)
     for (int v = 0; v < vs.vps; v++) {
-        // (compiler barrier: without it the 3K coefficient reads from LDS — invariant across views — are hoisted out of
-        // the loop into as many registers)
         __asm__ volatile("" ::: "memory");
         const size_t o = (size_t)v * P + il;
-        const float4 r0 = q0;
+        const float4 r0 = q0, j0 = qj0, j1 = qj1, j2 = qj2;
         const bool live = in_range && qrad > 0;
         const uint32_t cl = qcl;
-        if (v + 1 < vs.vps) { q0 = recs[(GGR_G2D_STRIDE / 4) * (o + P)]; qrad = radii[o + P]; qcl = clamped[o + P]; }
+        if (v + 1 < vs.vps) {   // (the per-view loads one view ahead)
+            q0 = recs[(GGR_G2D_STRIDE / 4) * (o + P)]; qrad = radii[o + P]; qcl = clamped[o + P];
+            qj0 = sh_jac[o + P]; qj1 = sh_jac[jac_plane + o + P]; qj2 = sh_jac[2 * jac_plane + o + P];
+        }
         float dcam[3] = {0.f, 0.f, 0.f};
         if (live) {
             const float dc0 = (cl & 1u) ? 0.f : r0.x, dc1 = (cl & 2u) ? 0.f : r0.y, dc2 = (cl & 4u) ? 0.f : r0.z;
@@ -774,11 +683,7 @@ preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ 
             const float vx = in_s * m0 - vs.campos[3 * v], vy = in_s * m1 - vs.campos[3 * v + 1], vz = in_s * m2 - vs.campos[3 * v + 2];
             const float len = sqrtf(vx * vx + vy * vy + vz * vz);
             float x = vx / len, y = vy / len, z = vz / len;
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-            // two passes over the basis instead of one (its polynomials are cheap): (a) the rows' accumulators from the
-            // basis VALUES, (b) the direction term from the basis GRADIENTS and the coefficients in LDS, band by band
-            // behind compiler fences — formed together, every band's values, gradients and coefficient reads were live
-            // next to the 3·K accumulators: 196 VGPRs (K = 16) / 286 (K = 25)
+            // the rows' accumulators from the basis VALUES; the direction term from the forward's Jacobian
             {
                 float B[GGR_SH_MAXK];
                 sh_basis25(deg, x, y, z, B);
@@ -786,19 +691,9 @@ preprocess_bwd_sh_views_kernel(int P, int M, int deg, const float* __restrict__ 
                 for (int k = 0; k < KMAX; k++)
                     if (k < K) { acc[0][k] += B[k] * dc0; acc[1][k] += B[k] * dc1; acc[2][k] += B[k] * dc2; }
             }
-            __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z) :: "memory");
-#define SH_TERM(k, Bk, bx, by, bz)                                                                     \
-{                                                                                                  \
-    if ((k) < KMAX) {                                                                              \
-        const int o0 = (k) * sh_ks, o1 = o0 + sh_cs, o2 = o1 + sh_cs;                              \
-        const float sd = sh[o0] * dc0 + sh[o1] * dc1 + sh[o2] * dc2;                               \
-        ddx += (bx) * sd; ddy += (by) * sd; ddz += (bz) * sd;                                      \
-    }                                                                                              \
-}
-#define SH_FENCE __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(xx), "+v"(yy), "+v"(zz), "+v"(xy), "+v"(yz), "+v"(xz), "+v"(ddx), "+v"(ddy), "+v"(ddz) :: "memory");
-            GGR_SH_TERMS(SH_TERM, deg, SH_FENCE)
-#undef SH_FENCE
-#undef SH_TERM
+            const float ddx = j0.x * dc0 + j1.x * dc1 + j2.x * dc2;
+            const float ddy = j0.y * dc0 + j1.y * dc1 + j2.y * dc2;
+            const float ddz = j0.z * dc0 + j1.z * dc1 + j2.z * dc2;
             const float sum2 = vx * vx + vy * vy + vz * vz;
             const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
             const float gx_ = ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
@@ -888,7 +783,7 @@ pose_finish_kernel(const float* __restrict__ pose_acc, int nblocks, float* __res
     }
 }
 
-void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs,
+void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float* shs, const float4* sh_jac,
                            int has_colors_precomp, const float* scales, const float* rotations,
                            float scale_modifier, const float* cov3D, ViewSet vs, int W, int H, const int32_t* radii,
                            const uint32_t* clamped,
@@ -915,7 +810,7 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                                         : (size_t)256 * row_stride * sizeof(float);
 #define GGR_LAUNCH_PBWD(POSE_, MULTI_, KC_, CM_)                                                                            \
     hipLaunchKernelGGL((preprocess_bwd_kernel<POSE_, MULTI_, KC_, CM_>), dim3(blocks, vs.sets), dim3(256), lds, s, P, D, M, means3D, shs, \
-                       has_colors_precomp, scales, rotations, scale_modifier, cov3D, vs, W, H, radii, clamped, grad2d,     \
+                       sh_jac, (size_t)P * vs.V, has_colors_precomp, scales, rotations, scale_modifier, cov3D, vs, W, H, radii, clamped, grad2d,     \
                        has_dz, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors_precomp, dL_dcov3D, dL_dscales,   \
                        dL_drotations, dL_daux, pose_acc, inf, cov_is_input)
 #define GGR_LAUNCH_PBWD_P(POSE_)                                                                                         \
@@ -931,7 +826,7 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
         const size_t lds_sh = sizeof(float) * std::max((size_t)256 * row_stride, (size_t)88 * 3 * M);
 #define GGR_LAUNCH_SHV(K_, POSE_)                                                                                          \
     hipLaunchKernelGGL((preprocess_bwd_sh_views_kernel<K_, POSE_>), dim3(blocks, vs.sets), dim3(256), lds_sh, s, P, M, deg,  \
-                       means3D, shs, vs, radii, clamped, grad2d, dL_dmeans3D, dL_dsh, pose_acc, inf)
+                       means3D, shs, sh_jac, (size_t)P * vs.V, vs, radii, clamped, grad2d, dL_dmeans3D, dL_dsh, pose_acc, inf)
         if (deg >= 4) { if (pose) GGR_LAUNCH_SHV(25, true); else GGR_LAUNCH_SHV(25, false); }
         else { if (pose) GGR_LAUNCH_SHV(16, true); else GGR_LAUNCH_SHV(16, false); }
 #undef GGR_LAUNCH_SHV

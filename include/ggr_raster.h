@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 8
+#define GGR_ABI_VERSION 9
 
 enum {
     GGR_OK = 0,
@@ -163,7 +163,12 @@ typedef struct GgrForwardOut {
 /* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */
 enum {
     GGR_FWD_PREPROCESS = 0, GGR_FWD_DEPTH_SORT = 1, GGR_FWD_TILE_COUNT = 2 /* counts + scans + the N readback */,
-    GGR_FWD_TILE_SCATTER = 3, GGR_FWD_BLEND = 4, GGR_FWD_STAGES = 5
+    GGR_FWD_TILE_SCATTER = 3, GGR_FWD_BLEND = 4,
+    GGR_FWD_COLOUR = 5 /* ABI 9: the SH colour kernel's own duration when the forward runs it on its side stream BESIDE
+                          stages 1-3 (then stage 0 is the geometry half alone and stage 4 contains whatever wait for the
+                          colours was left); 0 when the per-Gaussian stage ran as one kernel.  Not a term of the forward's
+                          duration: stages 0-4 add up to it */,
+    GGR_FWD_STAGES = 6
 };
 enum { GGR_BWD_CLEAR = 0, GGR_BWD_BLEND = 1, GGR_BWD_PREPROCESS = 2, GGR_BWD_STAGES = 3 };
 

@@ -19,7 +19,7 @@ def test_library_builds_and_loads():
     path = _build.build_library()
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.ggr_abi_version() == 8
+    assert lib.ggr_abi_version() == 9
     assert lib.ggr_source_hash().decode() == _build.source_hash() == _build.embedded_hash()
 
 
