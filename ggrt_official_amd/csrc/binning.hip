@@ -83,6 +83,7 @@ radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per 
                          uint32_t* __restrict__ hist, const uint32_t* __restrict__ block_max, uint32_t nmax) {
     __shared__ uint32_t h[GGR_SORT_PASSES][GGR_SORT_MAX_BINS];
     __shared__ uint32_t wm[GGR_HIST_THREADS / 64];
+    GGR_CRITICAL_PRIO();
     const int tid = threadIdx.x;
     // this block's keys: all loads issued before anything waits (the kernel is latency-bound)
     uint32_t ks[GGR_HIST_ITEMS];
@@ -151,6 +152,7 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     __shared__ uint2 sorted[(GGR_SORT_THREADS * ITEMS)];             // the tile's (key, val) pairs — then its payloads — in output order
     __shared__ uint32_t wsum[NW];
     __shared__ uint32_t tile_sh;
+    GGR_CRITICAL_PRIO();
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     // segments are dealt round robin to the workgroups, so that all of them progress together

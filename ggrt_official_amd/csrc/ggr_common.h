@@ -69,6 +69,18 @@
 #define GGR_MAX_WIDTH_TILES (64 * GGR_COUNT_SLOTS)  // one tile row must fit a wave's slots: 768 tiles = 12 288 px
 #define GGR_COUNT_GROUPS 8 // groups of count workgroups: the prefix over workgroups runs per group (T·groups-way parallel)
 
+// The kernels of the forward's critical path that run beside the colour kernel of the side stream (api.hip forward_impl:
+// depth sort, tile counts) raise their waves' issue priority: a colour wave on the same SIMD then only issues in the slots
+// they leave (s_setprio; -DGGR_PRIO=0: off)
+#ifndef GGR_PRIO
+#define GGR_PRIO 1
+#endif
+#if GGR_PRIO
+#define GGR_CRITICAL_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define GGR_CRITICAL_PRIO() ((void)0)
+#endif
+
 // ---- streaming accesses of the two preprocess kernels (round 4) ------------------------------------------------------------
 // What this launch set never reads again — the gradient tensors, radii, clamp bits — is stored NON-TEMPORALLY, and what
 // preprocess_bwd reads exactly once in whole lines — SH rows, gradient records, means, covariances — is loaded so: the lines

@@ -77,6 +77,7 @@ bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, 
                  uint32_t rows_total, uint32_t band_rows, uint32_t nchunks, uint32_t* __restrict__ table,
                  uint32_t* __restrict__ wsum) {
     extern __shared__ uint32_t grid[];  // [band_rows][grid_x] corner deltas → column prefixes
+    GGR_CRITICAL_PRIO();
     const uint32_t w = blockIdx.x, band = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t r0 = band * band_rows, r1 = min(rows_total, r0 + band_rows), nr = r1 - r0;
     const uint32_t cells = nr * grid_x, tile0 = r0 * grid_x;
