@@ -6,6 +6,7 @@
 // one event for the num_rendered read-back.
 #include "../../include/ggr_raster.h"
 #include "ggr_common.h"
+#include <algorithm>
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -152,25 +153,25 @@ bool split_colour_enabled() {
     return v != 0;
 }
 
-// Blocks of the colour kernel's launch (per Gaussian set): GGR_COLOUR_BLOCKS_PER_CU persistent blocks per CU (default 1;
-// 0 = one block per 256-Gaussian chunk, unthrottled).  Unthrottled the kernel finishes in 50 µs at C3 and DOUBLES the
-// duration of the depth-sort passes it runs beside (a sort tile waits for a CU's wave slots and LDS, and every later
-// tile waits for its look-back): forward +13 µs instead of −30.  It has ≈ 150 µs until the blend needs the colours.
-int colour_fork_point() {
-    static const int v = [] { const char* e = getenv("GGR_COLOUR_FORK"); return (e && *e) ? atoi(e) : 0; }();
-    return v;
-}
-int colour_grid_blocks() {
-    static const int v = [] {
-        const char* e = getenv("GGR_COLOUR_BLOCKS_PER_CU");
-        const int per_cu = (e && *e) ? atoi(e) : 1;
-        int dev = 0, cus = 256;
+// Blocks of the colour kernel's launch (per Gaussian set): a few PERSISTENT blocks per CU.  Unthrottled (one block per
+// 256-Gaussian chunk) the kernel finishes in 50 µs at C3 and doubles the duration of the depth-sort passes it runs beside (a
+// sort tile waits for a CU's wave slots and LDS, every later tile for its look-back): forward +13 µs instead of −30.  One
+// block per CU streams ≈ 2.7 TB/s and has until the blend needs the colours — the depth sort and the tile-list kernels,
+// whose duration grows with the number of (view, Gaussian) pairs as the colour kernel's bytes do; beyond ≈ 2 M pairs one
+// block per CU is no longer enough (C6′, 4.9 M pairs: the blend waited 0.35 ms for the colours), so the count grows with the
+// pairs: 1 + pairs / 2 M, at most 4.  GGR_COLOUR_BLOCKS_PER_CU overrides (0 = unthrottled).
+#define GGR_SPLIT_MAX_POINTS 2500000
+int colour_grid_blocks(size_t pairs) {
+    static const int forced = [] { const char* e = getenv("GGR_COLOUR_BLOCKS_PER_CU"); return (e && *e) ? atoi(e) : -1; }();
+    static const int cus = [] {
+        int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        return per_cu <= 0 ? 0 : per_cu * cus;
+            return prop.multiProcessorCount;
+        return 256;
     }();
-    return v;
+    const int per_cu = forced >= 0 ? forced : (int)std::min<size_t>(4, 1 + pairs / 2000000);
+    return per_cu <= 0 ? 0 : per_cu * cus;
 }
 
 // The exact mode's wait for num_rendered: the host watches the pinned word (armed with a sentinel no count can take)
@@ -351,7 +352,10 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     //    would be pulled into the capture), not in debug mode (one kernel at a time), not for precomputed colours.
     const InputForm inf = input_form(st, in, vs.sets);
     SideStream* side = nullptr;
-    if (in->shs && P1 > 0 && !dbg && split_colour_enabled()) {
+    // … nor for more than GGR_SPLIT_MAX_POINTS Gaussians per set: the colour kernel's bytes grow with them faster than the
+    // window beside the binning does (C6′, 4.9 M Gaussians of 25 coefficients: 1.9 GB to move within ≈ 0.47 ms — at that rate
+    // the depth sort beside it takes 0.66 instead of 0.29 ms; step 2.43 ms as one kernel, 2.51 split)
+    if (in->shs && P1 > 0 && P1 <= GGR_SPLIT_MAX_POINTS && !dbg && split_colour_enabled()) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) side = side_stream();
         else (void)hipGetLastError();
@@ -367,17 +371,21 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         colour_pending = false;
         HIP_TRY(hipEventRecord(side->fork, s));
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        // (the launch's grid is (blocks, Gaussian sets): the persistent blocks are shared out between the sets)
+        const int cg = colour_grid_blocks((size_t)P);
+        const int colour_grid = cg <= 0 ? 0 : std::max(1, cg / std::max(1, vs.sets));
         if (out->stage_ms) (void)hipEventRecord(side->t0, side->stream);
         ggr::launch_preprocess_fwd(P1, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
                                    in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
                                    in->aux_precomp, vs, W, H, out->radii, g, inf, side->stream, GGR_PRE_COLOUR,
-                                   colour_grid_blocks(), out->no_backward ? 0 : 1);
+                                   colour_grid, out->no_backward ? 0 : 1);
         if (out->stage_ms) (void)hipEventRecord(side->t1, side->stream);
         HIP_TRY(hipEventRecord(side->join, side->stream));
         return GGR_OK;
     };
-    const int fork_at = colour_fork_point();   // 0: beside the depth sort onwards, 1: behind the sort, 2: behind the tile counts
-    if (fork_at == 0) { const int rc = fork_colour(); if (rc != GGR_OK) return rc; }
+    // (started right behind the geometry kernel: started behind the depth sort, or behind the tile counts, it delays the
+    //  blend by more than it spares the sort — NOTES r5)
+    { const int rc = fork_colour(); if (rc != GGR_OK) return rc; }
     // (every return below this point must leave the caller's stream ordered behind the side stream: JoinGuard)
     struct JoinGuard {
         SideStream* sd; hipStream_t s; bool done = false;
@@ -404,7 +412,6 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
                               g.rect, rect_sorted, zero_area, zero_words);
         KCHECK(dbg, s, "depth sort");
     }
-    if (fork_at <= 1) { const int rc = fork_colour(); if (rc != GGR_OK) return rc; }
     tm.mark();
 
     // 3. per-(chunk, tile) counts → list positions, tile ranges, num_rendered
@@ -432,7 +439,6 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         HIP_TRY(hipMemsetAsync(g.counters, 0, 8, s));
     }
     KCHECK(dbg, s, "tile_list_count");
-    { const int rc = fork_colour(); if (rc != GGR_OK) return rc; }
     if (dbg && sync_free && P > 0) {  // debug mode may sync: check the sort's fault bit right here
         uint32_t two[2] = {0u, 0u};
         HIP_TRY(hipMemcpy(two, g.counters, 8, hipMemcpyDeviceToHost));
