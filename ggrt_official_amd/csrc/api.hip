@@ -83,9 +83,8 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
         return fail(GGR_E_INVALID, "sh_stride %d too small for sh_degree %d", st->sh_stride, st->sh_degree);
     const int64_t tiles = (int64_t)((st->image_width + GGR_TILE - 1) / GGR_TILE) * ((st->image_height + GGR_TILE - 1) / GGR_TILE);
     if (tiles > (1 << 24)) return fail(GGR_E_LIMIT, "image has %lld tiles; at most 2^24 supported", (long long)tiles);
-    if (st->image_width > GGR_MAX_WIDTH_TILES * GGR_TILE)  // (a tile row must fit a count wave's slots: tile_lists.hip)
-        return fail(GGR_E_LIMIT, "image width %d exceeds %d px (%d tiles of %d px: the tile-count kernel's row limit)",
-                    st->image_width, GGR_MAX_WIDTH_TILES * GGR_TILE, GGR_MAX_WIDTH_TILES, GGR_TILE);
+    if (st->image_width > 65535 * GGR_TILE)   // (the packed tile rect holds 16-bit tile coordinates)
+        return fail(GGR_E_LIMIT, "image width %d exceeds %d px (65535 tile columns)", st->image_width, 65535 * GGR_TILE);
     if (st->image_height > 65535 * GGR_TILE)
         return fail(GGR_E_LIMIT, "image height %d exceeds %d px (65535 tile rows)", st->image_height, 65535 * GGR_TILE);
     return GGR_OK;

@@ -65,8 +65,8 @@
 #ifndef GGR_COUNT_CPG
 #define GGR_COUNT_CPG 4    // chunks per workgroup of the count kernel (their running per-tile counts stay in registers)
 #endif
-#define GGR_COUNT_SLOTS 12   // (row, 64-tile piece) pairs per count wave: bounds a count band AND the image width —
-#define GGR_MAX_WIDTH_TILES (64 * GGR_COUNT_SLOTS)  // one tile row must fit a wave's slots: 768 tiles = 12 288 px
+#define GGR_COUNT_SLOTS 12   // (row, 64-tile piece) pairs per count wave: bounds a count band; a tile row of more than
+                             // 64·12 = 768 tiles (12 288 px) is counted in column windows (tile_lists.hip)
 #define GGR_COUNT_GROUPS 8 // groups of count workgroups: the prefix over workgroups runs per group (T·groups-way parallel)
 
 // The kernels of the forward's critical path that run beside the colour kernel of the side stream (api.hip forward_impl:

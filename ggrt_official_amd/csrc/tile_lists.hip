@@ -30,6 +30,7 @@
 // tiles (18 KB of LDS), a scatter band ≤ 512, so any image size works.
 #include "ggr_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace ggr {
 
@@ -74,14 +75,18 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 // GGR_COUNT_SLOTS (ggr_common.h) = (row, 64-tile piece) pairs per wave: bounds the band, = registers for the running counts
 __global__ void __launch_bounds__(256)
 bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, uint32_t T, uint32_t grid_x,
-                 uint32_t rows_total, uint32_t band_rows, uint32_t nchunks, uint32_t* __restrict__ table,
+                 uint32_t rows_total, uint32_t band_rows, uint32_t col_w, uint32_t nchunks, uint32_t* __restrict__ table,
                  uint32_t* __restrict__ wsum) {
-    extern __shared__ uint32_t grid[];  // [band_rows][grid_x] corner deltas → column prefixes
+    extern __shared__ uint32_t grid[];  // [band_rows][gw] corner deltas → column prefixes
     GGR_CRITICAL_PRIO();
     const uint32_t w = blockIdx.x, band = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t r0 = band * band_rows, r1 = min(rows_total, r0 + band_rows), nr = r1 - r0;
-    const uint32_t cells = nr * grid_x, tile0 = r0 * grid_x;
-    const uint32_t pieces = (grid_x + 63u) >> 6;
+    // the band's window of tile columns [c0, c1): the whole row (blockIdx.z = 0, col_w ≥ grid_x) unless a row has more
+    // 64-tile pieces than a count wave has slots — then the row is cut into windows of col_w tiles, each counted like a
+    // band of its own: a rect is clipped to the window exactly as it is clipped to the band's rows
+    const uint32_t c0 = blockIdx.z * col_w, c1 = min(grid_x, c0 + col_w), gw = c1 - c0;
+    const uint32_t cells = nr * gw, tile0 = r0 * grid_x + c0;
+    const uint32_t pieces = (gw + 63u) >> 6;
     // slot k of this wave = (row wave + 4·(k / pieces), tiles [64·(k mod pieces), +64) of it); lane = tile inside the piece
     uint32_t run[GGR_COUNT_SLOTS];
 #pragma unroll
@@ -102,14 +107,15 @@ bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, 
             uint32_t x0, y0, x1, y1;
             unpack_rect(rc[q], x0, y0, x1, y1);
             const uint32_t ya = max(y0, r0), yb = min(y1, r1);
-            if (x1 > x0 && yb > ya) {  // (corners on the band's far edges would only feed cells outside it)
-                uint32_t* top = grid + (ya - r0) * grid_x;
-                atomicAdd(top + x0, 1u);
-                if (x1 < grid_x) atomicAdd(top + x1, 0xFFFFFFFFu);
+            const uint32_t xa = max(x0, c0), xb = min(x1, c1);
+            if (xb > xa && yb > ya) {  // (corners on the band's far edges would only feed cells outside it)
+                uint32_t* top = grid + (ya - r0) * gw;
+                atomicAdd(top + (xa - c0), 1u);
+                if (xb < c1) atomicAdd(top + (xb - c0), 0xFFFFFFFFu);
                 if (yb < r1) {
-                    uint32_t* bot = grid + (yb - r0) * grid_x;
-                    atomicAdd(bot + x0, 0xFFFFFFFFu);
-                    if (x1 < grid_x) atomicAdd(bot + x1, 1u);
+                    uint32_t* bot = grid + (yb - r0) * gw;
+                    atomicAdd(bot + (xa - c0), 0xFFFFFFFFu);
+                    if (xb < c1) atomicAdd(bot + (xb - c0), 1u);
                 }
             }
         }
@@ -124,16 +130,16 @@ bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, 
         __syncthreads();
         // prefix along y, in place: one thread per column (consecutive lanes, consecutive words), 8 rows' loads in
         // flight at a time (one LDS round trip per 8 rows instead of one per row)
-        for (uint32_t x = tid; x < grid_x; x += 256) {
+        for (uint32_t x = tid; x < gw; x += 256) {
             uint32_t acc = 0u;
             for (uint32_t rb = 0; rb < nr; rb += 8) {
                 uint32_t v[8];
 #pragma unroll
-                for (uint32_t u = 0; u < 8; u++) v[u] = rb + u < nr ? grid[(rb + u) * grid_x + x] : 0u;
+                for (uint32_t u = 0; u < 8; u++) v[u] = rb + u < nr ? grid[(rb + u) * gw + x] : 0u;
 #pragma unroll
                 for (uint32_t u = 0; u < 8; u++) {
                     acc += v[u];
-                    if (rb + u < nr) grid[(rb + u) * grid_x + x] = acc;
+                    if (rb + u < nr) grid[(rb + u) * gw + x] = acc;
                 }
             }
         }
@@ -144,7 +150,7 @@ bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, 
 #pragma unroll
         for (int k = 0; k < GGR_COUNT_SLOTS; k++) {
             const uint32_t row = wave + 4u * ((uint32_t)k / pieces), x = (((uint32_t)k % pieces) << 6) + lane;
-            v[k] = (row < nr && x < grid_x) ? grid[row * grid_x + x] : 0u;
+            v[k] = (row < nr && x < gw) ? grid[row * gw + x] : 0u;
         }
         uint32_t carry = 0u;
 #pragma unroll
@@ -154,7 +160,7 @@ bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, 
             if (piece == 0u) carry = 0u;
             const uint32_t incl = wave_scan_add(v[k]) + carry;
             carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (row < nr && x < grid_x) {
+            if (row < nr && x < gw) {
                 trow[row * grid_x + x] = run[k];
                 run[k] += incl;
             }
@@ -165,7 +171,7 @@ bin_count_kernel(uint32_t P, const uint2* __restrict__ rect /*in depth order*/, 
 #pragma unroll
     for (int k = 0; k < GGR_COUNT_SLOTS; k++) {
         const uint32_t row = wave + 4u * ((uint32_t)k / pieces), x = (((uint32_t)k % pieces) << 6) + lane;
-        if (row < nr && x < grid_x) {
+        if (row < nr && x < gw) {
             const uint32_t i = row * grid_x + x;
             wsum[wo + i] = run[k];
         }
@@ -502,20 +508,21 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     // kernel is a chain of LDS round trips and barriers: it needs several workgroups per CU).  1080p, 1 M Gaussians:
     // 245 workgroups of 4 chunks × 4 bands of 17 rows.
     const uint32_t gx = (uint32_t)grid_x, rows = (uint32_t)(T / gx);
-    const uint32_t pieces = (gx + 63u) / 64u;
-    if (pieces > GGR_COUNT_SLOTS) {   // image wider than GGR_MAX_WIDTH_TILES: api.hip's validate() refuses it (GGR_E_LIMIT);
-        (void)hipMemsetAsync(total_out, 0, 8, s);            // reached by any other route: an empty frame, never a
-        (void)hipMemsetAsync(ranges, 0, T * sizeof(uint2), s);  // division by zero below
-        return;
-    }
+    // A row of more than 64·GGR_COUNT_SLOTS tiles (12 288 px) does not fit a count wave's slots: it is cut into windows of
+    // equal width (a multiple of 64 tiles, ≤ 768), each counted like a band of its own (blockIdx.z).  The reference has no
+    // width limit; until round 5 this build refused such frames with GGR_E_LIMIT.
+    const uint32_t pieces_row = (gx + 63u) / 64u;
+    const uint32_t ncols = (pieces_row + GGR_COUNT_SLOTS - 1) / GGR_COUNT_SLOTS;
+    const uint32_t col_w = ncols == 1 ? gx : 64u * ((pieces_row + ncols - 1) / ncols);
+    const uint32_t pieces = (std::min(col_w, gx) + 63u) / 64u;
     const uint32_t max_rows = 4u * (GGR_COUNT_SLOTS / pieces);
     uint32_t nbands = (rows + max_rows - 1) / max_rows;
-    const uint32_t want = (1000u + pl.nw - 1) / pl.nw;
+    const uint32_t want = (1000u + pl.nw * ncols - 1) / (pl.nw * ncols);
     if (nbands < want) nbands = want < rows ? want : rows;
     const uint32_t band_rows = (rows + nbands - 1) / nbands;
     nbands = (rows + band_rows - 1) / band_rows;
-    hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nw, nbands), dim3(256), (size_t)band_rows * gx * 4, s, (uint32_t)P,
-                       w.rect_sorted, (uint32_t)T, gx, rows, band_rows, pl.nchunks, w.table, w.wsum);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nw, nbands, ncols), dim3(256), (size_t)band_rows * std::min(col_w, gx) * 4, s,
+                       (uint32_t)P, w.rect_sorted, (uint32_t)T, gx, rows, band_rows, col_w, pl.nchunks, w.table, w.wsum);
     const unsigned tb = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.wsum, (uint32_t)T, pl.nw, pl.wpg,
                        w.gsum, w.total);

@@ -42,10 +42,10 @@ enum {
     GGR_E_INVALID = 1,   /* bad argument combination (e.g. both/neither of shs & colors_precomp) */
     GGR_E_HIP = 2,       /* a HIP runtime call or kernel launch failed */
     GGR_E_ALLOC = 3,     /* the allocator callback returned NULL */
-    GGR_E_LIMIT = 4,     /* size beyond what the kernels index: P or N ≥ 2^31, > 2^24 tiles, image WIDTH > 12 288 px
-                            (768 tiles: one tile row must fit a tile-count wave's register slots — the reference has
-                            no such limit; a wider frame has to be rendered in vertical strips), height > 65 535 tile
-                            rows; the message of ggr_last_error() names the limit that was hit */
+    GGR_E_LIMIT = 4,     /* size beyond what the kernels index: P or N ≥ 2^31, > 2^24 tiles, width or height > 65 535
+                            tiles (1 048 560 px: the packed tile rects hold 16-bit tile coordinates); the message of
+                            ggr_last_error() names the limit that was hit.  (Until ABI 8 frames wider than 12 288 px were
+                            refused: rows of more than 768 tiles are now counted in column windows.) */
     GGR_E_CAPACITY = 5   /* GgrForwardOut.capacity_is_hint: num_rendered exceeds the buffer that was brought along — the
                             outputs of this call are void, repeat it in exact mode (or with a larger buffer) */
 };
