@@ -147,9 +147,10 @@ SideStream* side_stream() {
     return &r;
 }
 // GGR_SPLIT_COLOUR=0: the per-Gaussian stage as ONE kernel on the caller's stream (dev / A-B measurements)
+// (read on every forward: a test or a host can switch within a process)
 bool split_colour_enabled() {
-    static const int v = [] { const char* e = getenv("GGR_SPLIT_COLOUR"); return (e && *e == '0') ? 0 : 1; }();
-    return v != 0;
+    const char* e = getenv("GGR_SPLIT_COLOUR");
+    return !(e && *e == '0');
 }
 
 // Blocks of the colour kernel's launch (per Gaussian set): a few PERSISTENT blocks per CU.  Unthrottled (one block per

@@ -78,3 +78,59 @@ def test_two_host_threads_each_with_its_own_stream():
     assert not errs, errs
     for w, g in zip(want, got):
         _same(w, g)
+
+
+@pytest.mark.parametrize("case", ["one_view_d3", "one_view_d4_m25", "scale_rot", "views3"])
+def test_split_per_gaussian_stage_equals_one_kernel(case, monkeypatch):
+    """Round 5: with SH colours the forward runs the per-Gaussian stage as a geometry kernel on the caller's stream and a
+    colour kernel on a library-owned side stream (csrc/api.hip forward_impl); `GGR_SPLIT_COLOUR=0` runs it as one kernel.
+    Same arithmetic in the same order: colour, radii, depth and every gradient are bit-identical (the gradients up to the
+    blend's atomic order, as between any two runs)."""
+    import numpy as np
+    from ggrt_official_amd import GaussianRasterizer
+    from ggrt_official_amd.rasterizer import rasterize_views
+    from ggrt_official_amd.synthetic import make_scene, upstream_gradient
+    dev = "cuda:0"
+    deg = 4 if case == "one_view_d4_m25" else 3
+    sc = make_scene(30000, 208, 160, sh_degree=deg, profile="B" if deg == 4 else "A", seed=41).to(dev)
+    dL = upstream_gradient(sc.width, sc.height, seed=5, device=dev)
+
+    def run():
+        leaves = [t.clone().requires_grad_() for t in (sc.means3D, sc.shs, sc.opacities, sc.cov3D, sc.scales, sc.rotations)]
+        m, sh, op, cov, scl, rot = leaves
+        rs = sc.settings()._replace(sh_max_degree=4 if deg == 4 else 3)
+        if case == "views3":
+            views = []
+            for k in range(3):
+                c2w = torch.eye(4, dtype=torch.float64)
+                c2w[0, 3] = 0.05 * k
+                v = make_scene(8, sc.width, sc.height, sh_degree=deg, seed=1, c2w=c2w).to(dev)
+                views.append((v.viewmatrix, v.projmatrix, v.campos))
+            tanfov = torch.tensor([[sc.tanfovx, sc.tanfovy]] * 3, dtype=torch.float32, device=dev)
+            color, radii, depth = rasterize_views(m, op, torch.stack([v[0] for v in views]), torch.stack([v[1] for v in views]),
+                                                  torch.stack([v[2] for v in views]), sc.bg[None].expand(3, 3).contiguous(),
+                                                  tanfov, rs, shs=sh, cov3D_precomp=cov)
+            (color * dL[None]).sum().backward()
+            used = (m, sh, op, cov)
+        elif case == "scale_rot":
+            color, radii, depth = GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros_like(m), opacities=op, shs=sh,
+                                                         scales=scl, rotations=rot)
+            (color * dL).sum().backward()
+            used = (m, sh, op, scl, rot)
+        else:
+            color, radii, depth = GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros_like(m), opacities=op, shs=sh,
+                                                         cov3D_precomp=cov)
+            (color * dL).sum().backward()
+            used = (m, sh, op, cov)
+        torch.cuda.synchronize()
+        return color.detach().cpu(), radii.cpu(), depth.detach().cpu(), [t.grad.cpu().numpy() for t in used]
+
+    monkeypatch.setenv("GGR_SPLIT_COLOUR", "0")
+    one = run()
+    monkeypatch.setenv("GGR_SPLIT_COLOUR", "1")
+    two = run()
+    assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1]) and torch.equal(one[2], two[2])
+    assert int((one[1] > 0).sum()) > 1000
+    for a, b in zip(one[3], two[3]):
+        assert np.abs(a).max() > 0
+        assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
