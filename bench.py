@@ -678,6 +678,44 @@ def main():
                           "overlapped_ms_per_step": round(ov, 4), "mpix_s": round(world * W * H / ov / 1e3, 1),
                           "exchange_bound": bool(ov > 1.1 * raster_ms)})
         multi["grad_buffer_sweep"] = sweep
+        # … and the same exchange with the stand-in parameter gradients compressed to bf16 for the wire (what DDP's
+        # bf16 compression hook does: cast, all-reduce half the bytes, cast back; the 35 camera-gradient floats of the
+        # rasterizer itself stay fp32 in a message of their own) — xGMI rings are per-link bound, so halving the bytes halves
+        # the exchange.  Informational: the headline exchanges fp32.
+        try:
+            if G > 0:
+                wire = [torch.zeros(G, device=dev, dtype=torch.bfloat16) for _ in range(2)]
+                cam = [torch.zeros(35, device=dev) for _ in range(2)]
+                red_w = [parallel.ChunkedMeanAllReduce(args.exchange_chunks) for _ in range(2)]
+                red_c = [parallel.ChunkedMeanAllReduce(1) for _ in range(2)]
+
+                def exchange_bf16(i: int, blocking_: bool):
+                    k = i & 1
+                    red_w[k].wait(); red_c[k].wait()
+                    bufs[k][:G].copy_(wire[k])                      # the previous round's result back to fp32
+                    wire[k].copy_(bufs[k][:G])                      # this round's gradients to the wire format
+                    torch.cat([wl.view.grad.reshape(-1), wl.proj.grad.reshape(-1), wl.campos.grad.reshape(-1)], out=cam[k])
+                    red_w[k].issue(wire[k]); red_c[k].issue(cam[k])
+                    if blocking_:
+                        red_w[k].wait(); red_c[k].wait()
+
+                def drain_bf16():
+                    for r_ in red_w + red_c:
+                        r_.wait()
+
+                def leg_b(fn, fin=None):
+                    t, _ = timed_steps(fn, n_sw, 2, dev, barrier=parallel.barrier, finish=fin)
+                    return parallel.max_over_ranks(t, dev) / n_sw * 1e3
+                ar_b = leg_b(lambda i: exchange_bf16(i, True))
+                ov_b = leg_b(lambda i: (wl.step(), exchange_bf16(i, False)), drain_bf16)
+                multi["bf16_wire"] = {"floats": G, "MB_on_the_wire": round(G * 2 / 1e6, 1), "allreduce_ms_incl_casts": round(ar_b, 4),
+                                      "overlapped_ms_per_step": round(ov_b, 4), "mpix_s": round(world * W * H / ov_b / 1e3, 1),
+                                      "exchange_bound": bool(ov_b > 1.1 * raster_ms),
+                                      "note": "stand-in parameter gradients cast to bf16 for the all-reduce and back; camera "
+                                              "gradient fp32; informational — the headline exchanges fp32"}
+                del wire
+        except Exception as e:
+            log(f"bf16 wire leg skipped: {type(e).__name__}: {e}")
         log(f"multi-GPU legs: {multi}")
 
     # informational: the same K steps + W warm-up started from an IDLE device (0.5 s of sleep) — what a caller who renders
