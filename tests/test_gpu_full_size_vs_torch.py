@@ -1,4 +1,4 @@
-"""The HIP path against the INDEPENDENT restatement at FULL size (`-m gpu`, env-gated).
+"""The HIP path against the INDEPENDENT restatement at FULL size (`-m gpu`).
 
 At BASELINE's full sizes the kernels had only ever met `oracle/ggr_oracle.c`, whose preprocess they follow operation for
 operation; the independent leg (`oracle/torch_raster.py`: vectorised PyTorch, autograd backward, no shared code or
