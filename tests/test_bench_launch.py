@@ -42,3 +42,25 @@ def test_under_a_launcher_no_relaunch(monkeypatch):
     # WORLD_SIZE = 1 under a launcher but --gpus 2: the old, explicit error — not a silent re-launch, not a wrong n_gpus
     with pytest.raises(RuntimeError, match="torch.distributed.run"):
         bench.main()
+
+
+def test_profile_selection_prefers_the_stamp_of_the_current_sources(tmp_path, monkeypatch):
+    """the PMC-derived fields of the record must not come from a stale profile while a fresh sibling
+    exists — a profile whose `<tag>_meta.json` carries the library's current source hash wins over a 'newer' name; profiles of
+    another config are never picked for C3."""
+    import json
+    bench = _bench()
+    from ggrt_official_amd import _build
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    now = _build.source_hash()
+    for tag, meta in (("r09_v1", dict(source_hash=now, config="C3")), ("r09_v2", dict(source_hash="0" * 64, config="C3")),
+                      ("r09_zz", dict(source_hash=now, config="C5p"))):
+        (prof / f"{tag}_pmc_sq.json").write_text("{}")
+        (prof / f"{tag}_meta.json").write_text(json.dumps(meta))
+    (prof / "r01_v1_pmc_sq.json").write_text("{}")           # before the stamps: counts as C3, never as fresh
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert os.path.basename(bench.newest_profile("r*_pmc_sq.json", "C3")) == "r09_v1_pmc_sq.json"
+    (prof / "r09_v1_meta.json").write_text(json.dumps(dict(source_hash="1" * 64, config="C3")))
+    assert os.path.basename(bench.newest_profile("r*_pmc_sq.json", "C3")) == "r09_v2_pmc_sq.json"   # newest C3 by name
+    assert os.path.basename(bench.newest_profile("r*_pmc_sq.json")) == "r09_zz_pmc_sq.json"          # no config: by name
