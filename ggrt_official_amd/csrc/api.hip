@@ -162,7 +162,8 @@ bool split_colour_enabled() {
 // pairs: 1 + pairs / 2 M, at most 4.  GGR_COLOUR_BLOCKS_PER_CU overrides (0 = unthrottled).
 #define GGR_SPLIT_MAX_POINTS 2500000
 int colour_grid_blocks(size_t pairs) {
-    static const int forced = [] { const char* e = getenv("GGR_COLOUR_BLOCKS_PER_CU"); return (e && *e) ? atoi(e) : -1; }();
+    const char* e_blocks = getenv("GGR_COLOUR_BLOCKS_PER_CU");   // (read per call, like GGR_SPLIT_COLOUR)
+    const int forced = (e_blocks && *e_blocks) ? atoi(e_blocks) : -1;
     static const int cus = [] {
         int dev = 0;
         hipDeviceProp_t prop;

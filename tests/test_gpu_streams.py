@@ -127,10 +127,16 @@ def test_split_per_gaussian_stage_equals_one_kernel(case, monkeypatch):
 
     monkeypatch.setenv("GGR_SPLIT_COLOUR", "0")
     one = run()
-    monkeypatch.setenv("GGR_SPLIT_COLOUR", "1")
-    two = run()
-    assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1]) and torch.equal(one[2], two[2])
     assert int((one[1] > 0).sum()) > 1000
-    for a, b in zip(one[3], two[3]):
-        assert np.abs(a).max() > 0
-        assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
+    monkeypatch.setenv("GGR_SPLIT_COLOUR", "1")
+    # the colour kernel as persistent blocks walking the chunks (default: 1 per CU; 3 per CU) and one block per chunk (0)
+    for blocks in (None, "3", "0"):
+        if blocks is None:
+            monkeypatch.delenv("GGR_COLOUR_BLOCKS_PER_CU", raising=False)
+        else:
+            monkeypatch.setenv("GGR_COLOUR_BLOCKS_PER_CU", blocks)
+        two = run()
+        assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1]) and torch.equal(one[2], two[2]), blocks
+        for a, b in zip(one[3], two[3]):
+            assert np.abs(a).max() > 0
+            assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a), blocks
