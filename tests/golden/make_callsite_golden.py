@@ -23,6 +23,7 @@ import torch
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.environ.get("GGR_GOLDEN_OUT", HERE)   # (tests/test_golden_provenance.py regenerates into a temporary directory)
 sys.path.insert(0, ROOT)
 
 from oracle import torch_raster as tr  # noqa: E402
@@ -206,7 +207,7 @@ def main():
             for k, v in to_np(rec).items():
                 blob[f"view{i}_{k}"] = v
         blob["out_image"] = out.detach().numpy()
-        path = os.path.join(HERE, f"callsite_{name}.npz")
+        path = os.path.join(OUT, f"callsite_{name}.npz")
         np.savez_compressed(path, **blob)
         print(f"{name}: {len(RECORD)} boundary calls, out {tuple(out.shape)}, {os.path.getsize(path) / 1024:.0f} KiB")
 
@@ -248,7 +249,7 @@ def deferred_backprop_golden(cs, sh_cap=3):
             for n, t in zip(names, leaves):
                 blob[f"cell{i}{j}_grad_{n}"] = t.grad.numpy()
     name = "deferred_backprop_d25" + ("_shcap4" if sh_cap == 4 else "")
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **blob)
     print(f"{name}: {crop * crop} cells, {os.path.getsize(path) / 1024:.0f} KiB")
 

@@ -126,7 +126,7 @@ def decoder_golden():
                 d2 = module.render_depth(gs, inp["extrinsics"], inp["intrinsics"], inp["near"], inp["far"], shape,
                                          mode=mode)
                 assert torch.equal(d2, out.depth)
-    path = os.path.join(HERE, "decoder_b2v3.npz")
+    path = os.path.join(mc.OUT, "decoder_b2v3.npz")
     np.savez_compressed(path, **blob)
     print(f"decoder_b2v3: {os.path.getsize(path) / 1024:.0f} KiB, keys {len(blob)}")
 
@@ -185,7 +185,7 @@ def ply_golden():
     table = np.stack([el[c] for c in el.dtype.names], axis=1)
     assert table.dtype == np.float32 and el.tobytes() == table.tobytes()
     assert list(el.dtype.names) == mod.construct_list_of_attributes(0)
-    path = os.path.join(HERE, "ply_export_scene.npz")
+    path = os.path.join(mc.OUT, "ply_export_scene.npz")
     np.savez_compressed(path, in_extrinsics=extr.numpy(), in_means=means.numpy(), in_scales=scales.numpy(),
                         in_rotations=rot.numpy(), in_harmonics=sh.numpy(), in_opacities=op.numpy(),
                         columns=np.asarray(el.dtype.names), formats=np.asarray([el.dtype[c].str for c in el.dtype.names]),
