@@ -201,7 +201,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
     }
     const bool in_range = i < P;  // (threads past P run on Gaussian P-1's inputs and store nothing)
-    const int gx = (W + GGR_TILE - 1) / GGR_TILE, gy = (H + GGR_TILE - 1) / GGR_TILE;
+    const int gy = (H + GGR_TILE - 1) / GGR_TILE;   // (tile rows per view: the views' tile rows are stacked)
     uint32_t km = 0u;  // largest sort key of this thread over all views
 
     // ---- one pass per view: the Gaussian's inputs (and its SH row in LDS) are read ONCE for all of them ----------
@@ -222,7 +222,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 
         // defaults for a culled Gaussian
         int rad_out = 0;
-        uint32_t key_out = 0u, tiles_out = 0, clamp_bits = 0;  // sort key 0: culled (ggr_common.h GGR_KEY_BASE)
+        uint32_t key_out = 0u, clamp_bits = 0;  // sort key 0: culled (ggr_common.h GGR_KEY_BASE)
         uint2 rect_out = make_uint2(0, 0);
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
 
@@ -323,7 +323,6 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                     // > 0: t2 > 0.2f.  The three-pass sort takes 30-bit keys: depths ≥ 6.8e37 (incl. +inf) share the last key
                     // and keep ascending id among themselves instead of voiding the frame (ggr_raster.h "depth order")
                     key_out = min(__float_as_uint(t2) - GGR_KEY_BASE, GGR_KEY_MAX);
-                    tiles_out = (uint32_t)area_t;
                     // tile rows of view v sit below those of views 0 … v-1 in the virtual stacked image
                     const uint32_t yo = (uint32_t)((v0 + v) * gy);
                     if (area_t) rect_out = make_uint2((uint32_t)tx0 | (((uint32_t)ty0 + yo) << 16),

@@ -186,7 +186,6 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         float V[16], PM[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) { V[k] = vs.view[16 * v + k]; PM[k] = vs.proj[16 * v + k]; }
-        const float* campos = vs.campos + 3 * v;
         const float tanfovx = vs.tanfov ? vs.tanfov[2 * v] : vs.tanfovx;      // device-resident tan(fov/2)
         const float tanfovy = vs.tanfov ? vs.tanfov[2 * v + 1] : vs.tanfovy;
         const float in_s = vs.input_scale ? vs.input_scale[v] : 1.0f;

@@ -58,7 +58,7 @@ static __device__ __constant__ float bSH_C4[9] = {2.5033429417967046f, -1.770130
                     T(15, bSH_C3[6] * x * (xx - 3.f * yy), bSH_C3[6] * 3.f * (xx - yy), bSH_C3[6] * -6.f * xy, 0.f)       \
                     if ((deg) > 3) {                                                                                      \
                         F                                                                                                 \
-                        const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f, c21 = 21.f * zz - 3.f;                      \
+                        const float a7 = 7.f * zz - 1.f, b7 = 7.f * zz - 3.f; [[maybe_unused]] const float c21 = 21.f * zz - 3.f;                      \
                         const float xmy = xx - yy, x3y = xx - 3.f * yy, y3x = 3.f * xx - yy;                              \
                         T(16, bSH_C4[0] * xy * xmy, bSH_C4[0] * y * y3x, bSH_C4[0] * x * x3y, 0.f)                        \
                         T(17, bSH_C4[1] * yz * y3x, bSH_C4[1] * 6.f * xy * z, bSH_C4[1] * 3.f * z * xmy, bSH_C4[1] * y * y3x) \
