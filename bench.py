@@ -829,7 +829,7 @@ def main():
     # whose list sizes differ by > 25 % alternating — the guess is 1.25 × the largest of the last eight counts, so after
     # the first pair it holds for both; (c) the MISS path itself: the history is reset to the small scene before every
     # render of the large one, so each timed forward is enqueued with a buffer that is too small, detected at its end, and
-    # repeated in upstream's order.
+    # repaired inside the call (exact buffer, tile ranges, scatter and blend once more).
     hint_rec = None
     if world == 1 and not args.no_graph:
         try:
@@ -877,7 +877,8 @@ def main():
             hint_rec["forced_miss"] = {"large_scene_step_ms_wall_miss": percentiles(miss_ms[2:]),
                                        "large_scene_step_ms_wall_hit": percentiles(hit_ms[2:]), "forwards": st_miss,
                                        "note": "wall clock around ONE step incl. the final synchronize; a miss = the forward "
-                                               "enqueued with too small a buffer, detected at its end, repeated in upstream's order"}
+                                               "enqueued with too small a buffer, detected at its end, repaired inside the call (exact buffer from the allocator, "
+                                               "tile ranges + scatter + blend once more; until round 5 the whole call was repeated)"}
             log(f"list-hint legs: {hint_rec}")
             del wl_b
             torch.cuda.empty_cache()

@@ -387,6 +387,7 @@ const uint32_t* radix_sort_fault_word(const uint32_t* hist);
 void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint2** rect_sorted,
                               uint32_t** zero_area, uint32_t* zero_words);
 // K3: writes point_list[min(N, capacity)]
+void launch_tile_list_ranges(const TileListPlan& pl, size_t T, void* work, uint2* ranges, hipStream_t s);
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                               const uint2* rect, const void* work, uint32_t* point_list, uint32_t capacity,
                               hipStream_t s);

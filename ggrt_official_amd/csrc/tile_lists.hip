@@ -205,7 +205,9 @@ bin_group_prefix_kernel(uint32_t* __restrict__ wsum, uint32_t T, uint32_t nw, ui
                         uint2* __restrict__ ranges, uint32_t* __restrict__ total_out /*[0] = N, [1] = overflow | fault*/,
                         uint32_t capacity /*entries the caller's list buffer holds (sync-free mode); ~0u = exact*/,
                         uint32_t* __restrict__ host_total /*pinned host word that also receives N, or NULL*/,
-                        const uint32_t* __restrict__ sort_fault /*the depth sort's look-back timeout word, or NULL*/) {
+                        const uint32_t* __restrict__ sort_fault /*the depth sort's look-back timeout word, or NULL*/,
+                        int ranges_only /*1: only (re)write the tile ranges — the repair of a hinted forward whose guess
+                                          did not hold (api.hip): wsum already holds positions and is left alone*/) {
     __shared__ uint32_t w_part[4], w_own[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bx = gridDim.x - 1u - blockIdx.x, g = blockIdx.y;
@@ -234,6 +236,7 @@ bin_group_prefix_kernel(uint32_t* __restrict__ wsum, uint32_t T, uint32_t nw, ui
         const uint32_t rs = min(start, capacity), re = min(start + own, capacity);
         ranges[t] = re > rs ? make_uint2(rs, re) : make_uint2(0u, 0u);
     }
+    if (ranges_only) return;
     if (g == 0 && bx == gridDim.x - 1u && tid == 0) {
         const uint32_t n_all = base + w_own[0] + w_own[1] + w_own[2] + w_own[3];
         // a look-back spin of the depth sort that ran into its bound leaves a mis-sorted order behind: the frame
@@ -527,8 +530,17 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.wsum, (uint32_t)T, pl.nw, pl.wpg,
                        w.gsum, w.total);
     hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.wsum, (uint32_t)T, pl.nw,
-                       pl.wpg, w.gsum, w.total, ranges, total_out, capacity, host_total, sort_fault);
+                       pl.wpg, w.gsum, w.total, ranges, total_out, capacity, host_total, sort_fault, 0);
     if (after_scan) (void)hipEventRecord(after_scan, s);  // (N is in the host word long before: written by the launch's first block)
+}
+
+// the tile ranges once more, uncut: after a hinted forward's guess did not hold they are cut at the guessed capacity
+void launch_tile_list_ranges(const TileListPlan& pl, size_t T, void* work, uint2* ranges, hipStream_t s) {
+    if (T == 0) return;
+    const WorkArea w = carve_work(pl, work, T);
+    hipLaunchKernelGGL(bin_group_prefix_kernel, dim3((unsigned)((T + 255) / 256), 1), dim3(256), 0, s, w.wsum, (uint32_t)T,
+                       pl.nw, pl.wpg, w.gsum, w.total, ranges, (uint32_t*)nullptr, 0xFFFFFFFFu, (uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, 1);
 }
 
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,

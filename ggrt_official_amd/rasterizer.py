@@ -166,7 +166,7 @@ def set_list_hint(enabled: bool) -> bool:
 
 
 # what the default mode did with its guesses (process-wide): calls that ran with a guessed list buffer that held
-# ("hinted"), that had to be repeated in upstream's order ("missed"), and that ran in upstream's order from the start
+# ("hinted"), whose guess did not hold — repaired inside the call, or repeated in upstream's order ("missed") —, and that ran in upstream's order from the start
 # ("exact": first call of a shape, hints off, stage profiling)
 _hint_stats = {"hinted": 0, "missed": 0, "exact": 0}
 
@@ -228,7 +228,9 @@ def _forward_with_guess(call, fout, holder, lib, dev, W, H, key, user_capacity, 
         if rc != _GGR_E_CAPACITY:
             _check(rc, "ggr_forward")
             _note_rendered(key, int(fout.num_rendered))
-            _hint_stats["hinted"] += 1
+            # capacity_is_hint == 2: the guess did not hold and the call repaired itself (exact buffer through the allocator —
+            # `holder["bin"]` is that buffer now —, scatter and blend once more: csrc/api.hip)
+            _hint_stats["missed" if int(fout.capacity_is_hint) == 2 else "hinted"] += 1
             return
         _hint_stats["missed"] += 1
         # the guess did not hold: once more, in upstream's order (the buffers of the first attempt are released to the

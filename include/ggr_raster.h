@@ -46,8 +46,9 @@ enum {
                             tiles (1 048 560 px: the packed tile rects hold 16-bit tile coordinates); the message of
                             ggr_last_error() names the limit that was hit.  (Until ABI 8 frames wider than 12 288 px were
                             refused: rows of more than 768 tiles are now counted in column windows.) */
-    GGR_E_CAPACITY = 5   /* GgrForwardOut.capacity_is_hint: num_rendered exceeds the buffer that was brought along — the
-                            outputs of this call are void, repeat it in exact mode (or with a larger buffer) */
+    GGR_E_CAPACITY = 5   /* GgrForwardOut.capacity_is_hint: num_rendered exceeds the buffer that was brought along AND the
+                            allocator could not supply the exact one (or returned NULL) — the outputs of this call are
+                            void, repeat it in exact mode (or with a larger buffer) */
 };
 
 /* Mirrors the NamedTuple built at cuda_splatting.py:101-113 (field meaning identical). */
@@ -157,7 +158,11 @@ typedef struct GgrForwardOut {
                               waiting for it, then the call waits for num_rendered alone (the exact mode's early read-back;
                               the device is busy with scatter and blend meanwhile) and returns it.  Fits: every output is what
                               the exact mode gives, and the host's latency after the read-back — alloc, two launches — is off
-                              the device's critical path.  Does not fit: GGR_E_CAPACITY, outputs void. */
+                              the device's critical path.  Does not fit: the call REPAIRS itself (ABI 9) — the allocator
+                              is asked for ggr_binning_bytes(num_rendered) (its second call, as in the exact mode), scatter
+                              and blend run once more on that buffer, and on return binning_buffer / binning_capacity name
+                              the new buffer (the one to keep for ggr_backward) and this field reads 2 (IN/OUT).  Only if the
+                              allocator returns NULL: GGR_E_CAPACITY, outputs void. */
 } GgrForwardOut;
 
 /* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */

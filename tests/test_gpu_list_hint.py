@@ -49,7 +49,7 @@ def test_guessed_buffer_gives_the_exact_modes_results():
         ggrt_official_amd.set_list_hint(prev)
 
 
-def test_a_guess_that_is_too_small_repeats_the_call():
+def test_a_guess_that_is_too_small_is_repaired_inside_the_call():
     P, W, H = 50_000, 320, 240
     small = make_scene(P, W, H, sh_degree=1, profile="B", seed=6)      # small splats: few list entries
     big = make_scene(P, W, H, sh_degree=1, profile="A", seed=7)        # same shape, several times the entries
@@ -63,7 +63,7 @@ def test_a_guess_that_is_too_small_repeats_the_call():
         ggrt_official_amd.list_hint_stats(reset=True)
         _same(want_small, _run(small, dL))       # notes the small N
         assert ggrt_official_amd.list_hint_stats() == {"hinted": 0, "missed": 0, "exact": 1}
-        got_big = _run(big, dL)                  # guess too small → GGR_E_CAPACITY inside → repeated in upstream's order
+        got_big = _run(big, dL)                  # guess too small → repaired inside the call (exact buffer, scatter + blend again)
         _same(want_big, got_big)
         assert ggrt_official_amd.list_hint_stats() == {"hinted": 0, "missed": 1, "exact": 1}
         _same(want_big, _run(big, dL))           # now guessed from the big N
