@@ -86,3 +86,51 @@ def test_streaming_copy_yardstick():
         assert torch.equal(a, b)
     assert lib.ggr_debug_copy(a.data_ptr() + 4, b.data_ptr(), 1024, 0, None) == 1      # GGR_E_INVALID
     assert lib.ggr_debug_copy(a.data_ptr(), b.data_ptr(), 1000, 0, None) == 1
+
+
+def test_a_missed_guess_is_repaired_in_a_launch_set_too():
+    """The same repair on the launch-set entry (ggr_forward_views: three views of one Gaussian set): history holds the small
+    scene's count, the large scene misses, and the call still returns what upstream's order returns."""
+    from ggrt_official_amd.rasterizer import rasterize_views
+    P, W, H, V = 40_000, 256, 192, 3
+    small = make_scene(P, W, H, sh_degree=1, profile="B", seed=16).to(dev)
+    big = make_scene(P, W, H, sh_degree=1, profile="A", seed=17).to(dev)
+    dL = upstream_gradient(W, H, seed=5).to(dev)
+
+    def cams(sc):
+        vs = []
+        for k in range(V):
+            c2w = torch.eye(4, dtype=torch.float64)
+            c2w[0, 3] = 0.04 * k
+            v = make_scene(8, W, H, sh_degree=1, seed=1, c2w=c2w).to(dev)
+            vs.append((v.viewmatrix, v.projmatrix, v.campos))
+        tanfov = torch.tensor([[sc.tanfovx, sc.tanfovy]] * V, dtype=torch.float32, device=dev)
+        return (torch.stack([v[0] for v in vs]), torch.stack([v[1] for v in vs]), torch.stack([v[2] for v in vs]),
+                sc.bg[None].expand(V, 3).contiguous(), tanfov)
+
+    def run(sc):
+        leaves = [t.clone().requires_grad_() for t in (sc.means3D, sc.shs, sc.opacities, sc.cov3D)]
+        m, sh, op, cov = leaves
+        color, radii, depth = rasterize_views(m, op, *cams(sc), sc.settings(), shs=sh, cov3D_precomp=cov)
+        (color * dL[None]).sum().backward()
+        torch.cuda.synchronize()
+        return color.detach().cpu(), radii.cpu(), depth.detach().cpu(), [t.grad.cpu() for t in leaves]
+
+    def same(a, b):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for x, y in zip(a[3], b[3]):
+            assert rel_l2(x.numpy(), y.numpy()) < 2e-5
+
+    prev = ggrt_official_amd.set_list_hint(False)
+    try:
+        want_small, want_big = run(small), run(big)
+        ggrt_official_amd.set_list_hint(True)
+        ggrt_official_amd.clear_list_hints()
+        ggrt_official_amd.list_hint_stats(reset=True)
+        same(want_small, run(small))
+        same(want_big, run(big))                 # the miss
+        st = ggrt_official_amd.list_hint_stats(reset=True)
+        assert st["missed"] == 1 and st["exact"] == 1, st
+        same(want_big, run(big))
+    finally:
+        ggrt_official_amd.set_list_hint(prev)
