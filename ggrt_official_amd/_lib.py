@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libggr_raster.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -23,6 +23,7 @@ class GgrSettings(C.Structure):
         ("scale_modifier", C.c_float), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
         ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("tanfov_dev", C.c_void_p), ("sh_max_degree", C.c_int32), ("scissor", C.c_int32 * 4), ("reference_rects", C.c_int32),
+        ("depth_sort", C.c_int32),
     ]
 
 
@@ -47,7 +48,8 @@ class GgrForwardOut(C.Structure):
         ("out_color", C.c_void_p), ("radii", C.c_void_p), ("out_depth", C.c_void_p), ("geom_buffer", C.c_void_p),
         ("image_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("num_rendered", C.c_int64),
         ("stage_ms", C.c_void_p), ("binning_capacity", C.c_int64), ("no_backward", C.c_int32),
-        ("backward_scratch", C.c_void_p), ("capacity_is_hint", C.c_int32),
+        ("backward_scratch", C.c_void_p), ("capacity_is_hint", C.c_int32), ("max_list_len", C.c_int32),
+        ("depth_sort_used", C.c_int32),
     ]
 
 
@@ -68,7 +70,8 @@ class GgrBackwardOut(C.Structure):
         ("dL_dprojmatrix", C.c_void_p), ("dL_dcampos", C.c_void_p), ("stage_ms", C.c_void_p),
     ]
 
-FWD_STAGES = ["preprocess", "depth_sort", "tile_count", "tile_scatter", "blend", "colour_side_stream"]
+FWD_STAGES = ["preprocess", "depth_sort", "tile_count", "tile_scatter", "blend", "colour_side_stream", "tile_sort"]
+DEPTH_SORT = {"auto": 0, "global": 1, "per_tile": 2}
 BWD_STAGES = ["clear", "blend", "preprocess"]
 
 

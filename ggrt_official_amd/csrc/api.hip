@@ -41,23 +41,31 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(GGR_E_HIP, "%s: %s", what, hipGetErrorString(e_));    \
     } while (0)
 
-// Optional per-stage HIP-event timing (profiling mode only: stage_ms != NULL).
+// Optional per-stage HIP-event timing (profiling mode only: stage_ms != NULL).  mark(stage): the time since the previous
+// mark belongs to `stage` (the forward's stages are not walked in index order: the per-tile depth sort sits behind the scatter).
 struct StageTimer {
     hipStream_t s;
     float* out;
     int n;
-    hipEvent_t ev[16];
+    hipEvent_t ev[24];
+    int stage_of[24];
     int used = 0;
     StageTimer(hipStream_t s_, float* out_, int n_) : s(s_), out(out_), n(n_) {
-        if (out) for (int i = 0; i <= n; i++) (void)hipEventCreate(&ev[i]);
-        mark();
+        if (out) for (int i = 0; i < 24; i++) (void)hipEventCreate(&ev[i]);
+        mark(-1);
     }
-    void mark() { if (out && used <= n) { (void)hipEventRecord(ev[used], s); used++; } }
+    void mark(int stage) {
+        if (out && used < 24) { (void)hipEventRecord(ev[used], s); stage_of[used] = stage; used++; }
+    }
     void finish() {
         if (!out) return;
         (void)hipStreamSynchronize(s);
-        for (int i = 0; i + 1 < used; i++) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); out[i] += ms; }
-        for (int i = 0; i <= n; i++) (void)hipEventDestroy(ev[i]);
+        for (int i = 1; i < used; i++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+            if (stage_of[i] >= 0 && stage_of[i] < n) out[stage_of[i]] += ms;
+        }
+        for (int i = 0; i < 24; i++) (void)hipEventDestroy(ev[i]);
         out = nullptr;
     }
     ~StageTimer() { finish(); }
@@ -76,6 +84,8 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
                     "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
     if (st->sh_max_degree != 0 && st->sh_max_degree != 3 && st->sh_max_degree != 4)
         return fail(GGR_E_INVALID, "sh_max_degree must be 0 (default), 3 or 4");
+    if (st->depth_sort < GGR_DEPTH_SORT_AUTO || st->depth_sort > GGR_DEPTH_SORT_PER_TILE)
+        return fail(GGR_E_INVALID, "depth_sort must be 0 (auto), 1 (global) or 2 (per tile)");
     if ((st->scissor[0] | st->scissor[1] | st->scissor[2] | st->scissor[3]) &&
         (st->scissor[0] < 0 || st->scissor[1] < 0 || st->scissor[2] <= st->scissor[0] || st->scissor[3] <= st->scissor[1]))
         return fail(GGR_E_INVALID, "scissor must be x0 < x1, y0 < y1, all >= 0 (or all zero for none)");
@@ -138,7 +148,9 @@ SideStream* side_stream() {
     if (!r.stream) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority (numerically greatest)
-        bool ok = hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo) == hipSuccess;
+        const char* pe = getenv("GGR_COLOUR_PRIO");   // dev: "high" / "normal" instead of the lowest priority
+        const int prio = (pe && *pe == 'h') ? hi : (pe && *pe == 'n') ? (lo + hi) / 2 : lo;
+        bool ok = hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, prio) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&r.join, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreate(&r.t0) == hipSuccess && hipEventCreate(&r.t1) == hipSuccess;
@@ -346,6 +358,35 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     ImageLayout im = ggr_carve_image(out->image_buffer, W, H, NV);
     StageTimer tm(s, out->stage_ms, GGR_FWD_STAGES);
 
+    // How the lists get their depth order (GgrSettings.depth_sort; tile_sort.hip).  Per tile: no global depth sort — the
+    // tile-list builder walks the Gaussians in id order and every tile's list is sorted on its own afterwards.  A list longer
+    // than GGR_TSORT_CAP_LARGE cannot be sorted that way: with a read-back (exact mode, capacity_is_hint) the call then
+    // rebuilds the lists with the global sort; the pure sync-free mode has no read-back, so AUTO keeps the global sort there.
+    const bool sync_free = out->binning_capacity > 0 && out->binning_buffer != nullptr;
+    const bool hinted = sync_free && out->capacity_is_hint != 0;   // exact mode with a guessed buffer: N is awaited at the END
+    if (out->binning_capacity >= 0x7FFFFFFF) return fail(GGR_E_LIMIT, "binning_capacity too large");
+    int depth_sort = st->depth_sort;
+    if (const char* e = getenv("GGR_DEPTH_SORT")) {   // dev / A-B override of AUTO (read per call): "global" | "per_tile"
+        if (depth_sort == GGR_DEPTH_SORT_AUTO && *e)
+            depth_sort = (*e == 'g' || *e == '1') ? GGR_DEPTH_SORT_GLOBAL : (*e == 'p' || *e == '2') ? GGR_DEPTH_SORT_PER_TILE : depth_sort;
+    }
+    // AUTO = the global sort: at C3 the two forms measure the same (forward 0.404-0.409 ms per tile against 0.409 global,
+    // NOTES r6) — the per-tile sort is N entries' worth of LDS and vector work where the global sort is mostly waiting, and
+    // the colour kernel that hides beside the global sort finds no such partner per tile — so the default stays with the
+    // form that has no list-length limit
+    if (depth_sort == GGR_DEPTH_SORT_AUTO) depth_sort = GGR_DEPTH_SORT_GLOBAL;
+    bool per_tile = depth_sort == GGR_DEPTH_SORT_PER_TILE && P > 0 && tiles > 0;
+    out->depth_sort_used = per_tile ? GGR_DEPTH_SORT_PER_TILE : GGR_DEPTH_SORT_GLOBAL;
+    const uint32_t len_hint = out->max_list_len > 0 ? (uint32_t)out->max_list_len : 0u;
+    out->max_list_len = -1;
+
+    const ggr::TileListPlan plan = ggr::plan_tile_lists((size_t)P, tiles);
+    void* work = alloc(alloc_ctx, plan.work_bytes);  // 1st allocator call: transient work area
+    if (!work) return fail(GGR_E_ALLOC, "work-area allocator returned NULL");
+    uint2* rect_sorted = nullptr;
+    uint32_t *totals_area = nullptr, totals_words = 0;   // the tile-list builder's per-tile / per-group totals (start from zero)
+    ggr::tile_list_gather_targets(plan, work, tiles, &rect_sorted, &totals_area, &totals_words);
+
     // 1. per-Gaussian projection.  With SH colours the stage is split (preprocess.hip PART): the geometry half runs here, in
     //    front of the depth sort; the colour half — the SH rows, 4/5 of the stage's bytes, needed by the blend only — runs on
     //    the side stream beside the latency-bound sort / tile-list kernels (which leave HBM and most CUs idle) and is joined
@@ -356,15 +397,21 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // … nor for more than GGR_SPLIT_MAX_POINTS Gaussians per set: the colour kernel's bytes grow with them faster than the
     // window beside the binning does (C6′, 4.9 M Gaussians of 25 coefficients: 1.9 GB to move within ≈ 0.47 ms — at that rate
     // the depth sort beside it takes 0.66 instead of 0.29 ms; step 2.43 ms as one kernel, 2.51 split)
-    if (in->shs && P1 > 0 && P1 <= GGR_SPLIT_MAX_POINTS && !dbg && split_colour_enabled()) {
+    // … nor per tile: beside the tile counts and the scatter the colour kernel costs them what it saves (count +22, scatter +12 µs
+    // at C3), beside the per-tile sort it takes twice its time and the blend waits for it (NOTES r6)
+    if (in->shs && P1 > 0 && P1 <= GGR_SPLIT_MAX_POINTS && !dbg && split_colour_enabled() &&
+        (!per_tile || getenv("GGR_COLOUR_FORK") != nullptr)) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) side = side_stream();
         else (void)hipGetLastError();
     }
+    // (per tile: the kernel also clears the tile-list totals — the depth sort's last pass does it otherwise — and leaves the
+    //  sort's work area alone)
     ggr::launch_preprocess_fwd(P1, st->sh_degree, st->sh_stride, in->means3D, in->shs, in->colors_precomp,
                                in->opacities, in->scales, in->rotations, st->scale_modifier, in->cov3D_precomp,
                                in->aux_precomp, vs, W, H, out->radii, g, inf, s, side ? GGR_PRE_GEOMETRY : GGR_PRE_ALL, 0,
-                               out->no_backward ? 0 : 1);
+                               out->no_backward ? 0 : 1, per_tile ? totals_area : nullptr, per_tile ? totals_words : 0u,
+                               per_tile ? 1 : 0);
     KCHECK(dbg, s, "preprocess_fwd");
     bool colour_pending = side != nullptr;
     auto fork_colour = [&]() -> int {   // the colour kernel behind everything queued on `s` so far, on the side stream
@@ -386,131 +433,180 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     };
     // (started right behind the geometry kernel: started behind the depth sort, or behind the tile counts, it delays the
     //  blend by more than it spares the sort — NOTES r5)
-    { const int rc = fork_colour(); if (rc != GGR_OK) return rc; }
-    // (every return below this point must leave the caller's stream ordered behind the side stream: JoinGuard)
+    int colour_fork_at = 0;   // 0: behind the geometry kernel, 1: behind the tile counts, 2: behind the scatter (dev: NOTES r6)
+    if (const char* e = getenv("GGR_COLOUR_FORK")) { if (*e >= '0' && *e <= '2') colour_fork_at = *e - '0'; }
+    if (colour_fork_at == 0) { const int rc = fork_colour(); if (rc != GGR_OK) return rc; }
+    // (every return below this point must leave the caller's stream ordered behind the side stream: JoinGuard.  The guard
+    //  also covers a colour kernel that was never started: join() launches it first)
     struct JoinGuard {
         SideStream* sd; hipStream_t s; bool done = false;
         void join() { if (sd && !done) { (void)hipStreamWaitEvent(s, sd->join, 0); done = true; } }
         ~JoinGuard() { join(); }
     } joiner{side, s};
-    tm.mark();
+    auto fork_colour_at = [&](int where) -> int { return (colour_pending && colour_fork_at == where) ? fork_colour() : GGR_OK; };
+    tm.mark(GGR_FWD_PREPROCESS);
 
-    // 2. stable sort of the Gaussians by depth bits (ties keep ascending id).  Its last pass also drops every
-    //    Gaussian's tile rect at its sorted position (into the tile-list work area) and clears the per-tile totals.
-    const ggr::TileListPlan plan = ggr::plan_tile_lists((size_t)P, tiles);
-    void* work = alloc(alloc_ctx, plan.work_bytes);  // 1st allocator call: transient work area
-    if (!work) return fail(GGR_E_ALLOC, "work-area allocator returned NULL");
-    uint32_t *dk = nullptr, *order = nullptr;
-    if (P > 0) {
-        uint2* rect_sorted = nullptr;
-        uint32_t *zero_area = nullptr, zero_words = 0;
-        ggr::tile_list_gather_targets(plan, work, tiles, &rect_sorted, &zero_area, &zero_words);
-        // (preprocess already wrote the keys into g.keys_a; the values are the identity, formed by the sort's first pass)
-        ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, (uint32_t)segs, &dk, &order, s,
-                              /*hist_zeroed=*/true /*by preprocess_fwd*/,
-                              /*block_max_ready=*/(uint32_t)((P1 + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS) * (uint32_t)vs.sets /*likewise*/,
-                              /*identity_vals=*/true /*preprocess_fwd writes no values: the first pass forms them*/,
-                              g.rect, rect_sorted, zero_area, zero_words);
-        KCHECK(dbg, s, "depth sort");
-    }
-    tm.mark();
-
-    // 3. per-(chunk, tile) counts → list positions, tile ranges, num_rendered
     // sync-free mode: the caller brought a list buffer of `binning_capacity` entries → no read-back, no host
     // sync, no second allocator call; the whole forward (and backward) is then hipGraph-capturable
-    const bool sync_free = out->binning_capacity > 0 && out->binning_buffer != nullptr;
-    const bool hinted = sync_free && out->capacity_is_hint != 0;   // exact mode with a guessed buffer: N is awaited at the END
-    if (out->binning_capacity >= 0x7FFFFFFF) return fail(GGR_E_LIMIT, "binning_capacity too large");
-    const uint32_t capacity = sync_free ? (uint32_t)out->binning_capacity : 0xFFFFFFFFu;
+    uint32_t capacity = sync_free ? (uint32_t)out->binning_capacity : 0xFFFFFFFFu;
     // exact mode: num_rendered travels to the host through a pinned word written by the scan kernel, with an
     // event right behind that kernel — the host wakes up while the last scan kernel still runs and has the list
     // buffer allocated and the scatter queued by the time the GPU gets there (a device→host memcpy into pageable
     // memory + stream sync left the GPU idle for that long)
     ReadbackSlot* rb = ((!sync_free || hinted) && P > 0) ? readback_slot() : nullptr;
-    if (rb) {
-        *(volatile uint32_t*)rb->host = GGR_READBACK_ARMED;
-        (void)hipEventRecord(rb->ev_start, s);
-    }
-    if (P > 0) {
+    const uint32_t* sort_fault = ggr::radix_sort_fault_word(g.hist);
+
+    // ---- the pieces of the list build --------------------------------------------------------------------------------
+    // 2. stable sort of the Gaussians by depth bits (ties keep ascending id).  Its last pass also drops every
+    //    Gaussian's tile rect at its sorted position (into the tile-list work area) and clears the per-tile totals.
+    uint32_t *dk = nullptr, *order = nullptr;
+    auto global_sort = [&](bool area_cleared) {
+        // (preprocess already wrote the keys into g.keys_a; the values are the identity, formed by the sort's first pass)
+        ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, (uint32_t)segs, &dk, &order, s,
+                              /*hist_zeroed=*/area_cleared /*by preprocess_fwd*/,
+                              /*block_max_ready=*/(uint32_t)((P1 + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS) * (uint32_t)vs.sets /*likewise*/,
+                              /*identity_vals=*/true /*preprocess_fwd writes no values: the first pass forms them*/,
+                              g.rect, rect_sorted, totals_area, totals_words);
+    };
+    // 3. per-(chunk, tile) counts → list positions, tile ranges, num_rendered (+ the longest list)
+    auto count_pass = [&](bool id_order, bool to_host) {
+        if (to_host && rb) {
+            ((volatile uint32_t*)rb->host)[1] = 0u;
+            *(volatile uint32_t*)rb->host = GGR_READBACK_ARMED;
+            (void)hipEventRecord(rb->ev_start, s);
+        }
         ggr::launch_tile_list_count(plan, (size_t)P, tiles, gx, order, g.rect, work, im.ranges, g.counters, capacity, s,
-                                    /*rects_gathered=*/true, rb ? rb->host : nullptr, rb ? rb->ev : nullptr,
-                                    ggr::radix_sort_fault_word(g.hist));
-    } else {
-        HIP_TRY(hipMemsetAsync(im.ranges, 0, (tiles ? tiles : 1) * sizeof(uint2), s));
-        HIP_TRY(hipMemsetAsync(g.counters, 0, 8, s));
-    }
-    KCHECK(dbg, s, "tile_list_count");
-    if (dbg && sync_free && P > 0) {  // debug mode may sync: check the sort's fault bit right here
-        uint32_t two[2] = {0u, 0u};
-        HIP_TRY(hipMemcpy(two, g.counters, 8, hipMemcpyDeviceToHost));
-        if (two[1] & 2u) return fail(GGR_E_HIP, "%s", kSpinFault);
-        if (two[1] & 4u) return fail(GGR_E_LIMIT, "%s", kRangeFault);
-    }
-    uint32_t num_rendered = 0;
+                                    /*rects_gathered=*/true, (to_host && rb) ? rb->host : nullptr, (to_host && rb) ? rb->ev : nullptr,
+                                    id_order ? nullptr : sort_fault, id_order, id_order ? GGR_TSORT_CAP_LARGE : 0xFFFFFFFFu);
+    };
+    // 4. in-order scatter of the ids into the per-tile lists (+ per tile: the depth order, list by list)
     uint32_t* point_list = nullptr;
-    if (!sync_free) {
+    uint32_t sorted_upto = 0;   // per tile: lists of up to this many entries have been depth-sorted in `point_list`
+    // the per-tile sort of the lists with sorted_upto < length <= upto: one launch per length class it spans (tile_sort.hip)
+    auto tile_sort_upto = [&](uint32_t upto) {
+        upto = std::min<uint32_t>(upto, GGR_TSORT_CAP_LARGE);
+        if (upto <= sorted_upto) return;
+        if (sorted_upto < GGR_TSORT_CAP_SMALL)
+            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, g.keys_a, sorted_upto, std::min<uint32_t>(upto, GGR_TSORT_CAP_SMALL), s);
+        if (upto > GGR_TSORT_CAP_SMALL)
+            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, g.keys_a, std::max<uint32_t>(sorted_upto, GGR_TSORT_CAP_SMALL), upto, s);
+        sorted_upto = upto;
+    };
+    auto scatter_pass = [&](bool id_order, uint32_t cap_entries, uint32_t expect_longest) {
+        ggr::launch_tile_list_scatter(plan, (size_t)P, tiles, gx, id_order ? nullptr : order, g.rect, work, point_list,
+                                      cap_entries, s);
+        tm.mark(GGR_FWD_TILE_SCATTER);
+        (void)fork_colour_at(2);
+        sorted_upto = 0;
+        if (id_order) {
+            tile_sort_upto(expect_longest);
+            tm.mark(GGR_FWD_TILE_SORT);
+        }
+    };
+    // 5. blend (clears the caller's backward scratch on the side; an image without tiles launches nothing)
+    const bool scissored = (st->scissor[0] | st->scissor[1] | st->scissor[2] | st->scissor[3]) != 0;
+    auto blend_pass = [&]() {
+        if (colour_pending) (void)fork_colour();   // (a frame without list entries: nothing started it yet)
+        joiner.join();   // the colour records (side stream) are complete before the blend reads them
+        ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, g.colour, vs.bg, out->out_color, out->no_backward ? nullptr : im.final_T,
+                              im.n_contrib, out->out_depth, out->no_backward ? nullptr : im.ckpt, im.ckpt_slots, im.tile_top, NV,
+                              scissored ? 1 : 0, out->backward_scratch, ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s);
+    };
+    // what the host word(s) said: N, or a fault; the longest list
+    uint32_t num_rendered = 0, longest = 0;
+    auto read_counts = [&]() -> int {
         if (rb) {
             // the single host sync of forward.  N is written by the FIRST block of the last tile-list kernel: the host
             // watches the pinned word instead of waiting for that kernel's end (wait_readback above)
             const int rc = wait_readback((volatile uint32_t*)rb->host, query_event, (void*)rb->ev, readback_timeout_s(), &num_rendered,
                                          query_event, (void*)rb->ev_start);
             if (rc != GGR_OK) return rc;
-        } else {
-            uint32_t two[2] = {0u, 0u};
-            HIP_TRY(hipMemcpyAsync(two, g.counters, 8, hipMemcpyDeviceToHost, s));
+            longest = ((volatile uint32_t*)rb->host)[1];   // (stored before N's release store)
+        } else {   // no pinned slot (hipHostMalloc / hipEventCreate failed): copy + sync — a frame is never returned unchecked
+            uint32_t w4[4] = {0u, 0u, 0u, 0u};
+            HIP_TRY(hipMemcpyAsync(w4, g.counters, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            num_rendered = (two[1] & 2u) ? GGR_HOST_FAULT_SPIN : (two[1] & 4u) ? GGR_HOST_FAULT_RANGE : two[0];
+            num_rendered = (w4[1] & 2u) ? GGR_HOST_FAULT_SPIN : (w4[1] & 4u) ? GGR_HOST_FAULT_RANGE : w4[0];
+            longest = w4[2];
         }
         // raised by the tile-list kernel that writes N (bin_group_prefix_kernel)
         if (num_rendered == GGR_HOST_FAULT_SPIN) return fail(GGR_E_HIP, "%s", kSpinFault);
         if (num_rendered == GGR_HOST_FAULT_RANGE) return fail(GGR_E_LIMIT, "%s", kRangeFault);
         if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
         out->num_rendered = (int64_t)num_rendered;
-        tm.mark();
+        out->max_list_len = (int32_t)longest;
+        return GGR_OK;
+    };
+    // a list too long for the per-tile sort: the lists once more, through the global depth sort (the counts restart from zero:
+    // the sort's last pass clears the totals; its own work area was left untouched by preprocess_fwd)
+    bool rebuilt = false;
+    auto rebuild_global = [&]() {
+        per_tile = false;
+        rebuilt = true;
+        out->depth_sort_used = GGR_DEPTH_SORT_GLOBAL;
+        global_sort(/*area_cleared=*/false);
+        tm.mark(GGR_FWD_DEPTH_SORT);
+        count_pass(/*id_order=*/false, /*to_host=*/false);
+        tm.mark(GGR_FWD_TILE_COUNT);
+    };
+
+    if (P > 0 && tiles > 0) {
+        if (!per_tile) {
+            global_sort(/*area_cleared=*/true);
+            KCHECK(dbg, s, "depth sort");
+        }
+        tm.mark(GGR_FWD_DEPTH_SORT);
+        count_pass(per_tile, /*to_host=*/true);
+    } else {
+        tm.mark(GGR_FWD_DEPTH_SORT);
+        HIP_TRY(hipMemsetAsync(im.ranges, 0, (tiles ? tiles : 1) * sizeof(uint2), s));
+        HIP_TRY(hipMemsetAsync(g.counters, 0, 16, s));
+        rb = nullptr;
+    }
+    KCHECK(dbg, s, "tile_list_count");
+    { const int rc = fork_colour_at(1); if (rc != GGR_OK) return rc; }
+    if (dbg && sync_free && P > 0 && tiles > 0) {  // debug mode may sync: check the sort's fault bit right here
+        uint32_t two[2] = {0u, 0u};
+        HIP_TRY(hipMemcpy(two, g.counters, 8, hipMemcpyDeviceToHost));
+        if (two[1] & 2u) return fail(GGR_E_HIP, "%s", kSpinFault);
+        if (two[1] & 4u) return fail(GGR_E_LIMIT, "%s", kRangeFault);
+    }
+    if (!sync_free) {
+        if (P > 0 && tiles > 0) { const int rc = read_counts(); if (rc != GGR_OK) return rc; }
+        else { out->num_rendered = 0; out->max_list_len = 0; }
+        tm.mark(GGR_FWD_TILE_COUNT);
+        if (per_tile && longest > GGR_TSORT_CAP_LARGE) rebuild_global();
         void* bin_mem = alloc(alloc_ctx, ggr_point_list_bytes(num_rendered));  // 2nd call: kept for backward
         if (!bin_mem) return fail(GGR_E_ALLOC, "binning allocator returned NULL");
         out->binning_buffer = bin_mem;
         point_list = (uint32_t*)bin_mem;
     } else {
         out->num_rendered = -1;  // known on the device only: ggr_forward_status reads it (and the overflow flag)
-        tm.mark();
+        tm.mark(GGR_FWD_TILE_COUNT);
         point_list = (uint32_t*)out->binning_buffer;
     }
-
-    // 4. in-order scatter of the ids into the per-tile lists
-    if (sync_free || num_rendered > 0) {
-        ggr::launch_tile_list_scatter(plan, (size_t)P, tiles, gx, order, g.rect, work, point_list, capacity, s);
+    if (P > 0 && tiles > 0 && (sync_free || num_rendered > 0)) {
+        // (how long the lists are that the per-tile sort is launched for: known in the exact mode, the caller's guess with a
+        //  guessed buffer — checked and repaired at the end —, everything it can take in the pure sync-free mode)
+        const uint32_t expect = !sync_free ? longest : hinted ? (len_hint ? len_hint : GGR_TSORT_CAP_SMALL) : GGR_TSORT_CAP_LARGE;
+        scatter_pass(per_tile, capacity, expect);
         KCHECK(dbg, s, "tile_list_scatter");
+    } else {
+        tm.mark(GGR_FWD_TILE_SCATTER);
     }
-    tm.mark();
 
-    // 5. blend (clears the caller's backward scratch on the side; an image without tiles launches nothing)
     if (out->backward_scratch && tiles == 0)
         HIP_TRY(hipMemsetAsync(out->backward_scratch, 0, ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s));
-    joiner.join();   // the colour records (side stream) are complete before the blend reads them
-    ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, g.colour, vs.bg, out->out_color, out->no_backward ? nullptr : im.final_T,
-                          im.n_contrib, out->out_depth, out->no_backward ? nullptr : im.ckpt, im.ckpt_slots, im.tile_top, NV,
-                          (st->scissor[0] | st->scissor[1] | st->scissor[2] | st->scissor[3]) != 0, out->backward_scratch,
-                          ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s);
+    blend_pass();
     KCHECK(dbg, s, "blend_fwd");
-    tm.mark();
-    if (hinted) {   // num_rendered, while the device works on scatter and blend; the guess must have held
+    tm.mark(GGR_FWD_BLEND);
+    if (hinted && P > 0 && tiles > 0) {   // num_rendered, while the device works on scatter and blend; the guesses must have held
         out->num_rendered = 0;
-        if (rb) {
-            const int rc = wait_readback((volatile uint32_t*)rb->host, query_event, (void*)rb->ev, readback_timeout_s(), &num_rendered,
-                                         query_event, (void*)rb->ev_start);
-            if (rc != GGR_OK) return rc;
-        } else if (P > 0) {   // no pinned slot (hipHostMalloc / hipEventCreate failed): copy + sync, like the exact mode —
-            uint32_t two[2] = {0u, 0u};   // a hinted frame is never returned unchecked
-            HIP_TRY(hipMemcpyAsync(two, g.counters, 8, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            num_rendered = (two[1] & 2u) ? GGR_HOST_FAULT_SPIN : (two[1] & 4u) ? GGR_HOST_FAULT_RANGE : two[0];
-        }
-        if (num_rendered == GGR_HOST_FAULT_SPIN) return fail(GGR_E_HIP, "%s", kSpinFault);
-        if (num_rendered == GGR_HOST_FAULT_RANGE) return fail(GGR_E_LIMIT, "%s", kRangeFault);
-        if (num_rendered >= 0x7FFFFFFFu) return fail(GGR_E_LIMIT, "num_rendered %u too large", num_rendered);
-        out->num_rendered = (int64_t)num_rendered;
-        if (num_rendered > capacity) {
+        { const int rc = read_counts(); if (rc != GGR_OK) return rc; }
+        const bool cut = num_rendered > capacity;
+        const bool too_long = per_tile && longest > GGR_TSORT_CAP_LARGE;
+        const bool unsorted_left = per_tile && !too_long && longest > sorted_upto;   // the length guess was too small
+        if (cut) {
             // The guess did not hold.  Everything up to the tile ranges is valid (the counts do not depend on the list
             // buffer); only the ranges and the lists were cut at the guessed capacity and the blend ran on cut lists.  With an allocator at hand the call repairs
             // itself: the exact buffer (the allocator's second call, as in the exact mode), the tile ranges, the scatter and the blend once
@@ -523,16 +619,37 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
             out->binning_capacity = (int64_t)num_rendered;
             out->capacity_is_hint = 2;
             point_list = (uint32_t*)bin_mem;
-            ggr::launch_tile_list_ranges(plan, tiles, work, im.ranges, s);   // (they were cut at the guessed capacity)
-            ggr::launch_tile_list_scatter(plan, (size_t)P, tiles, gx, order, g.rect, work, point_list, 0xFFFFFFFFu, s);
-            KCHECK(dbg, s, "tile_list_scatter (hint miss)");
-            ggr::launch_blend_fwd(W, H, im.ranges, point_list, g.splat, g.colour, vs.bg, out->out_color,
-                                  out->no_backward ? nullptr : im.final_T, im.n_contrib, out->out_depth,
-                                  out->no_backward ? nullptr : im.ckpt, im.ckpt_slots, im.tile_top, NV,
-                                  (st->scissor[0] | st->scissor[1] | st->scissor[2] | st->scissor[3]) != 0, out->backward_scratch,
-                                  ggr_carve_bwd(nullptr, (size_t)P1, (size_t)NV).bytes, s);
-            KCHECK(dbg, s, "blend_fwd (hint miss)");
+            capacity = 0xFFFFFFFFu;
         }
+        if (too_long) {
+            rebuild_global();    // (also rewrites the ranges, uncut)
+        } else if (cut) {
+            ggr::launch_tile_list_ranges(plan, tiles, work, im.ranges, s);   // (they were cut at the guessed capacity)
+            // … which also leaves the status word's overflow bit standing: cleared below
+        }
+        if (cut || too_long) {
+            if (!too_long) HIP_TRY(hipMemsetAsync(g.counters + 1, 0, 4, s));   // the frame is complete after all (ggr_forward_status)
+            scatter_pass(per_tile, 0xFFFFFFFFu, longest);
+            KCHECK(dbg, s, "tile_list_scatter (repair)");
+        } else if (unsorted_left) {
+            tile_sort_upto(longest);
+            KCHECK(dbg, s, "tile_depth_sort (repair)");
+        }
+        if (cut || too_long || unsorted_left) {
+            if (!cut) out->capacity_is_hint = 3;   // repaired for the list LENGTH guess alone: the caller's buffer stays
+            blend_pass();
+            KCHECK(dbg, s, "blend_fwd (repair)");
+        }
+    } else if (hinted) {
+        out->num_rendered = 0;
+        out->max_list_len = 0;
+    }
+    if (rebuilt) {   // the global sort of the rebuild ran behind the read-back: its fault word is checked here (rare path: one sync)
+        uint32_t two[2] = {0u, 0u};
+        HIP_TRY(hipMemcpyAsync(two, g.counters, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (two[1] & 2u) return fail(GGR_E_HIP, "%s", kSpinFault);
+        if (two[1] & 4u) return fail(GGR_E_LIMIT, "%s", kRangeFault);
     }
     tm.finish();
     if (out->stage_ms && side) {   // the colour kernel's own duration (it ran BESIDE stages 1-3, not in addition to them)
@@ -577,7 +694,7 @@ int backward_impl(const GgrSettings* st, const ViewSet& vs, const GgrBackwardIn*
     StageTimer tm(s, out->stage_ms, GGR_BWD_STAGES);
     if (!in->scratch_zeroed)  // (else: this frame's forward cleared it inside its blend kernel)
         HIP_TRY(hipMemsetAsync(in->scratch, 0, sc.bytes, s));  // dL_dmeans2D / dL_dopacities are written by preprocess_bwd
-    tm.mark();
+    tm.mark(GGR_BWD_CLEAR);
 
     if (in->num_rendered != 0) {  // (-1: sync-free forward, count known on the device only)
         ggr::launch_blend_bwd(W, H, im.ranges, point_list, g.splat, g.colour, vs.bg, im.final_T, im.n_contrib,
@@ -585,7 +702,7 @@ int backward_impl(const GgrSettings* st, const ViewSet& vs, const GgrBackwardIn*
                               im.ckpt_slots, im.bwd_segments, NV, s);
         KCHECK(dbg, s, "blend_bwd");
     }
-    tm.mark();
+    tm.mark(GGR_BWD_BLEND);
     const float* cov = in->fwd.cov3D_precomp ? in->fwd.cov3D_precomp : g.cov3D;
     ggr::launch_preprocess_bwd(P, st->sh_degree, st->sh_stride, in->fwd.means3D, in->fwd.shs, g.sh_jac, has_cp ? 1 : 0,
                                in->fwd.scales, in->fwd.rotations, st->scale_modifier, cov, vs, W, H, in->radii, g.clamped,
@@ -595,7 +712,7 @@ int backward_impl(const GgrSettings* st, const ViewSet& vs, const GgrBackwardIn*
                                npose ? sc.pose_acc : nullptr, out->dL_dviewmatrix, out->dL_dprojmatrix,
                                out->dL_dcampos, input_form(st, &in->fwd, vs.sets, out->dL_dshs), in->fwd.cov3D_precomp ? 1 : 0, s);
     KCHECK(dbg, s, "preprocess_bwd");
-    tm.mark();
+    tm.mark(GGR_BWD_PREPROCESS);
     return GGR_OK;
 }
 
@@ -675,7 +792,9 @@ int ggr_forward_status(const void* geom_buffer, int32_t P, int64_t* num_rendered
     HIP_TRY(hipMemcpyAsync(host, g.counters, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (num_rendered) *num_rendered = (int64_t)host[0];
-    if (overflow) *overflow = (int32_t)(host[1] & 1u);
+    // (bit 3: a tile list too long for the per-tile depth sort in a forward that could not fall back — the frame is as
+    //  incomplete as one whose lists were cut)
+    if (overflow) *overflow = (int32_t)((host[1] & 1u) | ((host[1] >> 3) & 1u));
     if (host[1] & 2u) return fail(GGR_E_HIP, "%s", kSpinFault);
     if (host[1] & 4u) return fail(GGR_E_LIMIT, "%s", kRangeFault);
     return GGR_OK;

@@ -67,6 +67,10 @@
 #endif
 #define GGR_COUNT_SLOTS 12   // (row, 64-tile piece) pairs per count wave: bounds a count band; a tile row of more than
                              // 64·12 = 768 tiles (12 288 px) is counted in column windows (tile_lists.hip)
+// per-tile depth sort (tile_sort.hip): list lengths of the two launch classes.  16 B of LDS per entry + 12 KB: a workgroup of
+// the small class leaves room for four per CU, one of the large class has the CU to itself
+#define GGR_TSORT_CAP_SMALL 2048
+#define GGR_TSORT_CAP_LARGE 8192
 #define GGR_COUNT_GROUPS 8 // groups of count workgroups: the prefix over workgroups runs per group (T·groups-way parallel)
 
 // The kernels of the forward's critical path that run beside the colour kernel of the side stream (api.hip forward_impl:
@@ -345,7 +349,10 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            GeomLayout g, InputForm inf, hipStream_t s,
                            int part = 0 /*GGR_PRE_ALL, GGR_PRE_GEOMETRY, GGR_PRE_COLOUR (preprocess.hip)*/,
                            int colour_grid = 0 /*COLOUR: persistent blocks walking the chunks; 0 = one block per chunk*/,
-                           int keep_jacobian = 1 /*0: no backward will follow (inference) — sh_jac is not written*/);
+                           int keep_jacobian = 1 /*0: no backward will follow (inference) — sh_jac is not written*/,
+                           uint32_t* zero_area2 = nullptr /*also cleared (the tile-list builder's per-tile totals when no
+                           depth sort runs in front of it)*/, uint32_t zero_words2 = 0,
+                           int sort_area_untouched = 0 /*1: the depth sort's work area is NOT cleared (no sort will run)*/);
 #define GGR_PRE_ALL 0
 #define GGR_PRE_GEOMETRY 1
 #define GGR_PRE_COLOUR 2
@@ -380,17 +387,26 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
                             uint32_t* host_total = nullptr /*pinned, device-visible: also receives N …*/,
                             hipEvent_t after_scan = nullptr /*… and this event is recorded right behind the scan*/,
                             const uint32_t* sort_fault = nullptr /*device word the depth sort raises when a look-back
-                            spin hit its bound: folded into total_out[1] (bit 1) and host_total (~0u)*/);
+                            spin hit its bound: folded into total_out[1] (bit 1) and host_total (~0u)*/,
+                            bool id_order = false /*no depth sort ran: chunks = runs of Gaussian ids, `rect` is read as it is
+                            and the per-tile totals have been cleared by preprocess_fwd (tile_sort.hip)*/,
+                            uint32_t list_limit = 0xFFFFFFFFu /*longest list the per-tile depth sort takes: a longer one
+                            raises bit 3 of total_out[1]; total_out[2] / host_total[1] = the longest list*/);
 // the depth sort's fault word inside its work area (binning.hip)
 const uint32_t* radix_sort_fault_word(const uint32_t* hist);
 // where the depth sort's last pass should put the rects in depth order / which words it should clear
 void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint2** rect_sorted,
                               uint32_t** zero_area, uint32_t* zero_words);
-// K3: writes point_list[min(N, capacity)]
+// K3: writes point_list[min(N, capacity)]; order == NULL: id order (rect = the Gaussians' rects in id order)
 void launch_tile_list_ranges(const TileListPlan& pl, size_t T, void* work, uint2* ranges, hipStream_t s);
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                               const uint2* rect, const void* work, uint32_t* point_list, uint32_t capacity,
                               hipStream_t s);
+
+// tile_sort.hip: stable sort of every tile's list by the Gaussians' depth keys — lists with min_len < length <= max_len
+// (others are left alone; max_len <= GGR_TSORT_CAP_LARGE)
+void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint32_t* keys, uint32_t min_len,
+                            uint32_t max_len, hipStream_t s);
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float4* colour,

@@ -114,13 +114,20 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       uint32_t* __restrict__ depth_key,
                       uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
                       float* __restrict__ cov3D_out, uint32_t* __restrict__ zero_area, uint32_t zero_words,
+                      uint32_t* __restrict__ zero_area2, uint32_t zero_words2,
                       uint32_t* __restrict__ block_max, InputForm inf) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_row_stride]
     // zero the depth sort's histogram / ticket / look-back words here instead of with a separate fill launch
-    if (PART != GGR_PRE_COLOUR)
+    // (zero_area2: the tile-list builder's per-tile totals when NO depth sort runs in front of it — the sort's last pass
+    //  clears them otherwise; tile_sort.hip)
+    if (PART != GGR_PRE_COLOUR) {
         for (uint32_t wz = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; wz < zero_words;
              wz += gridDim.x * gridDim.y * blockDim.x)
             zero_area[wz] = 0u;
+        for (uint32_t wz = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; wz < zero_words2;
+             wz += gridDim.x * gridDim.y * blockDim.x)
+            zero_area2[wz] = 0u;
+    }
     // ---- Gaussian set blockIdx.y of the launch set (ViewSet.sets; one set: nothing moves) ----------------------------
     // The set's inputs are rows [set·P, (set+1)·P) of the caller's arrays, its views are views [v0, v0 + vps): every
     // pointer is rebased once, here, so that the rest of the kernel indexes (view, Gaussian) relative to the set.
@@ -480,11 +487,15 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
                            const float* aux_precomp, ViewSet vs, int W, int H, int32_t* radii,
-                           GeomLayout g, InputForm inf, hipStream_t s, int part, int colour_grid, int keep_jacobian) {
+                           GeomLayout g, InputForm inf, hipStream_t s, int part, int colour_grid, int keep_jacobian,
+                           uint32_t* zero_area2, uint32_t zero_words2, int sort_area_untouched) {
     if (P <= 0) return;
     if (part == GGR_PRE_COLOUR && !shs) return;   // precomputed colours: GEOMETRY has written the colour records
     // the depth sort's work area (binning.hip), sized for the V·P keys of all views
-    const uint32_t zero_words = (uint32_t)ggr_sort_zero_words((size_t)P * vs.V, ggr_sort_segments((size_t)vs.V));
+    // (sort_area_untouched: no depth sort will read the area — unless the per-tile sort has to be given up, and then the
+    //  host clears it — so it is not cleared here: 9 MB of stores at C3; the block maxima are left where the sort expects them)
+    const uint32_t sort_words = (uint32_t)ggr_sort_zero_words((size_t)P * vs.V, ggr_sort_segments((size_t)vs.V));
+    const uint32_t zero_words = sort_area_untouched ? 0u : sort_words;
     const int threads = GGR_PRE_THREADS;
     const int chunks = (P + threads - 1) / threads;
     // (colour_grid > 0, COLOUR only: that many persistent blocks walk the chunks — see the kernel)
@@ -503,7 +514,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     hipLaunchKernelGGL((preprocess_fwd_kernel<MULTI_, KC_, PART_, JAC_>), dim3(blocks, vs.sets), dim3(threads), lds, s, P, D, \
                        M, means3D, shs, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,       \
                        aux_precomp, vs, W, H, radii, g.splat, g.colour, g.sh_jac, (size_t)P * vs.V, g.keys_a, g.rect, g.clamped, g.cov3D,    \
-                       g.hist, zero_words, g.hist + zero_words, inf)
+                       g.hist, zero_words, zero_area2, zero_words2, g.hist + sort_words, inf)
     const bool jac = keep_jacobian != 0 && shs != nullptr;
 #define GGR_LAUNCH_PFWD(MULTI_, KC_, PART_)                                                                               \
     do { if (jac) GGR_LAUNCH_PFWD_J(MULTI_, KC_, PART_, true); else GGR_LAUNCH_PFWD_J(MULTI_, KC_, PART_, false); } while (0)

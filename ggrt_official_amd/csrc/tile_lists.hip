@@ -207,23 +207,26 @@ bin_group_prefix_kernel(uint32_t* __restrict__ wsum, uint32_t T, uint32_t nw, ui
                         uint32_t* __restrict__ host_total /*pinned host word that also receives N, or NULL*/,
                         const uint32_t* __restrict__ sort_fault /*the depth sort's look-back timeout word, or NULL*/,
                         int ranges_only /*1: only (re)write the tile ranges — the repair of a hinted forward whose guess
-                                          did not hold (api.hip): wsum already holds positions and is left alone*/) {
-    __shared__ uint32_t w_part[4], w_own[4];
+                                          did not hold (api.hip): wsum already holds positions and is left alone*/,
+                        uint32_t list_limit /*per-tile depth sort (tile_sort.hip): the longest list it can take; a longer one
+                                              raises bit 3 of the status word.  ~0u: no limit (global depth sort)*/) {
+    __shared__ uint32_t w_part[4], w_own[4], w_max[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bx = gridDim.x - 1u - blockIdx.x, g = blockIdx.y;
     const uint32_t first = bx * 256u, t = first + tid;
     // totals of all tiles in front of this block's (independent loads, 8 in flight per trip)
-    uint32_t part = 0;
+    uint32_t part = 0, longest = 0;   // (longest: only the block that owns the last tiles has seen every tile)
     for (uint32_t i0 = 0; i0 < first; i0 += 8 * 256) {
         uint32_t v[8];
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) { const uint32_t i = i0 + u * 256 + tid; v[u] = i < first ? total[i] : 0u; }
 #pragma unroll
-        for (uint32_t u = 0; u < 8; u++) part += v[u];
+        for (uint32_t u = 0; u < 8; u++) { part += v[u]; longest = max(longest, v[u]); }
     }
     const uint32_t own = t < T ? total[t] : 0u;
     const uint32_t incl = wave_scan_add(own), psum = wave_scan_add(part);
-    if (lane == 63u) { w_own[wave] = incl; w_part[wave] = psum; }
+    const uint32_t lmax = wave_scan_max(max(longest, own));
+    if (lane == 63u) { w_own[wave] = incl; w_part[wave] = psum; w_max[wave] = lmax; }
     __syncthreads();
     uint32_t base = w_part[0] + w_part[1] + w_part[2] + w_part[3];
     uint32_t before = 0;
@@ -244,11 +247,17 @@ bin_group_prefix_kernel(uint32_t* __restrict__ wsum, uint32_t T, uint32_t nw, ui
         // key beyond the sort's 30 bits (the sort's fault word shifted up by one); the exact mode's host word
         // carries GGR_HOST_FAULT_SPIN / _RANGE instead of N (ggr_forward fails with GGR_E_HIP / GGR_E_LIMIT on them).
         const uint32_t fault = sort_fault ? (*sort_fault & 3u) : 0u;
+        // the frame's longest tile list: what the per-tile depth sort must be able to hold (status bit 3: it cannot; the
+        // host's second pinned word carries the length itself, written BEFORE the release store of N)
+        const uint32_t n_longest = max(max(w_max[0], w_max[1]), max(w_max[2], w_max[3]));
         total_out[0] = n_all;
-        total_out[1] = (n_all > capacity ? 1u : 0u) | (fault << 1);
-        if (host_total)
+        total_out[1] = (n_all > capacity ? 1u : 0u) | (fault << 1) | (n_longest > list_limit ? 8u : 0u);
+        total_out[2] = n_longest;
+        if (host_total) {
+            host_total[1] = n_longest;
             __hip_atomic_store(host_total, (fault & 1u) ? GGR_HOST_FAULT_SPIN : fault ? GGR_HOST_FAULT_RANGE : n_all,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (t >= T) return;
     const uint32_t w0 = g * wpg, w1 = min(nw, w0 + wpg);
@@ -317,8 +326,8 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
 #pragma unroll
     for (int q = 0; q < NB; q++) {
         const uint32_t i = base + 64 * q + lane;
-        gq[q] = i < end ? order[i] : 0u;
-        rq[q] = i < end ? rect[i] : make_uint2(0u, 0u);  // rect is already in depth order (rect_sorted)
+        gq[q] = i < end ? (order ? order[i] : i) : 0u;   // (order == NULL: the chunks are walked in id order — tile_sort.hip)
+        rq[q] = i < end ? rect[i] : make_uint2(0u, 0u);  // rect is already in walk order (rect_sorted, or the rects themselves)
     }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -496,14 +505,17 @@ void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint
 void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                             const uint2* rect, void* work, uint2* ranges, uint32_t* total_out, uint32_t capacity,
                             hipStream_t s, bool rects_gathered, uint32_t* host_total, hipEvent_t after_scan,
-                            const uint32_t* sort_fault) {
+                            const uint32_t* sort_fault, bool id_order, uint32_t list_limit) {
     const WorkArea w = carve_work(pl, work, T);
     if (T == 0 || P == 0) {
         (void)hipMemsetAsync(total_out, 0, 8, s);
         if (T) (void)hipMemsetAsync(ranges, 0, T * sizeof(uint2), s);
         return;
     }
-    if (!rects_gathered)  // (ggr_forward: the depth sort's last pass has done both jobs already)
+    // id_order (per-tile depth sort, tile_sort.hip): the chunks are runs of Gaussian ids — the rects are read where preprocess_fwd
+    // left them, and it has cleared the totals
+    const uint2* rect_walk = id_order ? rect : w.rect_sorted;
+    if (!rects_gathered && !id_order)  // (ggr_forward: the depth sort's last pass has done both jobs already)
         hipLaunchKernelGGL(gather_rect_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (uint32_t)P, order,
                            rect, w.rect_sorted, w.gsum, (uint32_t)(pl.gsum_words + T));
     // count bands: whole tile rows; a wave holds the running counts of its (row, 64-tile piece) slots in registers, so a
@@ -525,12 +537,12 @@ void launch_tile_list_count(const TileListPlan& pl, size_t P, size_t T, int grid
     const uint32_t band_rows = (rows + nbands - 1) / nbands;
     nbands = (rows + band_rows - 1) / band_rows;
     hipLaunchKernelGGL(bin_count_kernel, dim3(pl.nw, nbands, ncols), dim3(256), (size_t)band_rows * std::min(col_w, gx) * 4, s,
-                       (uint32_t)P, w.rect_sorted, (uint32_t)T, gx, rows, band_rows, col_w, pl.nchunks, w.table, w.wsum);
+                       (uint32_t)P, rect_walk, (uint32_t)T, gx, rows, band_rows, col_w, pl.nchunks, w.table, w.wsum);
     const unsigned tb = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(bin_group_sum_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.wsum, (uint32_t)T, pl.nw, pl.wpg,
                        w.gsum, w.total);
     hipLaunchKernelGGL(bin_group_prefix_kernel, dim3(tb, pl.groups), dim3(256), 0, s, w.wsum, (uint32_t)T, pl.nw,
-                       pl.wpg, w.gsum, w.total, ranges, total_out, capacity, host_total, sort_fault, 0);
+                       pl.wpg, w.gsum, w.total, ranges, total_out, capacity, host_total, sort_fault, 0, list_limit);
     if (after_scan) (void)hipEventRecord(after_scan, s);  // (N is in the host word long before: written by the launch's first block)
 }
 
@@ -540,19 +552,19 @@ void launch_tile_list_ranges(const TileListPlan& pl, size_t T, void* work, uint2
     const WorkArea w = carve_work(pl, work, T);
     hipLaunchKernelGGL(bin_group_prefix_kernel, dim3((unsigned)((T + 255) / 256), 1), dim3(256), 0, s, w.wsum, (uint32_t)T,
                        pl.nw, pl.wpg, w.gsum, w.total, ranges, (uint32_t*)nullptr, 0xFFFFFFFFu, (uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, 1);
+                       (const uint32_t*)nullptr, 1, 0xFFFFFFFFu);
 }
 
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                               const uint2* rect, const void* work, uint32_t* point_list, uint32_t capacity,
                               hipStream_t s) {
-    (void)rect;
     if (T == 0 || P == 0) return;
     const WorkArea w = carve_work(pl, (void*)work, T);
+    const uint2* rect_walk = order ? w.rect_sorted : rect;   // (order == NULL: id order, the rects as preprocess_fwd left them)
     const size_t lds = (3 * (size_t)pl.sband_tiles + 4 * (GGR_BIN_CHUNK / GGR_SCATTER_PARTS) + 64) * 4;
     const uint32_t bands8 = (pl.nsbands + 7u) / 8u;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks * bands8 * 8u), dim3(64), lds, s, (uint32_t)P, order,
-                       w.rect_sorted, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, w.wsum, point_list, capacity,
+                       rect_walk, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, w.wsum, point_list, capacity,
                        pl.nsbands);
 }
 

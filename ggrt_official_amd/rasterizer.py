@@ -70,6 +70,11 @@ class GaussianRasterizationSettings(NamedTuple):
     #                         gradient); 4: the nine degree-4 terms are evaluated when sh_degree >= 4 with >= 25
     #                         coefficients.  0 = not chosen (also settable process-wide: GGR_SH_MAX_DEGREE=3|4): bands
     #                         0..3, and the first call that thereby leaves coefficients 16.. unused warns once
+    depth_sort: str = "auto"  # how the tile lists get their (depth, index) order — identical lists either way
+    #                         (include/ggr_raster.h GgrSettings.depth_sort): "global" = one depth sort of the Gaussians in front of
+    #                         the tile-list build; "per_tile" = lists built in index order, then every tile's list sorted by
+    #                         depth in LDS (no global dependency on the forward's critical path); "auto" = global (the two
+    #                         measure the same at 1080p / 1 M Gaussians; the global form has no list-length limit)
 
 
 class StageProfile:
@@ -191,20 +196,23 @@ def _scissor_key(rs):
     return tuple(int(v) for v in sc) if sc else None
 
 
-def _capacity_guess(key) -> int:
+def _capacity_guess(key):
+    """(list entries, longest tile list) to plan for: 1.25 × the largest of the last calls of the same shape; (0, 0) = no idea"""
     if not _HINTS_ON:
-        return 0
+        return 0, 0
     with _hint_lock:
         h = _hints.get(key)
-        return (int(1.25 * max(h)) + 4096) if h else 0
+        if not h:
+            return 0, 0
+        return int(1.25 * max(n for n, _ in h)) + 4096, int(1.25 * max(l for _, l in h))
 
 
-def _note_rendered(key, n: int):
+def _note_rendered(key, n: int, longest: int = 0):
     with _hint_lock:
         if len(_hints) > 256 and key not in _hints:   # (shapes that keep changing: start over rather than grow)
             _hints.clear()
         h = _hints.setdefault(key, [])
-        h.append(int(n))
+        h.append((int(n), max(int(longest), 0)))
         del h[:-8]
 
 
@@ -218,30 +226,34 @@ def _forward_with_guess(call, fout, holder, lib, dev, W, H, key, user_capacity, 
         fout.binning_capacity = user_capacity
         _check(call(), "ggr_forward")
         return
-    guess = 0 if profiling else _capacity_guess(key)   # (stage timing keeps upstream's order: the read-back is a stage)
+    # (stage timing keeps upstream's order: the read-back is a stage)
+    guess, len_guess = (0, 0) if profiling else _capacity_guess(key)
     if guess > 0:
         holder["bin"] = torch.empty((lib.ggr_binning_bytes(guess, W, H),), dtype=torch.uint8, device=dev)
         fout.binning_buffer = holder["bin"].data_ptr()
         fout.binning_capacity = guess
         fout.capacity_is_hint = 1
+        fout.max_list_len = len_guess
         rc = call()
         if rc != _GGR_E_CAPACITY:
             _check(rc, "ggr_forward")
-            _note_rendered(key, int(fout.num_rendered))
+            _note_rendered(key, int(fout.num_rendered), int(fout.max_list_len))
             # capacity_is_hint == 2: the guess did not hold and the call repaired itself (exact buffer through the allocator —
-            # `holder["bin"]` is that buffer now —, scatter and blend once more: csrc/api.hip)
-            _hint_stats["missed" if int(fout.capacity_is_hint) == 2 else "hinted"] += 1
+            # `holder["bin"]` is that buffer now —, scatter and blend once more: csrc/api.hip); == 3: the list buffer held, the
+            # guess of the longest tile list did not (the long lists were sorted and the frame blended once more)
+            _hint_stats["missed" if int(fout.capacity_is_hint) >= 2 else "hinted"] += 1
             return
         _hint_stats["missed"] += 1
         # the guess did not hold: once more, in upstream's order (the buffers of the first attempt are released to the
         # stream-ordered allocator: what is still running on them was enqueued before what follows)
-        _note_rendered(key, int(fout.num_rendered))
+        _note_rendered(key, int(fout.num_rendered), int(fout.max_list_len))
         holder.clear()
         fout.binning_buffer = None
         fout.binning_capacity = 0
         fout.capacity_is_hint = 0
+    fout.max_list_len = 0
     _check(call(), "ggr_forward")
-    _note_rendered(key, int(fout.num_rendered))
+    _note_rendered(key, int(fout.num_rendered), int(fout.max_list_len))
     if guess == 0:
         _hint_stats["exact"] += 1
 
@@ -273,6 +285,13 @@ def _sh_cap(rs, M: int) -> int:
     return cap
 
 
+def _depth_sort(rs) -> int:
+    v = getattr(rs, "depth_sort", "auto") or "auto"
+    if v not in _lib.DEPTH_SORT:
+        raise RuntimeError(f"depth_sort must be one of {sorted(_lib.DEPTH_SORT)}, not {v!r}")
+    return _lib.DEPTH_SORT[v]
+
+
 def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view, proj, campos) -> _lib.GgrSettings:
     tf = getattr(rs, "tanfov", None)
     if tf is not None and (tf.dtype != torch.float32 or not tf.is_contiguous() or (bg is not None and tf.device != bg.device)):
@@ -284,7 +303,8 @@ def _settings_struct(rs: GaussianRasterizationSettings, P: int, M: int, bg, view
         campos=_ptr(campos), prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfov_dev=_ptr(tf),
         sh_max_degree=_sh_cap(rs, int(M)),
         scissor=(C.c_int32 * 4)(*[int(v) for v in (getattr(rs, "scissor", None) or (0, 0, 0, 0))]),
-        reference_rects=int(bool(getattr(rs, "reference_rects", False))))
+        reference_rects=int(bool(getattr(rs, "reference_rects", False))),
+        depth_sort=_depth_sort(rs))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -367,6 +387,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # exact mode: count known, nothing to keep.  Sync-free mode: count + flags live in the geometry buffer on the
         # device, so that (≈100 MB at P = 1 M) buffer stays referenced until this thread's next forward
         _tls.last_forward = (geom, P) if capacity > 0 else (None, int(fout.num_rendered))
+        _tls.last_binning = (int(fout.depth_sort_used), int(fout.max_list_len))
         ctx.raster_settings = rs
         ctx.num_rendered = int(fout.num_rendered)
         ctx.dims = (P, M, H, W)
@@ -541,6 +562,7 @@ class _RasterizeViews(torch.autograd.Function):
                                 fout, holder, lib, dev, W, H, (dev.index, P, W, H, V, _scissor_key(rs)),
                                 capacity, prof is not None)
         _tls.last_forward = (geom, P * V) if capacity > 0 else (None, int(fout.num_rendered))
+        _tls.last_binning = (int(fout.depth_sort_used), int(fout.max_list_len))
         ctx.raster_settings = rs
         ctx.num_rendered = int(fout.num_rendered)
         ctx.dims = (P, M, H, W, V, B)
@@ -694,6 +716,15 @@ def last_forward_status():
         _check(lib.ggr_forward_status(geom.data_ptr(), P, C.byref(n), C.byref(ov),
                                       torch.cuda.current_stream(geom.device).cuda_stream), "ggr_forward_status")
     return int(n.value), bool(ov.value)
+
+
+def last_forward_binning():
+    """("global" | "per_tile", longest tile list or -1) of this thread's most recent forward: which form of the depth sort
+    built its lists (GgrForwardOut.depth_sort_used — "global" also after a per-tile attempt met a list it could not hold)."""
+    last = getattr(_tls, "last_binning", None)
+    if last is None:
+        raise RuntimeError("no forward has run on this thread")
+    return ("per_tile" if last[0] == 2 else "global"), last[1]
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 9
+#define GGR_ABI_VERSION 10
 
 enum {
     GGR_OK = 0,
@@ -90,7 +90,18 @@ typedef struct GgrSettings {
                                 (Gaussian, tile) pairs are exactly pairs every pixel would `continue` past — only the
                                 internal lists are shorter (num_rendered, n_contrib positions).  1: the reference's rects,
                                 i.e. lists identical to the reference's 64-bit sort, entry for entry. */
+    int32_t depth_sort;      /* ABI 10.  How the per-tile lists get their (depth, index) order — the same lists either way, bit
+                                for bit (the reference: ONE 64-bit radix sort over all (tile, depth) keys).
+                                GGR_DEPTH_SORT_GLOBAL (1): the P Gaussians are sorted by depth once, in front of the tile-list
+                                build, which then walks them in that order.  GGR_DEPTH_SORT_PER_TILE (2): the tile lists are
+                                built in index order and every tile's list is then sorted by depth, stably, in LDS — no global
+                                dependency on the forward's critical path; a list of more than 8192 entries cannot be sorted
+                                that way: ggr_forward then rebuilds the lists with the global sort inside the call (exact mode
+                                and capacity_is_hint), or raises the overflow flag of ggr_forward_status (sync-free mode).
+                                GGR_DEPTH_SORT_AUTO (0): the global sort (the two measure the same on a 1080p frame with 1 M
+                                Gaussians; the global form has no list-length limit). */
 } GgrSettings;
+enum { GGR_DEPTH_SORT_AUTO = 0, GGR_DEPTH_SORT_GLOBAL = 1, GGR_DEPTH_SORT_PER_TILE = 2 };
 
 /* Inputs of GaussianRasterizer.forward (cuda_splatting.py:118-125).
  * Exactly one of {shs, colors_precomp} and one of {cov3D_precomp, (scales, rotations)}. */
@@ -163,6 +174,12 @@ typedef struct GgrForwardOut {
                               and blend run once more on that buffer, and on return binning_buffer / binning_capacity name
                               the new buffer (the one to keep for ggr_backward) and this field reads 2 (IN/OUT).  Only if the
                               allocator returns NULL: GGR_E_CAPACITY, outputs void. */
+    int32_t max_list_len;  /* ABI 10.  OUT: the longest tile list of the frame (-1 in sync-free mode: known on the device only).
+                              IN, with capacity_is_hint = 1 and the per-tile depth sort: the longest list the caller expects (e.g.
+                              1.25 x the previous frame's; 0 = no idea) — decides whether the launch for lists of 2049..8192
+                              entries is enqueued up front.  A guess that was too small is repaired inside the call (those
+                              lists are sorted and the frame blended once more). */
+    int32_t depth_sort_used; /* ABI 10.  OUT: GGR_DEPTH_SORT_GLOBAL or GGR_DEPTH_SORT_PER_TILE — what built this frame's lists */
 } GgrForwardOut;
 
 /* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */
@@ -173,7 +190,8 @@ enum {
                           stages 1-3 (then stage 0 is the geometry half alone and stage 4 contains whatever wait for the
                           colours was left); 0 when the per-Gaussian stage ran as one kernel.  Not a term of the forward's
                           duration: stages 0-4 add up to it */,
-    GGR_FWD_STAGES = 6
+    GGR_FWD_TILE_SORT = 6 /* ABI 10: the per-tile depth sort (GgrSettings.depth_sort), behind the scatter; stage 1 is then 0 */,
+    GGR_FWD_STAGES = 7
 };
 enum { GGR_BWD_CLEAR = 0, GGR_BWD_BLEND = 1, GGR_BWD_PREPROCESS = 2, GGR_BWD_STAGES = 3 };
 

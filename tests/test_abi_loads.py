@@ -19,7 +19,7 @@ def test_library_builds_and_loads():
     path = _build.build_library()
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.ggr_abi_version() == 9
+    assert lib.ggr_abi_version() == _lib.ABI_VERSION == 10
     assert lib.ggr_source_hash().decode() == _build.source_hash() == _build.embedded_hash()
 
 
@@ -81,13 +81,29 @@ def test_size_queries_are_consistent():
         assert f(*args) % 256 == 0
 
 
-def test_struct_layouts_match_header_sizes():
-    # 64-bit ABI: sizes follow from the field lists in include/ggr_raster.h
-    assert ctypes.sizeof(_lib.GgrSettings) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4 + 8 + 4 + 4 * 4 + 4  # + sh_max_degree, scissor, reference_rects
-    assert ctypes.sizeof(_lib.GgrForwardIn) == 9 * 8 + 3 * 4 + 2 * 4 + 4
-    assert ctypes.sizeof(_lib.GgrForwardOut) == 9 * 8 + 8 + 8 + 8  # + no_backward (padded) + backward_scratch + capacity_is_hint (padded)
-    assert ctypes.sizeof(_lib.GgrBackwardIn) == (9 * 8 + 3 * 4 + 2 * 4 + 4) + 8 * 8 + 8  # + scratch_zeroed, padded
-    assert ctypes.sizeof(_lib.GgrBackwardOut) == 13 * 8
+def test_struct_layouts_match_header_sizes(tmp_path):
+    """The ctypes mirrors in _lib.py against the header itself: gcc compiles include/ggr_raster.h and prints every struct's
+    size and the offset of its last field (64-bit ABI)."""
+    import subprocess
+    last = {"GgrSettings": "depth_sort", "GgrForwardIn": "aux_b", "GgrForwardOut": "depth_sort_used",
+            "GgrBackwardIn": "scratch_zeroed", "GgrBackwardOut": "stage_ms", "GgrViews": "num_sets"}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ggr_raster.h"\nint main(void) {\n' + "".join(
+        f'  printf("{n} %zu %zu\\n", sizeof({n}), offsetof({n}, {f}));\n' for n, f in last.items()) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    seen = 0
+    for line in out:
+        if not line.strip():
+            continue
+        name, size, off = line.split()
+        cls = getattr(_lib, name)
+        assert ctypes.sizeof(cls) == int(size), name
+        assert getattr(cls, last[name]).offset == int(off), name
+        assert cls._fields_[-1][0] == last[name], name
+        seen += 1
+    assert seen == len(last)
 
 
 def test_readback_wait_never_spins_forever():

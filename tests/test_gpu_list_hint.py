@@ -41,7 +41,7 @@ def test_guessed_buffer_gives_the_exact_modes_results():
         ggrt_official_amd.set_list_hint(True)
         first = _run(sc, dL)                     # nothing known about this shape yet: upstream's order, notes N
         key = (0, P, W, H, 1, None)
-        assert R._capacity_guess(key) >= want[4]
+        assert R._capacity_guess(key)[0] >= want[4]
         second = _run(sc, dL)                    # guessed buffer
         _same(want, first)
         _same(want, second)
