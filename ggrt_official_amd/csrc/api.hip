@@ -836,6 +836,21 @@ int ggr_debug_readback_wait(int32_t scenario, double timeout_s, uint32_t* value)
     return wait_readback(&word, fake_query, &q, timeout_s, value);
 }
 
+int ggr_debug_counters(uint64_t* out, int32_t reset) {
+    g_err[0] = 0;
+    if (!out) return fail(GGR_E_INVALID, "null output");
+    unsigned long long f[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    HIP_TRY(hipDeviceSynchronize());
+    ggr::blend_fwd_counters(f, reset);
+    ggr::blend_bwd_counters(b, reset);
+    for (int i = 0; i < 4; i++) { out[i] = f[i]; out[4 + i] = b[i]; }
+#ifdef GGR_DEV_COUNTERS
+    return GGR_OK;
+#else
+    return fail(GGR_E_INVALID, "this library was built without -DGGR_DEV_COUNTERS: the counters are zero");
+#endif
+}
+
 int ggr_debug_copy(const void* src, void* dst, size_t bytes, int32_t blocks, void* stream) {
     g_err[0] = 0;
     if (!src || !dst || (bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return fail(GGR_E_INVALID, "bad arguments (16-byte granularity)");

@@ -28,6 +28,14 @@ namespace ggr {
 #define BATCH GGR_BATCH
 #define RB 8  // entries per reduction batch
 
+// dev counters (-DGGR_DEV_COUNTERS builds only; ggr_debug_counters): [0] (quadrant, entry) slots that survive the cull, [1] slots
+// in which NO lane is valid, [2] valid (slot, lane) pairs, [3] batches culled
+__device__ unsigned long long g_bwd_counters[4];
+void blend_bwd_counters(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_counters), sizeof(g_bwd_counters));
+    if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_counters), z, sizeof z); }
+}
+
 // [budget: reduce-dpp-moves]  (scripts/valu_budget.py attributes the ISA below each marker to that phase)
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -215,6 +223,9 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
     const int vix = vi < 4 ? vi : 11 - vi;   // the value transpose_cols8 leaves in this lane
     const int my_slot = lane >> 3;
 
+#ifdef GGR_DEV_COUNTERS
+    unsigned long long dc_slots = 0, dc_dead = 0, dc_pairs = 0, dc_batches = 0;
+#endif
     // [budget: stage]
     // the list ids of a batch are requested one batch ahead (id → record is a chain of two global round trips)
     uint32_t g_next = tid < seg_hi - seg_lo ? point_list[range.x + seg_hi - 1 - tid] : 0u;
@@ -262,6 +273,9 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#ifdef GGR_DEV_COUNTERS
+        dc_slots += (unsigned long long)ns; dc_batches++;
+#endif
         {
             for (int k0 = 0; k0 < ns; k0 += RB) {
                 // [budget: slot-setup]
@@ -302,6 +316,9 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                         const float G = __builtin_amdgcn_exp2f(-q2);
                         const float alpha_raw = fminf(amax, b.y * G);
                         const bool valid = ok_sl[sl] && idx < last && q2 >= 0.0f && alpha_raw >= amin;
+#ifdef GGR_DEV_COUNTERS
+                        if (ok_sl[sl]) { const uint64_t vm = __ballot(valid); dc_dead += vm ? 0ull : 1ull; dc_pairs += (unsigned long long)__popcll(vm); }
+#endif
                         const float alpha = valid ? alpha_raw : 0.f;
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32 (1 ulp); __frcp_rn would expand to a 10-instruction IEEE division
                         T = T * inv;
@@ -397,6 +414,12 @@ blend_bwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             }
         }
     }
+#ifdef GGR_DEV_COUNTERS
+    if (lane == 0) {
+        atomicAdd(&g_bwd_counters[0], dc_slots); atomicAdd(&g_bwd_counters[1], dc_dead);
+        atomicAdd(&g_bwd_counters[2], dc_pairs); atomicAdd(&g_bwd_counters[3], dc_batches);
+    }
+#endif
 }
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,

@@ -19,6 +19,14 @@
 
 namespace ggr {
 
+// dev counters (-DGGR_DEV_COUNTERS builds only; ggr_debug_counters): [0] survivors listed by the quadrant cull, [1] survivors
+// walked (a wave leaves the walk when its pixels are saturated), [2] (survivor, lane) pairs that composited, [3] batches culled
+__device__ unsigned long long g_fwd_counters[4];
+void blend_fwd_counters(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_counters), sizeof(g_fwd_counters));
+    if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_counters), z, sizeof z); }
+}
+
 #define BATCH GGR_BATCH
 #ifndef SURV_GROUP
 #define SURV_GROUP 4   // survivors per trip of the blend loop (one broadcast read of their offsets; measured, 2 / 4 / 8:
@@ -84,6 +92,9 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
     uint32_t last = 0;
+#ifdef GGR_DEV_COUNTERS
+    unsigned long long dc_listed = 0, dc_walked = 0, dc_taken = 0, dc_batches = 0;
+#endif
     // false: the pixel is saturated (or outside the image) and takes no further entry.  A lane MASK in scalar
     // registers, like every per-pixel condition below: a vector compare costs 4.6 cycles, a select 2.4, a literal operand
     // 2 more (tools/valu_peak_bench.hip, round 3) — the conditions are combined with scalar ANDs and applied by ONE select
@@ -153,6 +164,9 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                 if (keep) my_surv[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (surv_t)(e * 48);
                 ns += __popcll(mk);
             }
+#ifdef GGR_DEV_COUNTERS
+            dc_listed += (unsigned long long)ns; dc_batches++;
+#endif
             if (lane < SURV_GROUP) my_surv[ns + lane] = (surv_t)(BATCH * 48);  // pad with the null record (opacity 0)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -183,6 +197,9 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                     // (which entry: its LDS offset, already in a register — the list position follows from it after the
                     //  batch; reading it from the record was a fourth LDS read per survivor, 2 of 12 LDS cycles)
                     if (TRAIN) hit_off = take ? off : hit_off;
+#ifdef GGR_DEV_COUNTERS
+                    if (k0 + u < ns) { dc_walked++; dc_taken += (unsigned long long)__popcll(__ballot(take)); }
+#endif
                 }
                 if (!__any(live)) { wdone = true; break; }
             }
@@ -191,6 +208,12 @@ blend_fwd_kernel(int W, int H, int grid_x, const uint2* __restrict__ ranges,
             if (wdone && lane == 0) wave_done[wave] = 1;
         }
     }
+#ifdef GGR_DEV_COUNTERS
+    if (lane == 0) {
+        atomicAdd(&g_fwd_counters[0], dc_listed); atomicAdd(&g_fwd_counters[1], dc_walked);
+        atomicAdd(&g_fwd_counters[2], dc_taken); atomicAdd(&g_fwd_counters[3], dc_batches);
+    }
+#endif
     // [budget: epilogue]
     // the tile's last contributor: the backward replays the list entries before it (and nothing else)
     if (TRAIN) {

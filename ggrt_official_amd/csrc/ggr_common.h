@@ -416,6 +416,10 @@ void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_l
                       void* zero_area /*or null: also cleared, on the side*/, size_t zero_bytes /*multiple of 16*/,
                       hipStream_t s);
 
+// dev counters of the two blend kernels (zero unless the library was built with -DGGR_DEV_COUNTERS)
+void blend_fwd_counters(unsigned long long* out4, int reset);
+void blend_bwd_counters(unsigned long long* out4, int reset);
+
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float4* colour,
                       const float* bg, const float* final_T, const uint32_t* n_contrib,

@@ -362,6 +362,12 @@ int ggr_debug_readback_wait(int32_t scenario, double timeout_s, uint32_t* value)
  * what a pure HBM streaming kernel reaches on this part next to the 8 TB/s spec. */
 int ggr_debug_copy(const void* src, void* dst, size_t bytes, int32_t blocks, void* stream);
 
+/* Work counters of the two blend kernels on the current device since the last reset (no counterpart in the reference; dev builds
+ * only — a library built without -DGGR_DEV_COUNTERS returns GGR_E_INVALID and zeros).  out[0..3]: forward — survivors the
+ * quadrant culls listed, survivors walked, (survivor, pixel) pairs composited, batches culled; out[4..7]: backward — (quadrant,
+ * entry) slots that survived, slots without a single valid pixel, valid (slot, pixel) pairs, batches culled.  Synchronises the device. */
+int ggr_debug_counters(uint64_t* out /*[8]*/, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif
