@@ -299,16 +299,22 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 const float mid = 0.5f * (a + c);
                 const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
                 const float l1 = mid + sq, l2 = mid - sq;
-                const int rad = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+                const float radf = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
                 px = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
                 py = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
+                // NON-FINITE INPUTS (include/ggr_raster.h "non-finite inputs"; same test at the same place in
+                // oracle/ggr_oracle.c): a Gaussian whose projected geometry or opacity is not finite — or whose radius would
+                // overflow the int — takes no part in the frame.  (area stays 0: culled like an off-screen one.)
+                const bool finite = isfinite(px) && isfinite(py) && isfinite(con0) && isfinite(con1) && isfinite(con2) &&
+                                    isfinite(opac) && isfinite(a) && isfinite(c) && isfinite(t2) && radf < 1073741824.f;
+                const int rad = finite ? (int)radf : 0;
                 // (the reference clips the rect to the tile grid [0, gx] × [0, gy]; the scissor extension to its window's
                 //  tiles — the whole grid unless GgrSettings.scissor is set)
                 const int rminx = min(inf.sc_x1, max(inf.sc_x0, (int)((px - (float)rad) / (float)GGR_TILE)));
                 const int rminy = min(inf.sc_y1, max(inf.sc_y0, (int)((py - (float)rad) / (float)GGR_TILE)));
                 const int rmaxx = min(inf.sc_x1, max(inf.sc_x0, (int)((px + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
                 const int rmaxy = min(inf.sc_y1, max(inf.sc_y0, (int)((py + (float)rad + (float)(GGR_TILE - 1)) / (float)GGR_TILE)));
-                const int area = (rmaxx - rminx) * (rmaxy - rminy);
+                const int area = finite ? (rmaxx - rminx) * (rmaxy - rminy) : 0;
                 if (area != 0) {   // (visibility — radii, colours — follows the REFERENCE's rect whatever the lists hold)
                     vis = true;
                     rad_out = rad;
@@ -442,6 +448,22 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             r[0] += 0.5f; r[1] += 0.5f; r[2] += 0.5f;
             if (vis) clamp_bits = (r[0] < 0.f ? 1u : 0u) | (r[1] < 0.f ? 2u : 0u) | (r[2] < 0.f ? 4u : 0u);
             rgb[0] = fmaxf(r[0], 0.f); rgb[1] = fmaxf(r[1], 0.f); rgb[2] = fmaxf(r[2], 0.f);
+            if (!(isfinite(r[0]) && isfinite(r[1]) && isfinite(r[2]))) rgb[0] = r[0] + r[1] + r[2];   // (NaN / Inf: caught below)
+        }
+        // non-finite colour (the contract above, colour part): the Gaussian leaves the frame
+        if (vis && !(isfinite(rgb[0]) && isfinite(rgb[1]) && isfinite(rgb[2]))) {
+            vis = false;
+            rgb[0] = rgb[1] = rgb[2] = 0.f;
+            clamp_bits = 0u;
+            rad_out = 0; key_out = 0u; rect_out = make_uint2(0, 0);
+            if (PART == GGR_PRE_COLOUR && in_range) {
+                // the geometry half has listed it already: its record gets opacity 0 and qmax < 0 — no quadrant cull keeps
+                // it, no pixel takes it — and its radius becomes 0 (no gradient)
+                float4 g1 = splat[2 * o + 1];
+                g1.y = 0.f; g1.w = -1.f;
+                splat[2 * o + 1] = g1;
+                ggr_st(radii + o, 0);
+            }
         }
         if (vis) {
             s0 = make_float4(px, py, con0, con1);

@@ -773,7 +773,11 @@ class GaussianRasterizer(nn.Module):
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, self.raster_settings, aux_precomp)
+                                   cov3D_precomp, self._settings_for_call(), aux_precomp)
+
+    def _settings_for_call(self) -> GaussianRasterizationSettings:
+        """The settings a forward runs with (the `diff_gaussian_rasterization` import shim fills in its SH-cap default here)."""
+        return self.raster_settings
 
 
 def debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_precomp=None, cov3D_precomp=None,

@@ -14,9 +14,12 @@ Reference quirks kept on purpose (drop-in parity):
   * ``scale_invariant`` divides translations / means by ``near`` and covariances by ``near²`` (:66-73);
   * the depth pass feeds depth as a degree-0 SH coefficient, so the rasterizer returns
     ``0.5 + C0·z`` per channel and the result is the channel mean (:256-269);
-  * ``sh_degree = isqrt(d_sh) - 1`` (GGRt: d_sh = 25 → 4); bands 0..min(sh_degree, ``SH_MAX_DEGREE``) are
-    evaluated.  ``SH_MAX_DEGREE`` (``set_sh_max_degree`` / ``DecoderSplattingCUDA(sh_max_degree=…)`` /
-    ``GGR_SH_MAX_DEGREE``) is 4 for THIS layer unless chosen otherwise: the package GGRt's README installs is
+  * ``sh_degree = isqrt(d_sh) - 1`` (GGRt: d_sh = 25 → 4); bands 0..min(sh_degree, cap) are evaluated.  The cap is
+    per call (``sh_max_degree=`` of every function here; ``DecoderSplattingCUDA(sh_max_degree=…)`` per INSTANCE) and
+    otherwise this layer's default ``SH_MAX_DEGREE`` (``set_sh_max_degree`` / ``GGR_SH_MAX_DEGREE``) — the default the
+    ``diff_gaussian_rasterization`` import shim uses too, so that GGRt's own ``cuda_splatting.py`` on the shim and this
+    module render one checkpoint identically (``tests/test_gpu_one_checkpoint_one_answer.py``).  The default
+    is 4 for THIS layer unless chosen otherwise: the package GGRt's README installs is
     pixelSplat's rasterizer fork, GGRt's encoder emits, masks and Wigner-rotates all of bands 0..4
     (``encoder/common/gaussian_adapter.py:45-46,90``) and passes ``sh_degree = 4`` on purpose; 3 reproduces the
     graphdeco / w-depth family (coefficients 16.. ignored); the raw ``GaussianRasterizer`` keeps "not chosen → 3 with
@@ -44,13 +47,23 @@ SH_MAX_DEGREE = int(os.environ.get("GGR_SH_MAX_DEGREE", "4") or 4)
 
 
 def set_sh_max_degree(cap: int) -> int:
-    """Chooses (process-wide, for this call-site layer) the highest SH band the rasterizer evaluates: 3 or 4 (0 = leave it
-    to the raw rasterizer: "not chosen", 3 with one warning).  Returns the previous setting."""
+    """Chooses the DEFAULT (process-wide: this call-site layer and the ``diff_gaussian_rasterization`` import shim) for the
+    highest SH band the rasterizer evaluates: 3 or 4 (0 = leave it to the raw rasterizer: "not chosen", 3 with one warning).
+    A per-call / per-instance ``sh_max_degree`` takes precedence.  Returns the previous setting."""
     global SH_MAX_DEGREE
     if int(cap) not in (0, 3, 4):
         raise ValueError("sh_max_degree must be 3 or 4")
     prev, SH_MAX_DEGREE = SH_MAX_DEGREE, int(cap)
     return prev
+
+
+def resolve_sh_max_degree(cap: Optional[int] = None) -> int:
+    """The cap a call uses: its own explicit choice, else this layer's default as it is NOW."""
+    if cap is None:
+        return SH_MAX_DEGREE
+    if int(cap) not in (0, 3, 4):
+        raise ValueError("sh_max_degree must be 3 or 4")
+    return int(cap)
 
 
 @dataclass
@@ -156,7 +169,7 @@ def adapter_scale_rotation(scales: Tensor, rotations_xyzw: Tensor, c2w_rotations
 
 def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                        gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant=True,
-                       use_sh=True, gaussian_scales=None, gaussian_rotations=None, scissor=None):
+                       use_sh=True, gaussian_scales=None, gaussian_rotations=None, scissor=None, sh_max_degree=None):
     """Everything ``render_cuda`` hands to the rasterizer, batched: a list of
     (GaussianRasterizationSettings, kwargs) per view.  Split out so the golden-vector tests can
     compare it with what the reference's call site produces.
@@ -197,8 +210,8 @@ def boundary_arguments(extrinsics, intrinsics, near, far, image_shape, backgroun
         settings = GaussianRasterizationSettings(
             image_height=h, image_width=w, tanfovx=tan_host[i][0], tanfovy=tan_host[i][1],
             bg=background_color[i], scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i],
-            sh_degree=degree, campos=extrinsics[i, :3, 3], prefiltered=False, sh_max_degree=SH_MAX_DEGREE,
-            **({} if scissor is None else {"scissor": tuple(scissor)}))
+            sh_degree=degree, campos=extrinsics[i, :3, 3], prefiltered=False,
+            sh_max_degree=resolve_sh_max_degree(sh_max_degree), **({} if scissor is None else {"scissor": tuple(scissor)}))
         kwargs = dict(means3D=gaussian_means[i], shs=shs[i] if use_sh else None,
                       colors_precomp=None if use_sh else shs[i, :, 0, :],
                       opacities=gaussian_opacities[i, ..., None])
@@ -231,7 +244,7 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
                 gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
                 gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True,
                 gaussian_scales: Optional[Tensor] = None, gaussian_rotations: Optional[Tensor] = None,
-                scissor=None) -> Tensor:
+                scissor=None, sh_max_degree: Optional[int] = None) -> Tensor:
     """[batch] views → [batch,3,h,w] (reference ``cuda_splatting.py:49-128``).  With
     ``gaussian_covariances=None`` the ellipsoids come as scales + world quaternions (§8f-4).
 
@@ -240,7 +253,7 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
     per crop cell and slices one cell out.  Inside the window the image equals the full render bit for bit."""
     calls = boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                                gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant,
-                               use_sh, gaussian_scales, gaussian_rotations, scissor)
+                               use_sh, gaussian_scales, gaussian_rotations, scissor, sh_max_degree)
     return torch.stack([o[0] for o in _rasterize_views(calls)])
 
 
@@ -284,7 +297,7 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                            gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor,
                            depth_mode: DepthRenderingMode = "depth", scale_invariant: bool = True,
                            use_sh: bool = True, gaussian_scales: Optional[Tensor] = None,
-                           gaussian_rotations: Optional[Tensor] = None):
+                           gaussian_rotations: Optional[Tensor] = None, sh_max_degree: Optional[int] = None):
     """ONE rasterization per view for what the reference obtains from two:
     ``render_cuda`` (colour, :49-128) + ``render_depth_cuda`` (:227-269).
 
@@ -297,7 +310,7 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
     aux = (0.5 + SH_C0 * feat).clamp(min=0.0)
     calls = boundary_arguments(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means,
                                gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities, scale_invariant,
-                               use_sh, gaussian_scales, gaussian_rotations)
+                               use_sh, gaussian_scales, gaussian_rotations, None, sh_max_degree)
     outs = _rasterize_views(calls, aux=aux)
     return torch.stack([o[0] for o in outs]), torch.stack([o[2] for o in outs])
 
@@ -305,7 +318,8 @@ def render_color_and_depth(extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
 def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape,
                        background_color: Tensor, gaussians: Gaussians, view_to_batch,
                        depth_mode: Optional[DepthRenderingMode] = None, scale_invariant: bool = True,
-                       device_camera: bool = True, list_capacity: int = 0, batched: bool = True, scissor=None):
+                       device_camera: bool = True, list_capacity: int = 0, batched: bool = True, scissor=None,
+                       sh_max_degree: Optional[int] = None):
     """The call site with NO torch operation on a Gaussian-sized tensor (SURVEY.md §8 a2 "where time goes"):
 
     * ``device_camera``: view / projection matrices, camera position, tan(fov/2) and 1/near of all views come
@@ -332,6 +346,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     h, w = image_shape
     d_sh = gaussians.harmonics.shape[-1]
     degree = isqrt(d_sh) - 1
+    sh_cap = resolve_sh_max_degree(sh_max_degree)
     ext_orig = extrinsics
     # the per-view camera quantities: one library kernel, everything (incl. tan(fov/2) and 1/near) stays on the
     # device — or, for poses that carry gradients / CPU golden tests, the reference's torch formulation
@@ -376,7 +391,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
             image_height=h, image_width=w, tanfovx=0.0, tanfovy=0.0, bg=background_color[0], scale_modifier=1.0,
             viewmatrix=view[0], projmatrix=full[0], sh_degree=degree, campos=campos[0], prefiltered=False,
             list_capacity=list_capacity * n, sh_channel_major=True, aux_affine=aux_affine,
-            sh_max_degree=SH_MAX_DEGREE, scissor=None if scissor is None else tuple(scissor))
+            sh_max_degree=sh_cap, scissor=None if scissor is None else tuple(scissor))
         kw = dict(cov3D_precomp=gaussians.covariances) if fused_cov else dict(scales=gaussians.scales,
                                                                               rotations=gaussians.rotations)
         col, _, dep = rasterize_views(gaussians.means, gaussians.opacities, view, full, campos, background_color, tf,
@@ -418,7 +433,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
             image_height=h, image_width=w, tanfovx=0.0, tanfovy=0.0, bg=background_color[idx[0]], scale_modifier=1.0,
             viewmatrix=view[idx[0]], projmatrix=full[idx[0]], sh_degree=degree, campos=campos[idx[0]],
             prefiltered=False, list_capacity=list_capacity * len(idx), sh_channel_major=True, aux_affine=aux_affine,
-            sh_max_degree=SH_MAX_DEGREE, scissor=None if scissor is None else tuple(scissor))
+            sh_max_degree=sh_cap, scissor=None if scissor is None else tuple(scissor))
         kw = dict(cov3D_precomp=g_cov[b]) if fused_cov else dict(scales=g_scales[b], rotations=g_rot[b])
         col, _, dep = rasterize_views(g_means[b], g_op[b][..., None], take(view), take(full), take(campos),
                                       take(background_color), tf, settings, shs=g_sh[b], aux_precomp=aux,
@@ -441,7 +456,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
             scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i], sh_degree=degree,
             campos=campos[i], prefiltered=False, list_capacity=list_capacity,
             input_scale=None if scale is None else scale[i:i + 1], sh_channel_major=True, aux_affine=aux_affine,
-            tanfov=None if tanfov is None else tanfov[i], sh_max_degree=SH_MAX_DEGREE,
+            tanfov=None if tanfov is None else tanfov[i], sh_max_degree=sh_cap,
             scissor=None if scissor is None else tuple(scissor))
         means = g_means[b]
         kw = dict(cov3D_precomp=g_cov[b]) if fused_cov else dict(scales=g_scales[b], rotations=g_rot[b])
@@ -465,9 +480,9 @@ class DecoderSplattingCUDA(nn.Module):
                  sh_max_degree: Optional[int] = None):
         super().__init__()
         self.cfg = cfg
-        # 3 / 4: the explicit choice of INTEGRATION.md §7 (process-wide for this module); None leaves it as it is
-        if sh_max_degree is not None:
-            set_sh_max_degree(sh_max_degree)
+        # 3 / 4: the explicit choice of INTEGRATION.md §7, for THIS decoder (two decoders of one process may differ); None =
+        # this layer's default at the time of each call (set_sh_max_degree / GGR_SH_MAX_DEGREE)
+        self.sh_max_degree = None if sh_max_degree is None else resolve_sh_max_degree(sh_max_degree)
         # > 0: sync-free rasterizer forward with per-tile lists of at most this many entries — with the fused
         # inputs the whole decoder call then has no host sync and can be captured in a HIP graph
         # (check ``ggrt_official_amd.last_forward_status()`` for overflow when a sync is affordable)
@@ -505,7 +520,7 @@ class DecoderSplattingCUDA(nn.Module):
             color, depth = render_views_fused(
                 extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(), image_shape, bg,
                 gaussians, [n // v for n in range(b * v)], depth_mode, list_capacity=self.list_capacity,
-                scissor=scissor)
+                scissor=scissor, sh_max_degree=self.sh_max_degree)
             return DecoderOutput(color.reshape(b, v, *color.shape[1:]),
                                  None if depth is None else depth.reshape(b, v, *depth.shape[1:]))
         if depth_mode is not None and self.fused_depth:
@@ -513,12 +528,13 @@ class DecoderSplattingCUDA(nn.Module):
                 extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(), image_shape, bg,
                 self._per_view(gaussians.means, v), self._opt_per_view(gaussians.covariances, v),
                 self._per_view(gaussians.harmonics, v), self._per_view(gaussians.opacities, v), depth_mode,
-                **self._ellipsoids(gaussians, v))
+                sh_max_degree=self.sh_max_degree, **self._ellipsoids(gaussians, v))
             return DecoderOutput(color.reshape(b, v, *color.shape[1:]), depth.reshape(b, v, *depth.shape[1:]))
         color = render_cuda(extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(), far.flatten(),
                             image_shape, bg, self._per_view(gaussians.means, v),
                             self._opt_per_view(gaussians.covariances, v), self._per_view(gaussians.harmonics, v),
-                            self._per_view(gaussians.opacities, v), **self._ellipsoids(gaussians, v))
+                            self._per_view(gaussians.opacities, v), sh_max_degree=self.sh_max_degree,
+                            **self._ellipsoids(gaussians, v))
         color = color.reshape(b, v, *color.shape[1:])
         depth = None if depth_mode is None else self.render_depth(gaussians, extrinsics, intrinsics, near, far,
                                                                   image_shape, depth_mode)

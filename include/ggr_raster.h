@@ -24,6 +24,14 @@
  *
  * Return value: 0 on success, a GGR_E_* code otherwise; ggr_last_error() returns a thread-local
  * message.
+ *
+ * Non-finite inputs (a contract of this build; the reference has none — there a NaN mean is culled by the near-plane test or
+ * not, a NaN covariance reaches `(int)ceil(NaN)`, a NaN colour poisons every pixel it touches): a Gaussian with a NaN or an
+ * infinity in its mean, covariance (scale / rotation), opacity, aux feature... in anything its projected geometry is computed
+ * from, or in an EVALUATED SH coefficient / its precomputed colour, takes no part in the frame — radius 0, no contribution to
+ * any pixel, zero gradient in every one of its inputs; so does one whose screen radius exceeds 2^30 px.  The other Gaussians
+ * render as if it were absent; nothing faults or hangs.  (SH coefficients of bands that are not evaluated are never read.)
+ * A non-finite camera matrix or upstream gradient is the caller's error: it reaches every Gaussian.
  */
 #ifndef GGR_RASTER_H
 #define GGR_RASTER_H

@@ -362,8 +362,17 @@ int64_t ggo_preprocess(int P, int D, int M, const float* means3D, const float* s
         const float mid = 0.5f * (e.a + e.c);
         const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
         const float l1 = mid + sq, l2 = mid - sq;
-        const int rad = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+        const float radf = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
         const float px = ndc2pix(ppx, W), py = ndc2pix(ppy, H);
+        /* NON-FINITE INPUTS — the build's contract (the reference has none: a NaN mean is culled by its `z <= 0.2` test or
+         * not, a NaN covariance reaches `(int)ceil(NaN)`): a Gaussian whose projected geometry, opacity or colour is not
+         * finite — a NaN / Inf in its mean, covariance (scale, rotation), opacity, evaluated SH coefficients or precomputed
+         * colour — takes no part in the frame: radius 0, no list entry, zero gradient.  So does one whose radius exceeds
+         * 2^30 px (the int conversion would overflow).  Same test, same place in csrc/preprocess.hip. */
+        if (!(isfinite(px) && isfinite(py) && isfinite(con[0]) && isfinite(con[1]) && isfinite(con[2]) &&
+              isfinite(opacities[i]) && isfinite(e.a) && isfinite(e.c) && isfinite(pv[2]) && radf < 1073741824.f))
+            continue;
+        const int rad = (int)radf;
         int rmin[2], rmax[2];
         get_rect(px, py, rad, gx, gy, rmin, rmax);
         int area = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
@@ -372,7 +381,7 @@ int64_t ggo_preprocess(int P, int D, int M, const float* means3D, const float* s
             tighten_rect(px, py, e.a, e.c, opacities[i], rmin, rmax);
             area = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
         }
-        if (rect_out) { rect_out[4 * i] = rmin[0]; rect_out[4 * i + 1] = rmin[1]; rect_out[4 * i + 2] = rmax[0]; rect_out[4 * i + 3] = rmax[1]; }
+        int colour_finite = 1;   /* (the contract above, colour part) */
         if (rgb) {
             if (colors_precomp) {
                 for (int k = 0; k < 3; k++) rgb[3 * i + k] = colors_precomp[3 * i + k];
@@ -390,9 +399,16 @@ int64_t ggo_preprocess(int P, int D, int M, const float* means3D, const float* s
                     r += 0.5f;
                     if (clamped) clamped[3 * i + ch] = (r < 0.f);
                     rgb[3 * i + ch] = fmaxf(r, 0.f);
+                    if (!isfinite(r)) colour_finite = 0;
                 }
             }
+            for (int k = 0; k < 3; k++) if (!isfinite(rgb[3 * i + k])) colour_finite = 0;
+            if (!colour_finite) {
+                for (int k = 0; k < 3; k++) { rgb[3 * i + k] = 0.f; if (clamped) clamped[3 * i + k] = 0; }
+                continue;
+            }
         }
+        if (rect_out) { rect_out[4 * i] = rmin[0]; rect_out[4 * i + 1] = rmin[1]; rect_out[4 * i + 2] = rmax[0]; rect_out[4 * i + 3] = rmax[1]; }
         if (depth) depth[i] = pv[2];
         radii[i] = rad;
         if (xy) { xy[2 * i] = px; xy[2 * i + 1] = py; }

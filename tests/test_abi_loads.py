@@ -210,10 +210,23 @@ def test_sh_cap_is_an_explicit_choice(monkeypatch):
     if "GGR_SH_MAX_DEGREE" not in os.environ or os.environ["GGR_SH_MAX_DEGREE"] == "4":
         monkeypatch.delenv("GGR_SH_MAX_DEGREE", raising=False)
         assert importlib.reload(splatting).SH_MAX_DEGREE == 4
+    # a decoder's choice is ITS OWN: it does not move the layer's default, two decoders may differ
     prev = splatting.set_sh_max_degree(4)
     try:
-        assert splatting.SH_MAX_DEGREE == 4
-        splatting.DecoderSplattingCUDA(sh_max_degree=3)
-        assert splatting.SH_MAX_DEGREE == 3
+        d3, d4, dd = (splatting.DecoderSplattingCUDA(sh_max_degree=3), splatting.DecoderSplattingCUDA(sh_max_degree=4),
+                      splatting.DecoderSplattingCUDA())
+        assert splatting.SH_MAX_DEGREE == 4 and (d3.sh_max_degree, d4.sh_max_degree, dd.sh_max_degree) == (3, 4, None)
+        assert splatting.resolve_sh_max_degree(d3.sh_max_degree) == 3 and splatting.resolve_sh_max_degree(None) == 4
+        splatting.set_sh_max_degree(3)
+        assert splatting.resolve_sh_max_degree(dd.sh_max_degree) == 3 and splatting.resolve_sh_max_degree(d4.sh_max_degree) == 4
+        # the import-name shim takes the same default for settings that leave the cap open — and only for those
+        import diff_gaussian_rasterization as shim
+        from ggrt_official_amd.synthetic import make_scene
+        rs = make_scene(4, 16, 16, sh_degree=0).settings()._replace(sh_max_degree=0)
+        assert shim.GaussianRasterizer(rs)._settings_for_call().sh_max_degree == 3
+        splatting.set_sh_max_degree(4)
+        assert shim.GaussianRasterizer(rs)._settings_for_call().sh_max_degree == 4
+        assert shim.GaussianRasterizer(rs._replace(sh_max_degree=3))._settings_for_call().sh_max_degree == 3
+        assert rasterizer.GaussianRasterizer(rs)._settings_for_call().sh_max_degree == 0   # the raw rasterizer: not chosen
     finally:
         splatting.set_sh_max_degree(prev)
