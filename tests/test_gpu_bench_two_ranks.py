@@ -49,6 +49,12 @@ def test_bench_two_ranks_share_one_gpu(mode):
     assert rec["exchange_bound"] == (mg["allreduce_ms"] > mg["raster_ms"])
     # … and every rank reported its device (here both ranks share GPU 0 on purpose: `--device 0`)
     assert [r["rank"] for r in rec["ranks"]] == [0, 1] and all(r["index"] == 0 for r in rec["ranks"])
+    # the N > 1 record says what its figures mean before anybody computes an efficiency from `value`
+    assert rec["scaling_basis"] == "raster_only_mpix_s" and "value_note" in rec
+    assert rec["ranks_on_distinct_gpus"] is False           # (this dry run shares one GPU, and the record says so)
+    sweep0 = [e for e in mg["grad_buffer_sweep"] if e["floats"] == 0][0]
+    assert rec["value_raster_plus_camera_grad"] == sweep0["mpix_s"] > 0
+    assert rec["ms_per_step_raster_plus_camera_grad"] == sweep0["overlapped_ms_per_step"]
 
 
 @pytest.mark.timeout(900)
