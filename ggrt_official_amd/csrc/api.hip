@@ -370,19 +370,27 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         if (depth_sort == GGR_DEPTH_SORT_AUTO && *e)
             depth_sort = (*e == 'g' || *e == '1') ? GGR_DEPTH_SORT_GLOBAL : (*e == 'p' || *e == '2') ? GGR_DEPTH_SORT_PER_TILE : depth_sort;
     }
-    // AUTO = the global sort: at C3 the two forms measure the same (forward 0.404-0.409 ms per tile against 0.409 global,
-    // NOTES r6) — the per-tile sort is N entries' worth of LDS and vector work where the global sort is mostly waiting, and
-    // the colour kernel that hides beside the global sort finds no such partner per tile — so the default stays with the
-    // form that has no list-length limit
-    if (depth_sort == GGR_DEPTH_SORT_AUTO) depth_sort = GGR_DEPTH_SORT_GLOBAL;
+    // AUTO: per tile where its lists are short — at most 256 (view, Gaussian) pairs per tile on average (a 1080p frame with 1 M
+    // Gaussians: 123; its longest list: 1 100 entries) and, when the caller knows, a longest list of at most 4096 entries — and
+    // the call has a read-back to fall back with.  Measured (NOTES r6, fwd+bwd): C3 0.78 against 0.80 ms, 200 k Gaussians at
+    // 504 × 378 0.22 against 0.30; GGRt's own shapes — 1 M pixel-aligned Gaussians on 660 tiles, every list 4 000-6 000 entries —
+    // 0.77 against 0.69: those keep the global sort.
+    const uint32_t len_hint_in = out->max_list_len > 0 ? (uint32_t)out->max_list_len : 0u;
+    if (depth_sort == GGR_DEPTH_SORT_AUTO)
+        depth_sort = ((!sync_free || hinted) && (size_t)P <= 256 * tiles && len_hint_in <= 4096) ? GGR_DEPTH_SORT_PER_TILE
+                                                                                             : GGR_DEPTH_SORT_GLOBAL;
     bool per_tile = depth_sort == GGR_DEPTH_SORT_PER_TILE && P > 0 && tiles > 0;
     out->depth_sort_used = per_tile ? GGR_DEPTH_SORT_PER_TILE : GGR_DEPTH_SORT_GLOBAL;
-    const uint32_t len_hint = out->max_list_len > 0 ? (uint32_t)out->max_list_len : 0u;
+    const uint32_t len_hint = len_hint_in;
     out->max_list_len = -1;
 
     const ggr::TileListPlan plan = ggr::plan_tile_lists((size_t)P, tiles);
-    void* work = alloc(alloc_ctx, plan.work_bytes);  // 1st allocator call: transient work area
+    // (per tile: the id-order scatter writes (id, key) entries that the per-tile sort reads — 8 B per list entry of scratch.
+    //  With the list buffer's size known up front it rides on the work area; in the exact mode on the list buffer's tail)
+    const size_t pairs_up_front = (per_tile && sync_free) ? ggr_pair_list_bytes((size_t)out->binning_capacity) : 0;
+    void* work = alloc(alloc_ctx, plan.work_bytes + pairs_up_front);  // 1st allocator call: transient work area
     if (!work) return fail(GGR_E_ALLOC, "work-area allocator returned NULL");
+    uint2* pair_list = pairs_up_front ? (uint2*)((char*)work + plan.work_bytes) : nullptr;
     uint2* rect_sorted = nullptr;
     uint32_t *totals_area = nullptr, totals_words = 0;   // the tile-list builder's per-tile / per-group totals (start from zero)
     ggr::tile_list_gather_targets(plan, work, tiles, &rect_sorted, &totals_area, &totals_words);
@@ -486,15 +494,22 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     auto tile_sort_upto = [&](uint32_t upto) {
         upto = std::min<uint32_t>(upto, GGR_TSORT_CAP_LARGE);
         if (upto <= sorted_upto) return;
-        if (sorted_upto < GGR_TSORT_CAP_SMALL)
-            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, g.keys_a, sorted_upto, std::min<uint32_t>(upto, GGR_TSORT_CAP_SMALL), s);
-        if (upto > GGR_TSORT_CAP_SMALL)
-            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, g.keys_a, std::max<uint32_t>(sorted_upto, GGR_TSORT_CAP_SMALL), upto, s);
+        // One launch when a class with at least four workgroups per CU covers everything (lists up to 3072 entries: a few tiles
+        // just beyond 2048 do not pay for a launch of their own); otherwise the lists up to 2048 in their class and the
+        // longer ones in theirs.  The launch with the largest class also copies the ids of lists beyond it: unsorted, but
+        // nothing uninitialised is left for the blend.
+        const uint32_t one_launch = 3072;
+        if (upto <= one_launch || sorted_upto >= GGR_TSORT_CAP_SMALL) {
+            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, pair_list, sorted_upto, upto, s, 1);
+        } else {
+            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, pair_list, sorted_upto, GGR_TSORT_CAP_SMALL, s, 0);
+            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, pair_list, GGR_TSORT_CAP_SMALL, upto, s, 1);
+        }
         sorted_upto = upto;
     };
     auto scatter_pass = [&](bool id_order, uint32_t cap_entries, uint32_t expect_longest) {
         ggr::launch_tile_list_scatter(plan, (size_t)P, tiles, gx, id_order ? nullptr : order, g.rect, work, point_list,
-                                      cap_entries, s);
+                                      cap_entries, s, id_order ? g.keys_a : nullptr, id_order ? pair_list : nullptr);
         tm.mark(GGR_FWD_TILE_SCATTER);
         (void)fork_colour_at(2);
         sorted_upto = 0;
@@ -576,10 +591,12 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         else { out->num_rendered = 0; out->max_list_len = 0; }
         tm.mark(GGR_FWD_TILE_COUNT);
         if (per_tile && longest > GGR_TSORT_CAP_LARGE) rebuild_global();
-        void* bin_mem = alloc(alloc_ctx, ggr_point_list_bytes(num_rendered));  // 2nd call: kept for backward
+        // 2nd call: kept for backward (per tile: + the (id, key) scratch on its tail)
+        void* bin_mem = alloc(alloc_ctx, ggr_point_list_bytes(num_rendered) + (per_tile ? ggr_pair_list_bytes(num_rendered) : 0));
         if (!bin_mem) return fail(GGR_E_ALLOC, "binning allocator returned NULL");
         out->binning_buffer = bin_mem;
         point_list = (uint32_t*)bin_mem;
+        if (per_tile) pair_list = (uint2*)((char*)bin_mem + ggr_point_list_bytes(num_rendered));
     } else {
         out->num_rendered = -1;  // known on the device only: ggr_forward_status reads it (and the overflow flag)
         tm.mark(GGR_FWD_TILE_COUNT);
@@ -612,9 +629,11 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
             // itself: the exact buffer (the allocator's second call, as in the exact mode), the tile ranges, the scatter and the blend once
             // more — 0.21 ms at C3 instead of a whole second forward (round 5; until then GGR_E_CAPACITY and the host
             // repeated the call: 1.25 instead of 0.90 ms).  capacity_is_hint = 2 tells the host that this happened.
-            void* bin_mem = alloc ? alloc(alloc_ctx, ggr_point_list_bytes(num_rendered)) : nullptr;
+            void* bin_mem = alloc ? alloc(alloc_ctx, ggr_point_list_bytes(num_rendered) +
+                                                         ((per_tile && !too_long) ? ggr_pair_list_bytes(num_rendered) : 0)) : nullptr;
             if (!bin_mem)
                 return fail(GGR_E_CAPACITY, "num_rendered %u exceeds the hinted capacity %u", num_rendered, capacity);
+            if (per_tile && !too_long) pair_list = (uint2*)((char*)bin_mem + ggr_point_list_bytes(num_rendered));
             out->binning_buffer = bin_mem;
             out->binning_capacity = (int64_t)num_rendered;
             out->capacity_is_hint = 2;

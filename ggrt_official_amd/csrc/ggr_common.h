@@ -201,6 +201,8 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P, size_t segments = 
 }
 
 static inline size_t ggr_point_list_bytes(size_t N) { return ggr_align((N ? N : 1) * 4); }
+// bytes of the (id, key) entries the id-order scatter writes for the per-tile depth sort (tile_sort.hip): scratch of one forward
+static inline size_t ggr_pair_list_bytes(size_t N) { return ggr_align((N ? N : 1) * 8); }
 
 // Depth segments of the blend backward (blend_bwd.hip).  An image with few tiles cannot fill 256 CUs with one
 // workgroup per tile (480×352 = 660 tiles = 2.6 waves per SIMD: the backward ran at half the per-entry rate of
@@ -401,12 +403,15 @@ void tile_list_gather_targets(const TileListPlan& pl, void* work, size_t T, uint
 void launch_tile_list_ranges(const TileListPlan& pl, size_t T, void* work, uint2* ranges, hipStream_t s);
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                               const uint2* rect, const void* work, uint32_t* point_list, uint32_t capacity,
-                              hipStream_t s);
+                              hipStream_t s, const uint32_t* keys = nullptr /*id order: the Gaussians' depth keys …*/,
+                              uint2* pair_list = nullptr /*… and where the (id, key) entries go instead of point_list*/);
 
 // tile_sort.hip: stable sort of every tile's list by the Gaussians' depth keys — lists with min_len < length <= max_len
 // (others are left alone; max_len <= GGR_TSORT_CAP_LARGE)
-void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint32_t* keys, uint32_t min_len,
-                            uint32_t max_len, hipStream_t s);
+void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* pair_list, uint32_t min_len,
+                            uint32_t max_len, hipStream_t s, int copy_longer /*1: lists longer than max_len are copied out
+                            unsorted (the last launch of a forward: the blend must find valid ids)*/);
+
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,
                       const float4* colour,

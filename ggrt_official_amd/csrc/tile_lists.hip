@@ -279,12 +279,17 @@ bin_group_prefix_kernel(uint32_t* __restrict__ wsum, uint32_t T, uint32_t nw, ui
 }
 
 // ---- K3 ------------------------------------------------------------------------------------------
+// PAIRS (id order, for the per-tile depth sort — tile_sort.hip): the chunk is a run of Gaussian ids (no `order`), and every
+// list entry is written as (id, depth key) into `pair_list` — the sort then reads a tile's entries in one coalesced sweep
+// instead of gathering a key per id (7.9 M random 4-B reads at C3: 16 of its 68 µs)
+template <bool PAIRS>
 __global__ void __launch_bounds__(64)
 bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect, uint32_t T,
                    uint32_t band_tiles, uint32_t grid_x, const uint32_t* __restrict__ table,
                    const uint32_t* __restrict__ wsum /*[workgroup of K1][T]: absolute base of the chunk's count workgroup*/,
                    uint32_t* __restrict__ point_list, uint32_t capacity /*entries in point_list; ~0u = exact size*/,
-                   uint32_t nbands_total) {
+                   uint32_t nbands_total, const uint32_t* __restrict__ keys /*PAIRS: depth key per Gaussian*/,
+                   uint2* __restrict__ pair_list /*PAIRS: [capacity] (id, key) instead of point_list*/) {
     // LDS: cursor[band_tiles] (next free list position per tile of the band) + the compacted list of this
     // chunk's Gaussians that touch the band: id, first tile relative to the band, rect width, first slot;
     // mark[64]: scratch of one step
@@ -300,6 +305,7 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
     uint32_t* l_wh = l_xy + HALF;                 // of LDS round trips (1 / 2 / 4 parts at C3: 0.092 / 0.075 / 0.072 ms)
     uint32_t* l_pre = l_wh + HALF;
     uint32_t* mark = l_pre + HALF;
+    uint32_t* l_key = mark + 64;                  // (PAIRS only: the launch sizes the LDS for it)
     // XCD-affine work order.  Workgroup b runs on XCD b mod 8, and every XCD has its own L2: when the waves that
     // append to one tile list sit on different XCDs, each L2 writes back its own partial copy of every 64-B list
     // line (measured: 366 MB written for 43 MB of ids).  So a band is given to ONE XCD — band = xcd + 8·k — and the
@@ -316,7 +322,7 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
     // loops, 52 % of a wave's life was spent in ≈19 serial 1–2 µs round trips): the band's start positions
     // (≤ 512 tiles = 8 per lane) and the chunk's 1024 (id, rect) pairs (16 per lane).
     constexpr int NB = GGR_BIN_CHUNK / 64;
-    uint32_t cur0[8], gq[NB];
+    uint32_t cur0[8], gq[NB];   // (PAIRS: gq holds the KEYS — the id of position i is i)
     uint2 rq[NB];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -326,7 +332,7 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
 #pragma unroll
     for (int q = 0; q < NB; q++) {
         const uint32_t i = base + 64 * q + lane;
-        gq[q] = i < end ? (order ? order[i] : i) : 0u;   // (order == NULL: the chunks are walked in id order — tile_sort.hip)
+        gq[q] = i < end ? (PAIRS ? keys[i] : order[i]) : 0u;
         rq[q] = i < end ? rect[i] : make_uint2(0u, 0u);  // rect is already in walk order (rect_sorted, or the rects themselves)
     }
 #pragma unroll
@@ -344,7 +350,7 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
 #pragma unroll
     for (int qq = 0; qq < NB / GGR_SCATTER_PARTS; qq++) {
         const int q = half * (NB / GGR_SCATTER_PARTS) + qq;
-        const uint32_t g = gq[q];
+        const uint32_t g = PAIRS ? base + 64u * (uint32_t)q + lane : gq[q];
         uint32_t x0, y0, x1, y1;
         unpack_rect(rq[q], x0, y0, x1, y1);
         const uint32_t ya = max(y0, row_lo), yb = min(y1, row_hi);
@@ -356,6 +362,7 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
         if (hit) {
             const uint32_t p = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
             l_id[p] = g;
+            if (PAIRS) l_key[p] = gq[q];
             l_xy[p] = ya * grid_x + x0 - lo;  // first tile of the clipped rect RELATIVE to the band (may wrap below 0)
             l_wh[p] = w;
             l_pre[p] = S + incl - n;
@@ -418,7 +425,8 @@ bin_scatter_kernel(uint32_t P, const uint32_t* __restrict__ order, const uint2* 
         const int leader = in ? (int)__builtin_ctzll(m) : (int)lane;
         p0 = (uint32_t)__shfl((int)p0, leader);
         const uint32_t pos = p0 + before;
-        if (in && pos < capacity) point_list[pos] = cg;
+        if (PAIRS) { if (in && pos < capacity) pair_list[pos] = make_uint2(cg, l_key[k]); }
+        else if (in && pos < capacity) point_list[pos] = cg;
     }
     // the next half's list overwrites this one: order this half's LDS reads before those writes
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -557,15 +565,21 @@ void launch_tile_list_ranges(const TileListPlan& pl, size_t T, void* work, uint2
 
 void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int grid_x, const uint32_t* order,
                               const uint2* rect, const void* work, uint32_t* point_list, uint32_t capacity,
-                              hipStream_t s) {
+                              hipStream_t s, const uint32_t* keys, uint2* pair_list) {
     if (T == 0 || P == 0) return;
     const WorkArea w = carve_work(pl, (void*)work, T);
     const uint2* rect_walk = order ? w.rect_sorted : rect;   // (order == NULL: id order, the rects as preprocess_fwd left them)
-    const size_t lds = (3 * (size_t)pl.sband_tiles + 4 * (GGR_BIN_CHUNK / GGR_SCATTER_PARTS) + 64) * 4;
+    const bool pairs = order == nullptr;
+    const size_t lds = (3 * (size_t)pl.sband_tiles + (pairs ? 5 : 4) * (GGR_BIN_CHUNK / GGR_SCATTER_PARTS) + 64) * 4;
     const uint32_t bands8 = (pl.nsbands + 7u) / 8u;
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(pl.nchunks * bands8 * 8u), dim3(64), lds, s, (uint32_t)P, order,
-                       rect_walk, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, w.wsum, point_list, capacity,
-                       pl.nsbands);
+    if (pairs)
+        hipLaunchKernelGGL(bin_scatter_kernel<true>, dim3(pl.nchunks * bands8 * 8u), dim3(64), lds, s, (uint32_t)P, order,
+                           rect_walk, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, w.wsum, point_list, capacity,
+                           pl.nsbands, keys, pair_list);
+    else
+        hipLaunchKernelGGL(bin_scatter_kernel<false>, dim3(pl.nchunks * bands8 * 8u), dim3(64), lds, s, (uint32_t)P, order,
+                           rect_walk, (uint32_t)T, pl.sband_tiles, (uint32_t)grid_x, w.table, w.wsum, point_list, capacity,
+                           pl.nsbands, (const uint32_t*)nullptr, (uint2*)nullptr);
 }
 
 }  // namespace ggr

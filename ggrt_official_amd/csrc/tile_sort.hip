@@ -33,7 +33,7 @@
 //       rank     the lowest lane of each digit group takes the group's positions with ONE ds_add_rtn on the base (distinct
 //                addresses within an instruction; rounds in program order ⇒ stable), the others get it by ds_bpermute;
 //       move     entries to their positions in the exchange buffer, barrier, every thread reads its positions back.
-//     The last step writes the ids straight into the list (in place: the list was read completely before).
+//     The last step writes the ids straight into the tile's list.
 #include "ggr_common.h"
 #include <algorithm>
 
@@ -51,9 +51,15 @@ namespace ggr {
 // registers: the small class is held to 80 per lane (6 workgroups per CU: the kernel waits on LDS and on two global round
 // trips per tile, and what hides them is resident workgroups); the large class keeps its 32 rounds in registers as it can
 #ifndef GGR_TSORT_WAVES_PER_EU
-#define GGR_TSORT_WAVES_PER_EU 6
+#define GGR_TSORT_WAVES_PER_EU 8
 #endif
-#define GGR_TSORT_WAVES(Q_) __attribute__((amdgpu_waves_per_eu((Q_) <= 8 ? GGR_TSORT_WAVES_PER_EU : 1, 8)))
+#define GGR_TSORT_WAVES(Q_) __attribute__((amdgpu_waves_per_eu((Q_) <= 8 ? GGR_TSORT_WAVES_PER_EU : (Q_) <= 12 ? 4 : (Q_) <= 16 ? 3 : 1, 8)))
+
+// LDS words of a workgroup whose exchange buffer holds `cap` entries (see the kernel's layout)
+__host__ __device__ static inline uint32_t tsort_lds_words(uint32_t cap) {
+    const uint32_t r1 = 2u * cap + 2u * GGR_TSORT_BINS, r2 = cap + 4u * GGR_TSORT_BINS + 512u;
+    return ((r1 > r2 ? r1 : r2) + 16u + 3u) & ~3u;
+}
 
 namespace {
 
@@ -82,21 +88,40 @@ __device__ __forceinline__ void ts_order() {
 template <int Q>
 __global__ void __launch_bounds__(256) GGR_TSORT_WAVES(Q)
 tile_depth_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
-                       const uint32_t* __restrict__ keys, uint32_t min_len, uint32_t cap) {
+                       const uint2* __restrict__ pair_list, uint32_t min_len, uint32_t cap, int copy_longer) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    // [exchange: cap words] [cnt: 4 × BINS] [same: 4 × 64 × u64] [red: 16]
-    uint32_t* ex = lds;
-    uint32_t* cnt = ex + cap;
+    // LDS (words), the two routes below laid over each other:
+    //   route 1  [ex: cap × (id, key) = 2·cap] [fill: BINS] [starts: BINS]
+    //   route 2  [exw: cap]                    [cnt: 4 × BINS] [same: 4 × 64 × u64 = 512]
+    //   [red: 16] behind the longer of the two
+    uint2* ex = reinterpret_cast<uint2*>(lds);
+    uint32_t* fill = lds + 2 * cap;                  // [BINS]: counts, then the buckets' fill pointers (= their ends at last)
+    uint32_t* starts = fill + GGR_TSORT_BINS;        // [BINS]: the buckets' first positions
+    uint32_t* exw = lds;                             // (route 2 moves ids and keys one after the other through its words)
+    uint32_t* cnt = lds + cap;
     unsigned long long* same = reinterpret_cast<unsigned long long*>(cnt + 4 * GGR_TSORT_BINS);
-    uint32_t* red = reinterpret_cast<uint32_t*>(same + 4 * 64);
+    uint32_t* red = lds + tsort_lds_words(cap) - 16;
 
     const uint32_t tile = blockIdx.x;
     if (tile >= T) return;
     const uint2 range = ranges[tile];
     const uint32_t n = range.y - range.x;
-    if (n < 2u || n <= min_len || n > cap) return;   // (uniform: before any barrier)
+    if (n <= min_len) return;   // (uniform: before any barrier; another launch's class)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t* list = point_list + range.x;
+    const uint2* pairs = pair_list + range.x;
+    if (n > cap) {
+        // longer than anything this launch sorts.  The last launch of a forward leaves such a list UNSORTED BUT VALID (ids in
+        // id order): the host learns the frame's longest list behind the blend and then sorts it and blends again — until
+        // then the blend must not find uninitialised ids
+        if (copy_longer)
+            for (uint32_t i = tid; i < n; i += 256) list[i] = pairs[i].x;
+        return;
+    }
+    if (n < 2u) {   // (nothing to sort, but the list must hold the id)
+        if (n == 1u && tid == 0) list[0] = pairs[0].x;
+        return;
+    }
     const uint32_t q = (n + 255u) >> 8;            // rounds per wave in use (≤ Q)
     const uint32_t p_lo = wave * q * 64u + lane;   // this thread's position in round r: p_lo + 64·r
 
@@ -112,13 +137,12 @@ tile_depth_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* _
             }                                                             \
         }
 
-    // ---- load: ids (coalesced), keys (gathered: 4 MB per million Gaussians, L2-resident), the bits that differ ----
+    // ---- load: the (id, key) entries as the id-order scatter wrote them (one coalesced sweep), the bits that differ ----
     uint32_t id[Q], ky[Q];
     bool valid[Q];
 #pragma unroll
     for (int r = 0; r < Q; r++) { id[r] = 0u; ky[r] = 0u; valid[r] = (uint32_t)r < q && p_lo + 64u * r < n; }
-    TS_GROUPS({ id[r] = list[min(p_lo + 64u * r, n - 1u)]; })
-    TS_GROUPS({ ky[r] = keys[id[r]]; })
+    TS_GROUPS({ const uint2 e = pairs[min(p_lo + 64u * r, n - 1u)]; id[r] = e.x; ky[r] = e.y; })
     uint32_t k_or = 0u, k_and = 0xFFFFFFFFu;
 #pragma unroll
     for (int r = 0; r < Q; r++)
@@ -128,22 +152,96 @@ tile_depth_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* _
         k_or |= (uint32_t)__shfl_xor((int)k_or, off);
         k_and &= (uint32_t)__shfl_xor((int)k_and, off);
     }
-    uint32_t* my_cnt = cnt + wave * GGR_TSORT_BINS;
-    unsigned long long* my_same = same + wave * 64;
-    for (uint32_t d = lane; d < GGR_TSORT_BINS; d += 64) my_cnt[d] = 0u;
-    my_same[lane] = 0ull;
+    for (uint32_t d = tid; d < GGR_TSORT_BINS; d += 256) fill[d] = 0u;
     if (lane == 0) { red[wave] = k_or; red[4 + wave] = k_and; }
     __syncthreads();
     const uint32_t diff = (red[0] | red[1] | red[2] | red[3]) ^ (red[4] & red[5] & red[6] & red[7]);
-    if (diff == 0u) return;   // every key equal: the list is in id order already
+    if (diff == 0u) {   // every key equal: the entries are in id order already
+        TS_GROUPS({ if (valid[r]) list[p_lo + 64u * r] = id[r]; })
+        return;
+    }
     const uint32_t nbits = 32u - (uint32_t)__builtin_clz(diff);
-    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
+
+    // ---- route 1: the entries into the buckets of their top digit in ANY order, then ranked by (key, id) inside the bucket ----
+    // The (key, id) order is total — ids are unique — so nothing here depends on the order in which the entries arrive or in
+    // which the LDS serves conflicting atomics: one shared histogram (an order-free ds_add per entry), a scan over the digits,
+    // one ds_add_rtn per entry on its bucket's fill pointer (whatever it returns is a free slot of the bucket), and every entry
+    // counts the members of its bucket that precede it: one 64-bit compare per member, (key << 32 | id) as the exchange
+    // buffer holds it.  No per-wave counters, no lane matching, no ballots.
+    {
+        const uint32_t top_bits = min(nbits, (uint32_t)GGR_TSORT_BITS), top_shift = nbits - top_bits;
+        const uint32_t bins = 1u << top_bits, dmask = bins - 1u;
+        TS_GROUPS({ if (valid[r]) atomicAdd(&fill[(ky[r] >> top_shift) & dmask], 1u); })
+        __syncthreads();
+        uint32_t c[GGR_TSORT_DPT], tot = 0u, big = 0u;
+#pragma unroll
+        for (int j = 0; j < GGR_TSORT_DPT; j++) {
+            const uint32_t d = tid * GGR_TSORT_DPT + j;
+            c[j] = d < bins ? fill[d] : 0u;
+            tot += c[j];
+            big = max(big, c[j]);
+        }
+        const uint32_t incl = ts_wave_scan_add(tot);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, off));
+        if (lane == 63u) { red[8 + wave] = incl; red[12 + wave] = big; }
+        __syncthreads();
+        uint32_t run = incl - tot;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) run += w < wave ? red[8 + w] : 0u;
+        const uint32_t longest = max(max(red[12], red[13]), max(red[14], red[15]));
+        if (longest <= GGR_TSORT_RANK_MAX) {   // (uniform)
+#pragma unroll
+            for (int j = 0; j < GGR_TSORT_DPT; j++) {
+                const uint32_t d = tid * GGR_TSORT_DPT + j;
+                if (d < bins) { fill[d] = run; starts[d] = run; }
+                run += c[j];
+            }
+            __syncthreads();
+            uint32_t pos[Q];
+#pragma unroll
+            for (int r = 0; r < Q; r++) pos[r] = 0u;
+            TS_GROUPS({ if (valid[r]) pos[r] = atomicAdd(&fill[(ky[r] >> top_shift) & dmask], 1u); })
+            TS_GROUPS({ if (valid[r]) ex[pos[r]] = make_uint2(id[r], ky[r]); })
+            __syncthreads();   // (every entry is in its bucket; fill[d] = end of bucket d)
+            const unsigned long long* ex64 = reinterpret_cast<const unsigned long long*>(ex);
+#pragma unroll
+            for (int g_ = 0; g_ < Q / 4; g_++)
+                if ((uint32_t)(4 * g_) < q) {
+                    uint32_t bs[4], be[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t d = (ky[4 * g_ + u] >> top_shift) & dmask;
+                        bs[u] = starts[d];
+                        be[u] = fill[d];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int r = 4 * g_ + u;
+                        const unsigned long long mine = ((unsigned long long)ky[r] << 32) | id[r];
+                        uint32_t rank = 0u;
+                        if (valid[r])
+                            for (uint32_t j = bs[u]; j < be[u]; j++) rank += ex64[j] < mine ? 1u : 0u;
+                        if (valid[r]) list[bs[u] + rank] = id[r];
+                    }
+                }
+            return;
+        }
+    }
+    // ---- route 2 (a bucket too large to rank by counting — depths clustered in few buckets): stable LSD passes over evenly
+    // split digits.  It relies on the entries arriving in id order (the id-order scatter is stable): equal keys keep it.
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint32_t p0[Q];
+    uint32_t* my_cnt = cnt + wave * GGR_TSORT_BINS;
+    unsigned long long* my_same = same + wave * 64;
+    __syncthreads();       // (route 1's counters and this route's lie over each other: every thread is done with the former)
+    my_same[lane] = 0ull;
     // One stable counting pass on the digit (key >> shift) & (2^bits − 1): leaves every entry's position in p0[]
     // (valid lanes) and `longest` = the largest bucket.  `cnt` must be zero on entry; on exit cnt[3·BINS + d] = end of bucket d
     // once every wave has ranked (barrier).
-    uint32_t p0[Q];
     uint32_t longest = 0u;
+    (void)longest;
     auto counting_pass = [&](uint32_t shift, uint32_t bits) {
         const uint32_t bins = 1u << bits, dmask = bins - 1u;
 #define TS_DIGIT(r_) ((ky[r_] >> shift) & dmask)   // (recomputed where it is needed: a register per round less)
@@ -233,89 +331,50 @@ tile_depth_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* _
         TS_GROUPS({ p0[r] = (uint32_t)__shfl((int)p0[r], (int)((info[r] >> 8) & 0xFFu)) + (info[r] & 0xFFu); })
 #undef TS_DIGIT
     };
-
-    // ---- route 1: one pass on the top digit, then rank inside the buckets --------------------------------------------
-    const uint32_t top_bits = min(nbits, (uint32_t)GGR_TSORT_BITS), top_shift = nbits - top_bits;
-    counting_pass(top_shift, top_bits);
-    if (top_shift == 0u) {   // the digit was the whole key: done
-        TS_GROUPS({ if (valid[r]) list[p0[r]] = id[r]; })
-        return;
-    }
-    if (longest <= GGR_TSORT_RANK_MAX) {
-        // (only the KEYS travel: an entry stays in its thread's registers and is ranked where it is)
-        TS_GROUPS({ if (valid[r]) ex[p0[r]] = ky[r]; })
-        __syncthreads();   // (every wave has ranked: cnt[3][d] = end of bucket d)
-        const uint32_t* ends = cnt + 3 * GGR_TSORT_BINS;
-        const uint32_t top_mask = (1u << top_bits) - 1u;
-#pragma unroll
-        for (int g_ = 0; g_ < Q / 4; g_++)
-            if ((uint32_t)(4 * g_) < q) {
-                uint32_t bs[4], be[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t d = (ky[4 * g_ + u] >> top_shift) & top_mask;
-                    be[u] = ends[d];
-                    bs[u] = d ? ends[d - 1u] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int r = 4 * g_ + u;
-                    // members in front of this one in (key, position) order: positions inside a bucket are in id order
-                    // (the pass was stable)
-                    // — one 64-bit compare of (key, position) per member
-                    uint32_t rank = 0u;
-                    const unsigned long long mine = ((unsigned long long)ky[r] << 32) | p0[r];
-                    if (valid[r])
-                        for (uint32_t j = bs[u]; j < be[u]; j++)
-                            rank += ((((unsigned long long)ex[j]) << 32 | j) < mine) ? 1u : 0u;
-                    if (valid[r]) list[bs[u] + rank] = id[r];
-                }
-            }
-        return;
-    }
-    // ---- route 2 (clustered depths): LSD passes over evenly split digits ----------------------------------------------
     const uint32_t npass = (nbits + GGR_TSORT_BITS - 1) / GGR_TSORT_BITS;
     const uint32_t bits = (nbits + npass - 1) / npass;
     for (uint32_t pass = 0; pass < npass; pass++) {
         // the wave's counters back to zero (its own ranking is behind it: in-order LDS; the scan of the pass that wrote them
         // lies behind a barrier)
         for (uint32_t d = lane; d < GGR_TSORT_BINS; d += 64) my_cnt[d] = 0u;
-        if (pass == 0) __syncthreads();   // (route 1's scan wrote EVERY wave's counters)
         counting_pass(pass * bits, bits);
         if (pass + 1 == npass) {
             TS_GROUPS({ if (valid[r]) list[p0[r]] = id[r]; })
             break;
         }
         // the exchange buffer holds one word per entry: the ids first, then the keys
-        TS_GROUPS({ if (valid[r]) ex[p0[r]] = id[r]; })
+        TS_GROUPS({ if (valid[r]) exw[p0[r]] = id[r]; })
         __syncthreads();
-        TS_GROUPS({ id[r] = ex[min(p_lo + 64u * r, n - 1u)]; })
+        TS_GROUPS({ id[r] = exw[min(p_lo + 64u * r, n - 1u)]; })
         __syncthreads();
-        TS_GROUPS({ if (valid[r]) ex[p0[r]] = ky[r]; })
+        TS_GROUPS({ if (valid[r]) exw[p0[r]] = ky[r]; })
         __syncthreads();
-        TS_GROUPS({ ky[r] = ex[min(p_lo + 64u * r, n - 1u)]; })
+        TS_GROUPS({ ky[r] = exw[min(p_lo + 64u * r, n - 1u)]; })
         // (the next pass's exchange writes come behind two more barriers: every thread has read its entries by then)
     }
 #undef TS_GROUPS
 }
 
 template <int Q>
-static void launch_tsort_class(size_t T, const uint2* ranges, uint32_t* point_list, const uint32_t* keys, uint32_t min_len,
-                               uint32_t cap, hipStream_t s) {
-    const size_t lds = (size_t)cap * 4 + 4 * GGR_TSORT_BINS * 4 + 4 * 64 * 8 + 64;
+static void launch_tsort_class(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* keys, uint32_t min_len,
+                               uint32_t cap, int copy_longer, hipStream_t s) {
+    const size_t lds = (size_t)tsort_lds_words(cap) * 4;
     if (lds > 64 * 1024)   // (a workgroup may take the CU's whole 160 KB, but beyond 64 KB it has to be asked for)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_depth_sort_kernel<Q>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(tile_depth_sort_kernel<Q>, dim3((unsigned)T), dim3(256), lds, s, (uint32_t)T, ranges, point_list, keys,
-                       min_len, cap);
+                       min_len, cap, copy_longer);
 }
 
-void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint32_t* keys, uint32_t min_len,
-                            uint32_t max_len, hipStream_t s) {
-    if (T == 0 || max_len < 2u || max_len <= min_len) return;
-    const uint32_t cap = (max_len + 255u) & ~255u;   // (the exchange buffer: what the longest list of the launch needs)
-    if (max_len <= GGR_TSORT_CAP_SMALL) launch_tsort_class<GGR_TSORT_CAP_SMALL / 256>(T, ranges, point_list, keys, min_len, cap, s);
-    else launch_tsort_class<GGR_TSORT_CAP_LARGE / 256>(T, ranges, point_list, keys, min_len, std::min<uint32_t>(cap, GGR_TSORT_CAP_LARGE), s);
+void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* keys, uint32_t min_len,
+                            uint32_t max_len, hipStream_t s, int copy_longer) {
+    if (T == 0 || max_len == 0u || max_len <= min_len) return;   // (a list of ONE entry is still copied out of the pairs)
+    const uint32_t cap = std::min<uint32_t>((max_len + 255u) & ~255u, GGR_TSORT_CAP_LARGE);   // the exchange buffer of the launch
+    // the class = rounds per wave the registers hold: 8 (lists up to 2048: 6 workgroups per CU), 12 (3072), 16 (4096), 32 (8192)
+    if (cap <= 2048) launch_tsort_class<8>(T, ranges, point_list, keys, min_len, cap, copy_longer, s);
+    else if (cap <= 3072) launch_tsort_class<12>(T, ranges, point_list, keys, min_len, cap, copy_longer, s);
+    else if (cap <= 4096) launch_tsort_class<16>(T, ranges, point_list, keys, min_len, cap, copy_longer, s);
+    else launch_tsort_class<32>(T, ranges, point_list, keys, min_len, cap, copy_longer, s);
 }
 
 }  // namespace ggr

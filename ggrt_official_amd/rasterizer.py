@@ -73,8 +73,9 @@ class GaussianRasterizationSettings(NamedTuple):
     depth_sort: str = "auto"  # how the tile lists get their (depth, index) order — identical lists either way
     #                         (include/ggr_raster.h GgrSettings.depth_sort): "global" = one depth sort of the Gaussians in front of
     #                         the tile-list build; "per_tile" = lists built in index order, then every tile's list sorted by
-    #                         depth in LDS (no global dependency on the forward's critical path); "auto" = global (the two
-    #                         measure the same at 1080p / 1 M Gaussians; the global form has no list-length limit)
+    #                         depth in LDS (no global dependency on the forward's critical path); "auto" = per tile for
+    #                         frames with <= 256 Gaussians per tile on average and (once known) a longest list <= 4096,
+    #                         outside the sync-free mode; global otherwise (GGRt's 660-tile frames)
 
 
 class StageProfile:

@@ -106,8 +106,11 @@ typedef struct GgrSettings {
                                 dependency on the forward's critical path; a list of more than 8192 entries cannot be sorted
                                 that way: ggr_forward then rebuilds the lists with the global sort inside the call (exact mode
                                 and capacity_is_hint), or raises the overflow flag of ggr_forward_status (sync-free mode).
-                                GGR_DEPTH_SORT_AUTO (0): the global sort (the two measure the same on a 1080p frame with 1 M
-                                Gaussians; the global form has no list-length limit). */
+                                GGR_DEPTH_SORT_AUTO (0): per tile when the frame holds at most 256 (view, Gaussian) pairs per tile on
+                                average, the caller's max_list_len guess (if any) is at most 4096, and the call is not
+                                sync-free (a 1080p frame with 1 M Gaussians: 123 per tile, longest list 1 100: 3 % faster
+                                fwd+bwd; 200 k Gaussians at 504 x 378: 26 %); global otherwise (GGRt's own 660-tile frames
+                                hold lists of 4 000-6 000 entries: the global sort is 10 % faster there). */
 } GgrSettings;
 enum { GGR_DEPTH_SORT_AUTO = 0, GGR_DEPTH_SORT_GLOBAL = 1, GGR_DEPTH_SORT_PER_TILE = 2 };
 

@@ -128,15 +128,24 @@ def test_sync_free_per_tile_overflow_flag():
         assert how_g[0] == "global" and last_forward_status()[1] is False
 
 
-def test_auto_is_the_global_sort(monkeypatch):
-    """`auto` = global (the two forms measure the same at C3, NOTES r6); GGR_DEPTH_SORT overrides `auto` only."""
+def test_what_auto_picks(monkeypatch):
+    """`auto`: per tile for frames of short lists (<= 256 Gaussians per tile on average; once a call of the shape has reported
+    it, a longest list <= 4096), global for GGRt-like frames and in the sync-free mode; GGR_DEPTH_SORT overrides `auto` only."""
     from ggrt_official_amd.rasterizer import clear_list_hints
     clear_list_hints()
     monkeypatch.delenv("GGR_DEPTH_SORT", raising=False)
-    sc = make_scene(50000, 1920, 1080, sh_degree=0, profile="A", seed=10)
-    assert _state(sc, "auto")[1][0] == "global"
-    monkeypatch.setenv("GGR_DEPTH_SORT", "per_tile")
-    assert _state(sc, "auto")[1][0] == "per_tile" and _state(sc, "global")[1][0] == "global"
+    sparse = make_scene(50000, 1920, 1080, sh_degree=0, profile="A", seed=10)      # 6 per tile
+    dense = make_scene(300000, 480, 352, sh_degree=0, profile="B", seed=10)        # 455 per tile
+    assert _state(sparse, "auto")[1][0] == "per_tile" and _state(dense, "auto")[1][0] == "global"
+    assert _state(sparse, "auto", list_capacity=2000000)[1][0] == "global"          # sync-free: no read-back to fall back with
+    # a frame whose average is low but whose longest list is beyond 4096: per tile on the first call (nothing known), global
+    # once the shape's history says so
+    clear_list_hints()
+    pile = _pile(7000)
+    first, second = _state(pile, "auto")[1], _state(pile, "auto")[1]
+    assert first[0] == "per_tile" and first[1] > 4096 and second[0] == "global"
+    monkeypatch.setenv("GGR_DEPTH_SORT", "global")
+    assert _state(sparse, "auto")[1][0] == "global" and _state(sparse, "per_tile")[1][0] == "per_tile"
 
 
 def test_views_and_sets_per_tile_equal_global():
