@@ -71,6 +71,48 @@ def _matching_cap(z):
     return min(errs, key=errs.get), errs
 
 
+def _depth_semantics(z, st):
+    """What the extension's THIRD return value is (the fork GGRt installs returns a 3-tuple, reference
+    cuda_splatting.py:118 unpacks and drops it): the oracle's candidates against the file's `out_depth` — (a) Σ z·α·T, what
+    this build returns and SURVEY A.3 assumes ("w-depth" family); (b) the same normalised by the accumulated opacity
+    1 − T_final (expected depth); (c) the accumulated opacity itself; (d) 1 / (a) where it is positive.  Returns
+    (name of the best candidate, {name: max abs error relative to the file's peak})."""
+    if "out_depth" not in z.files:
+        return None, {}
+    ref = np.asarray(z["out_depth"], np.float64).reshape(st.out_depth.shape)
+    acc = 1.0 - np.asarray(st.final_T, np.float64)
+    a = np.asarray(st.out_depth, np.float64)
+    cands = {"sum_z_alpha_T": a, "expected_depth = sum_z_alpha_T / (1 - T_final)": a / np.maximum(acc, 1e-8),
+             "accumulated_opacity = 1 - T_final": acc, "inverse of sum_z_alpha_T": np.where(a > 0, 1.0 / np.maximum(a, 1e-12), 0.0)}
+    peak = max(1e-12, float(np.abs(ref).max()))
+    errs = {k: float(np.abs(v - ref).max() / peak) for k, v in cands.items()}
+    return min(errs, key=errs.get), errs
+
+
+def verdict(path) -> dict:
+    """Everything one run on a host with the real extension settles, for one exported file (printed by
+    `python tests/test_upstream_goldens.py` and by the tests with -s): the extension's surface (settings fields, length of the
+    returned tuple), the SH cap its binary implements (degree-4 files), what its third output is, and the oracle's errors."""
+    z = np.load(path, allow_pickle=False)
+    out = {"file": os.path.basename(path), "return_tuple_len": int(z["meta_return_len"]),
+           "settings_fields": [str(f) for f in z["meta_settings_fields"].tolist()],
+           "extension": [str(v) for v in z["meta_extension"].tolist()] if "meta_extension" in z.files else None}
+    cap = 3
+    if int(z["meta_size"][2]) >= 4 and "in_shs" in z.files and z["in_shs"].shape[1] >= 25:
+        cap, errs = _matching_cap(z)
+        out["band4_probe"] = {"extension_evaluates_bands_up_to": cap, "max_abs_image_error_by_cap": errs,
+                              "decided": bool(min(errs.values()) <= 0.02 and max(errs.values()) > 10 * min(errs.values()) + 1e-6),
+                              "choose": f"sh_max_degree={cap} (GaussianRasterizationSettings / DecoderSplattingCUDA / GGR_SH_MAX_DEGREE)"}
+    st, grads = _oracle(z, cap)
+    best, derr = _depth_semantics(z, st)
+    out["third_output"] = {"is": best, "relative_max_abs_error_by_candidate": derr} if best else "the extension returns no third tensor"
+    out["oracle_vs_extension"] = {"radii_equal": bool(np.array_equal(st.radii, z["out_radii"])),
+                                  "image_max_abs": float(np.abs(st.color - z["out_color"]).max()),
+                                  "grad_rel_l2": {k[5:]: rel_l2(np.asarray(grads[k[5:]]).reshape(z[k].shape), z[k])
+                                                  for k in z.files if k.startswith("grad_") and grads.get(k[5:]) is not None}}
+    return out
+
+
 def _check_oracle_against(path):
     z = np.load(path, allow_pickle=False)
     cap = 3
@@ -81,6 +123,12 @@ def _check_oracle_against(path):
         print(f"\n[upstream goldens] {os.path.basename(path)}: the extension evaluates SH bands 0..{cap} "
               f"(max abs image error cap 3: {errs[3]:.2e}, cap 4: {errs[4]:.2e}) -> choose sh_max_degree={cap} (INTEGRATION.md §7)")
     st, grads = _oracle(z, cap)
+    best, derr = _depth_semantics(z, st)
+    if best:
+        print(f"[upstream goldens] {os.path.basename(path)}: the extension's third output is `{best}` "
+              f"(relative max abs error {derr[best]:.2e}; the others: " + ", ".join(f"{k}: {v:.1e}" for k, v in derr.items() if k != best) + ")")
+        assert best == "sum_z_alpha_T" and derr[best] <= 1e-3, \
+            f"the extension's depth output is not the Σ z·α·T this build returns: {derr} (INTEGRATION.md §7)"
     _compare(z, st.color, st.radii, st.out_depth, grads, f"C oracle (sh cap {cap}) vs {os.path.basename(path)}")
     return cap
 
@@ -204,6 +252,26 @@ def test_hip_consumer_on_stub_exports(tmp_path):
             _check_hip_against(f)
 
 
+def test_verdict_says_what_a_real_export_would_settle(tmp_path):
+    """The one-command pin kit's report (`python tests/test_upstream_goldens.py`), on stub exports: the SH cap of the "binary"
+    is read off the degree-4 file, the third output is recognised as Σ z·α·T, the surface fields are reported."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import export_upstream_goldens as ex
+    finally:
+        sys.path.pop(0)
+    for cap, ret_len in ((3, 3), (4, 2)):
+        files = ex.export(str(tmp_path / f"c{cap}"), mod=_stub_extension(cap, False, ret_len), device="cpu", names=["ggrt_d4_m25"])
+        v = verdict(files[0])
+        assert v["band4_probe"]["extension_evaluates_bands_up_to"] == cap and v["band4_probe"]["decided"]
+        assert v["return_tuple_len"] == ret_len and "debug" not in v["settings_fields"]
+        if ret_len == 3:
+            assert v["third_output"]["is"] == "sum_z_alpha_T"
+        else:
+            assert isinstance(v["third_output"], str)
+        assert v["oracle_vs_extension"]["radii_equal"] and v["oracle_vs_extension"]["image_max_abs"] < 1e-5
+
+
 def test_exporter_refuses_the_repository_shim():
     """Run from this repository, `import diff_gaussian_rasterization` finds the import-name shim of the HIP build — the
     exporter must not mistake it for the extension."""
@@ -219,3 +287,12 @@ def test_exporter_refuses_the_repository_shim():
     finally:
         if saved is not None:
             sys.modules["diff_gaussian_rasterization"] = saved
+
+
+if __name__ == "__main__":   # the pin kit's report: one JSON object per exported file
+    import json
+    if not FILES:
+        print(UNPINNED)
+        sys.exit(1)
+    for f in FILES:
+        print(json.dumps(verdict(f), indent=1))
