@@ -939,86 +939,92 @@ def main():
     N = wl.num_rendered()  # num_rendered of this rank's frame by the reference's emit rule (algorithmic bytes)
     N_built = wl.num_rendered(reference=False)
 
-    # informational: TWO frames in flight — two different frames alternate on two HIP streams, so one frame's latency-bound
-    # kernels (depth sort, tile lists: 0.19 ms with most CUs idle) run beside the other's blend kernels.  The library keeps
-    # no state between calls, every buffer belongs to its call.  Not the headline: that is one frame at a time.
-    overlap_rec = None
-    if world == 1 and not args.no_graph:
-        try:
-            wl2 = Workload(args.config, cfg, dev, seed=rank + 1)
-            pair, lanes = (wl, wl2), [torch.cuda.Stream(device=dev) for _ in range(2)]
-            for st_ in lanes:
-                st_.wait_stream(torch.cuda.current_stream(dev))
-
-            def step2(i):
-                with torch.cuda.stream(lanes[i & 1]):
-                    pair[i & 1].step()
-
-            el2, _ = timed_steps(step2, args.steps, args.warmup, dev, prewarm_ms=LEG_PREWARM_MS)
-            for st_ in lanes:
-                torch.cuda.current_stream(dev).wait_stream(st_)
-            ms2 = el2 / args.steps * 1e3
-            overlap_rec = {"ms_per_frame": round(ms2, 4), "mpix_s": round(W * H / ms2 / 1e3, 1), "frames_in_flight": 2,
-                           "note": "two different frames alternating on two HIP streams, one host thread, drop-in (exact) mode; "
-                                   "informational"}
-            log(f"two frames in flight: {ms2:.3f} ms/frame")
-            del wl2
-        except Exception as e:  # never let the informational leg break the contract line
-            log(f"two-streams leg skipped: {type(e).__name__}: {e}")
-
-    # informational: the same step with the sync-free forward (list buffer sized 1.25·N up front) captured in ONE
-    # HIP graph and replayed — no host sync, no per-kernel launch cost.  Not the headline value: the default,
-    # drop-in mode above is.
-    graph_rec = None
-    if world == 1 and not args.no_graph:
-        try:
-            from ggrt_official_amd.rasterizer import last_forward_status
-            cap = int(N * 1.25) + 4096
-            rast_g = GaussianRasterizer(wl.rs._replace(list_capacity=cap))
-            keep = {}
-
-            def step_g():
-                for t in wl.leaves:
-                    t.grad = None
-                color, _, _ = rast_g(means3D=wl.means, means2D=wl.means2D, opacities=wl.op, shs=wl.shs, cov3D_precomp=wl.cov)
-                keep["color"] = color  # keeps the forward's buffers alive for last_forward_status()
-                color.backward(wl.dL, retain_graph=False)
-
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    step_g()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step_g()
-            t_pre, k = time.perf_counter(), 0
-            while (time.perf_counter() - t_pre) * 1e3 < LEG_PREWARM_MS:   # (the capture left the device idle)
-                graph.replay()
-                k += 1
-                if k % 8 == 0:
-                    torch.cuda.synchronize(dev)
-            for _ in range(args.warmup):
-                graph.replay()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                graph.replay()
-            torch.cuda.synchronize(dev)
-            g_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    def stream_legs():
+        overlap_rec, graph_rec = None, None
+        # informational: TWO frames in flight — two different frames alternate on two HIP streams, so one frame's latency-bound
+        # kernels (depth sort, tile lists: 0.19 ms with most CUs idle) run beside the other's blend kernels.  The library keeps
+        # no state between calls, every buffer belongs to its call.  Not the headline: that is one frame at a time.
+        if world == 1 and not args.no_graph:
             try:
-                n_g, overflow = last_forward_status()
-            except RuntimeError:
-                n_g, overflow = None, None
-            graph_rec = {"ms_per_step": round(g_ms, 4), "mpix_s": round(W * H / g_ms / 1e3, 1), "list_capacity": cap,
-                         "num_rendered": n_g, "overflow": overflow,
-                         "note": "sync-free forward + backward captured in one HIP graph, replayed; informational"}
-            log(f"hip graph replay: {g_ms:.3f} ms/step")
-            del graph, keep
-        except Exception as e:  # never let the informational leg break the contract line
-            log(f"hip graph leg skipped: {type(e).__name__}: {e}")
+                wl2 = Workload(args.config, cfg, dev, seed=rank + 1)
+                pair, lanes = (wl, wl2), [torch.cuda.Stream(device=dev) for _ in range(2)]
+                for st_ in lanes:
+                    st_.wait_stream(torch.cuda.current_stream(dev))
 
+                def step2(i):
+                    with torch.cuda.stream(lanes[i & 1]):
+                        pair[i & 1].step()
+
+                el2, _ = timed_steps(step2, args.steps, args.warmup, dev, prewarm_ms=LEG_PREWARM_MS)
+                for st_ in lanes:
+                    torch.cuda.current_stream(dev).wait_stream(st_)
+                ms2 = el2 / args.steps * 1e3
+                overlap_rec = {"ms_per_frame": round(ms2, 4), "mpix_s": round(W * H / ms2 / 1e3, 1), "frames_in_flight": 2,
+                               "note": "two different frames alternating on two HIP streams, one host thread, drop-in (exact) mode; "
+                                       "informational"}
+                log(f"two frames in flight: {ms2:.3f} ms/frame")
+                del wl2
+            except Exception as e:  # never let the informational leg break the contract line
+                log(f"two-streams leg skipped: {type(e).__name__}: {e}")
+
+        # informational: the same step with the sync-free forward (list buffer sized 1.25·N up front) captured in ONE
+        # HIP graph and replayed — no host sync, no per-kernel launch cost.  Not the headline value: the default,
+        # drop-in mode above is.
+        if world == 1 and not args.no_graph:
+            try:
+                from ggrt_official_amd.rasterizer import last_forward_status
+                cap = int(N * 1.25) + 4096
+                rast_g = GaussianRasterizer(wl.rs._replace(list_capacity=cap))
+                keep = {}
+
+                def step_g():
+                    for t in wl.leaves:
+                        t.grad = None
+                    color, _, _ = rast_g(means3D=wl.means, means2D=wl.means2D, opacities=wl.op, shs=wl.shs, cov3D_precomp=wl.cov)
+                    keep["color"] = color  # keeps the forward's buffers alive for last_forward_status()
+                    color.backward(wl.dL, retain_graph=False)
+
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        step_g()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    step_g()
+                t_pre, k = time.perf_counter(), 0
+                while (time.perf_counter() - t_pre) * 1e3 < LEG_PREWARM_MS:   # (the capture left the device idle)
+                    graph.replay()
+                    k += 1
+                    if k % 8 == 0:
+                        torch.cuda.synchronize(dev)
+                for _ in range(args.warmup):
+                    graph.replay()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    graph.replay()
+                torch.cuda.synchronize(dev)
+                g_ms = (time.perf_counter() - t0) / args.steps * 1e3
+                try:
+                    n_g, overflow = last_forward_status()
+                except RuntimeError:
+                    n_g, overflow = None, None
+                graph_rec = {"ms_per_step": round(g_ms, 4), "mpix_s": round(W * H / g_ms / 1e3, 1), "list_capacity": cap,
+                             "num_rendered": n_g, "overflow": overflow,
+                             "note": "sync-free forward + backward captured in one HIP graph, replayed; informational"}
+                log(f"hip graph replay: {g_ms:.3f} ms/step")
+                del graph, keep
+            except Exception as e:  # never let the informational leg break the contract line
+                log(f"hip graph leg skipped: {type(e).__name__}: {e}")
+
+
+        return overlap_rec, graph_rec
+
+    # (the two informational legs that create HIP streams of their own — two frames in flight, the HIP-graph replay — run LAST,
+    #  behind the call-site and secondary legs: streams a host creates can land the library's side stream on the hardware queue
+    #  of the caller's stream, and the legs behind them then measured GGRt's shapes 15-20 % slow — NOTES r6)
     # informational (VERDICT r3 missing #4 / weak #7a): the headline loop re-renders ONE frame, so the default mode's list-size
     # guess (rasterizer._forward_with_guess) always holds.  Three legs say what that hides: (a) the same loop with the guess
     # switched off — upstream's order: read num_rendered back, allocate, launch the rest; (b) two scenes of the same shape
@@ -1245,10 +1251,6 @@ def main():
             rec["value_note"] = ("value = frames·W·H ÷ the step incl. the one mean all-reduce of the stand-in parameter gradients "
                                  f"({(G + 35) * 4 / 1e6:.0f} MB, {args.exchange_mode}); scaling_basis names the figure that scales "
                                  "with the path itself")
-        if graph_rec is not None:
-            rec["hipgraph_replay"] = graph_rec
-        if overlap_rec is not None:
-            rec["two_frames_in_flight"] = overlap_rec
         if world == 1 and not args.no_callsite:
             # informational: GGRt's own shape through the call-site layer (scripts/callsite_bench.py)
             try:
@@ -1281,6 +1283,14 @@ def main():
                 except Exception as e:
                     log(f"secondary {name} skipped: {type(e).__name__}: {e}")
             rec["secondary"] = sec
+        try:
+            overlap_rec, graph_rec = stream_legs()
+            if graph_rec is not None:
+                rec["hipgraph_replay"] = graph_rec
+            if overlap_rec is not None:
+                rec["two_frames_in_flight"] = overlap_rec
+        except Exception as e:
+            log(f"stream legs skipped: {type(e).__name__}: {e}")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 rec["cpu_baseline"] = cpu_baseline_c_oracle(wl.sc_cpu, wl.dL.cpu().numpy())

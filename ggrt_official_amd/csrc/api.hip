@@ -133,30 +133,104 @@ ReadbackSlot* readback_slot() {
 // kernels of the caller's stream — the critical path — win the CUs whenever both have workgroups to place), ordered against
 // the caller's stream by two events per forward (fork behind the geometry kernel, join in front of the blend).  Holds no
 // state between calls; two forwards of one thread on two streams share it and merely serialise their colour kernels.
+// ROCm maps a process's streams onto a FEW hardware queues (four by default, GPU_MAX_HW_QUEUES): a side stream created after
+// the host has made three or more streams of its own lands on the queue of the caller's stream, and then every kernel the
+// forward chains on the caller's stream behind the fork is held up while the colour kernel runs — measured at C5' 0.80-0.86
+// instead of 0.69 ms per step (geometry stage 35 -> 63 µs, depth sort 113 -> 169-250, tile counts 47 -> 78;
+// tools/experiments/r06_slow_after_graph.py; bench.py's own graph legs did it to the legs behind them).  So a side stream is
+// PROBED against the caller's stream before it is used — the forward's own pattern in miniature: a kernel on the caller's
+// stream, the fork, a 100 µs one-wave spin on the candidate, a chain of eight empty kernels on the caller's stream, HIP events
+// around the chain, against the same with an empty kernel instead of the spin.  A candidate that stretches the chain is
+// dropped and the next one tried (the runtime hands its queues out round robin); no candidate after six: no split for this
+// caller stream.  Once per (host thread, device, caller stream): ≈ 0.5 ms and one synchronisation of the caller's stream.
+// GPU_MAX_HW_QUEUES=16 in the environment of the process avoids the sharing at its root (measured: 0.69 with eight host streams).
 struct SideStream {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // for the caller stream the call came with (set by side_stream())
     hipEvent_t fork = nullptr, join = nullptr;
-    hipEvent_t t0 = nullptr, t1 = nullptr;   // timing brackets of the colour kernel (stage profiling only)
+    hipEvent_t t0 = nullptr, t1 = nullptr;   // timing brackets of the colour kernel (stage profiling; the probe)
     bool failed = false;
+    struct Pair { hipStream_t caller; hipStream_t side; bool usable; } pairs[4];
+    int npairs = 0;
 };
-SideStream* side_stream() {
+// true: `cand` runs concurrently with `s`
+bool side_stream_is_concurrent(SideStream& r, hipStream_t s, hipStream_t cand) {
+    if (hipStreamSynchronize(s) != hipSuccess || hipStreamSynchronize(cand) != hipSuccess) { (void)hipGetLastError(); return false; }
+    ReadbackSlot* rb = readback_slot();   // (its pinned, coherent line: word 8 tells the host that the spin is on the device)
+    if (!rb) return false;
+    volatile uint32_t* started = rb->host + 8;
+    // the forward's own pattern: a kernel on the caller's stream, the fork (event on the caller's stream, the candidate waits
+    // for it), a kernel on the candidate, then a CHAIN of kernels on the caller's stream — timed with the candidate's kernel a
+    // 200 µs spin that is known to be running, and, for comparison, an empty one
+    float best = 1e9f, base = 1e9f;
+    for (int rep = 0; rep < 4; rep++) {   // (the first launches of a fresh stream pay for its set-up)
+        const bool spin = (rep & 1) != 0;
+        ggr::launch_noop(s);
+        if (hipEventRecord(r.fork, s) != hipSuccess || hipStreamWaitEvent(cand, r.fork, 0) != hipSuccess) break;
+        if (spin) {
+            *started = 0u;
+            ggr::launch_spin(20000ull /*200 µs*/, (uint32_t*)started, cand);
+            timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            while (*started == 0u) {   // (bounded: 50 ms)
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 50.0) break;
+            }
+        } else {
+            ggr::launch_noop(cand);
+        }
+        if (hipEventRecord(r.t0, s) != hipSuccess) break;
+        for (int k = 0; k < 8; k++) ggr::launch_noop(s);
+        if (hipEventRecord(r.t1, s) != hipSuccess || hipEventSynchronize(r.t1) != hipSuccess) break;
+        float ms = 1e9f;
+        if (hipEventElapsedTime(&ms, r.t0, r.t1) == hipSuccess) { if (spin) best = std::min(best, ms); else base = std::min(base, ms); }
+        (void)hipStreamSynchronize(cand);
+    }
+    (void)hipGetLastError();
+    // measured: 0.017-0.018 ms either way on a candidate with a queue of its own, 0.017-0.023 against 0.053-0.054 on one that
+    // shares the caller's
+    const bool ok = best < 1.5f * base + 0.010f;
+    if (getenv("GGR_SIDE_STREAM_DEBUG"))
+        fprintf(stderr, "[ggr] side-stream probe: caller %p candidate %p: chain of 8 kernels %.3f ms beside an empty kernel, %.3f beside a "
+                        "running spin -> %s\n", (void*)s, (void*)cand, base, best, ok ? "concurrent" : "shares the caller's queue");
+    return ok;
+}
+SideStream* side_stream(hipStream_t caller) {
     static thread_local SideStream slots[32];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
     SideStream& r = slots[dev];
     if (r.failed) return nullptr;
-    if (!r.stream) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority (numerically greatest)
-        const char* pe = getenv("GGR_COLOUR_PRIO");   // dev: "high" / "normal" instead of the lowest priority
-        const int prio = (pe && *pe == 'h') ? hi : (pe && *pe == 'n') ? (lo + hi) / 2 : lo;
-        bool ok = hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, prio) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
+    if (!r.fork) {
+        bool ok = hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&r.join, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreate(&r.t0) == hipSuccess && hipEventCreate(&r.t1) == hipSuccess;
-        if (!ok) { r.failed = true; r.stream = nullptr; (void)hipGetLastError(); return nullptr; }
+        if (!ok) { r.failed = true; (void)hipGetLastError(); return nullptr; }
     }
-    return &r;
+    for (int i = 0; i < r.npairs; i++)
+        if (r.pairs[i].caller == caller) { r.stream = r.pairs[i].side; return r.pairs[i].usable ? &r : nullptr; }
+    if (r.npairs == 4) return nullptr;   // (a fifth caller stream of one thread: no split for it)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority (numerically greatest)
+    const char* pe = getenv("GGR_COLOUR_PRIO");   // dev: "high" / "normal" instead of the lowest priority
+    const int prio = (pe && *pe == 'h') ? hi : (pe && *pe == 'n') ? (lo + hi) / 2 : lo;
+    const char* np = getenv("GGR_SIDE_STREAM_PROBE");   // "0": take the first stream unprobed (the behaviour until round 5)
+    const bool probe = !(np && *np == '0');
+    SideStream::Pair pr{caller, nullptr, false};
+    // (an earlier caller stream's side stream may serve this one too)
+    for (int i = 0; i < r.npairs && !pr.usable; i++)
+        if (r.pairs[i].usable && (!probe || side_stream_is_concurrent(r, caller, r.pairs[i].side))) { pr.side = r.pairs[i].side; pr.usable = true; }
+    hipStream_t rejected[6];
+    int nrej = 0;
+    for (int attempt = 0; attempt < 6 && !pr.usable; attempt++) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (!probe || side_stream_is_concurrent(r, caller, cand)) { pr.side = cand; pr.usable = true; }
+        else rejected[nrej++] = cand;   // (kept until the search ends: destroyed at once, its queue slot would be handed out again)
+    }
+    for (int i = 0; i < nrej; i++) (void)hipStreamDestroy(rejected[i]);
+    r.pairs[r.npairs++] = pr;
+    r.stream = pr.side;
+    return pr.usable ? &r : nullptr;
 }
 // GGR_SPLIT_COLOUR=0: the per-Gaussian stage as ONE kernel on the caller's stream (dev / A-B measurements)
 // (read on every forward: a test or a host can switch within a process)
@@ -410,7 +484,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     if (in->shs && P1 > 0 && P1 <= GGR_SPLIT_MAX_POINTS && !dbg && split_colour_enabled() &&
         (!per_tile || getenv("GGR_COLOUR_FORK") != nullptr)) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) side = side_stream();
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) side = side_stream(s);
         else (void)hipGetLastError();
     }
     // (per tile: the kernel also clears the tile-list totals — the depth sort's last pass does it otherwise — and leaves the

@@ -457,6 +457,9 @@ void launch_camera_setup(int n, const float* extrinsics, const float* intrinsics
 
 // util.hip: float4 streaming copy of `bytes` (multiple of 16) — the measured HBM ceiling bench.py quotes
 void launch_copy_f4(const void* src, void* dst, size_t bytes, int blocks /*0 = default*/, hipStream_t s);
+// util.hip: a one-wave kernel that occupies its stream for `ticks` of the 100 MHz wall clock / an empty kernel (side-stream probe)
+void launch_spin(unsigned long long ticks, uint32_t* started /*host-visible, or NULL*/, hipStream_t s);
+void launch_noop(hipStream_t s);
 
 void launch_unpack_geom(GeomLayout g, int P, float* depth, float* xy, float* conic_opacity, float* rgb,
                         int32_t* tiles_touched, uint8_t* clamped, hipStream_t s);

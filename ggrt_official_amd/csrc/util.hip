@@ -37,4 +37,17 @@ void launch_copy_f4(const void* src, void* dst, size_t bytes, int blocks, hipStr
         hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const v4f*)src, (v4f*)dst, n4);
 }
 
+// ---- the side-stream probe (api.hip side_stream) --------------------------------------------------------------------
+// one wave that stays on the device for `ticks` of the 100 MHz wall clock, and one that does nothing
+__global__ void spin_kernel(unsigned long long ticks, uint32_t* started /*host-visible word: set when the wave runs*/) {
+    if (started && threadIdx.x == 0) __hip_atomic_store(started, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void noop_kernel() {}
+void launch_spin(unsigned long long ticks, uint32_t* started, hipStream_t s) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks, started);
+}
+void launch_noop(hipStream_t s) { hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, s); }
+
 }  // namespace ggr
