@@ -151,6 +151,10 @@ def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int, N_built: i
         # tile scatter = the ids written + each Gaussian's (id, rect) read once + the per-chunk start table read once
         "depth_sort_compulsory": P * (3 * 16 + 4),
         "tile_scatter_compulsory": (N if N_built is None else N_built) * 4 + P * 12,   # (the ids this build writes)
+        # the per-tile form of the binning (round 6, csrc/tile_sort.hip): the id-order scatter writes (id, key) — 8 B per entry —
+        # and reads rect 8 + key 4 per Gaussian; the per-tile sort reads the 8-B entries and writes the 4-B ids
+        "tile_scatter_pairs_compulsory": (N if N_built is None else N_built) * 8 + P * 12,
+        "tile_sort_compulsory": (N if N_built is None else N_built) * 12,
         "fwd_blend": N * 40 + W * H * 20,
         # B_bwd = W·H·20 + N·40 + P(12+24+4+12K) + P(12+12+24+4+12M)
         "bwd_blend": W * H * 20 + N * 40,
@@ -163,6 +167,7 @@ def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int, N_built: i
         # tile rects), and for the binning what its kernels must move at least instead of SURVEY's 24 B of pair traffic
         # per entry, which no kernel here performs
         "fwd_binning_built": P * (3 * 16 + 4) + (N if N_built is None else N_built) * 4 + P * 12,
+        "fwd_binning_built_per_tile": (N if N_built is None else N_built) * 20 + P * 12,
         "fwd_blend_built": (N if N_built is None else N_built) * 40 + W * H * 20,
         "bwd_blend_built": W * H * 20 + (N if N_built is None else N_built) * 40,
     }
@@ -334,7 +339,8 @@ class Workload:
         # (the colour kernel runs BESIDE the sort / tile-list stages on the forward's side stream: not a term of the sum)
         t_fwd = sum(v for k, v in stages.items() if k.startswith("fwd_") and "side_stream" not in k)
         b_fwd = ab["fwd_preprocess"] + ab["fwd_binning"] + ab["fwd_blend"]
-        b_fwd_built = ab["fwd_preprocess"] + ab["fwd_binning_built"] + ab["fwd_blend_built"]
+        per_tile = stages.get("fwd_tile_sort_ms", 0.0) > 0
+        b_fwd_built = ab["fwd_preprocess"] + ab["fwd_binning_built_per_tile" if per_tile else "fwd_binning_built"] + ab["fwd_blend_built"]
         is_blend = dom.endswith("blend")
         bound, bound_evidence = ("hbm", "streaming kernel: bytes moved ÷ time against the HBM peak") if not is_blend else \
             self.blend_bound(dom)
@@ -397,8 +403,13 @@ class Workload:
             name: {"ms": round(stages[key], 4), "compulsory_bytes": ab[ck],
                    "achieved_GBps": round(ab[ck] / (stages[key] * 1e-3) / 1e9, 1),
                    "hbm_frac": round(ab[ck] / (stages[key] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-            for name, key, ck in (("depth_sort", "fwd_depth_sort_ms", "depth_sort_compulsory"),
-                                  ("tile_scatter", "fwd_tile_scatter_ms", "tile_scatter_compulsory"))}
+            for name, key, ck in ((("tile_sort", "fwd_tile_sort_ms", "tile_sort_compulsory"),
+                                   ("tile_scatter", "fwd_tile_scatter_ms", "tile_scatter_pairs_compulsory"))
+                                  if stages.get("fwd_tile_sort_ms", 0.0) > 0 else
+                                  (("depth_sort", "fwd_depth_sort_ms", "depth_sort_compulsory"),
+                                   ("tile_scatter", "fwd_tile_scatter_ms", "tile_scatter_compulsory")))
+            if stages.get(key, 0.0) > 0}
+        out["binning_form"] = "per_tile" if stages.get("fwd_tile_sort_ms", 0.0) > 0 else "global"
         if not self.fwd_only:
             t_bwd = sum(v for k, v in stages.items() if k.startswith("bwd_"))
             b_bwd = ab["bwd_blend"] + ab["bwd_preprocess"]
