@@ -250,13 +250,21 @@ bool split_colour_enabled() {
 int colour_grid_blocks(size_t pairs) {
     const char* e_blocks = getenv("GGR_COLOUR_BLOCKS_PER_CU");   // (read per call, like GGR_SPLIT_COLOUR)
     const int forced = (e_blocks && *e_blocks) ? atoi(e_blocks) : -1;
-    static const int cus = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            return prop.multiProcessorCount;
-        return 256;
-    }();
+    // (the CU count of the CURRENT device, looked up once per device — ADVICE r5: a process that drives several devices must
+    //  not throttle all of them by the first one's count)
+    static int cus_of[32] = {0};
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32) {
+        int c = __atomic_load_n(&cus_of[dev], __ATOMIC_RELAXED);
+        if (c == 0) {
+            hipDeviceProp_t prop;
+            c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            __atomic_store_n(&cus_of[dev], c, __ATOMIC_RELAXED);
+        }
+        cus = c;
+    } else {
+        (void)hipGetLastError();
+    }
     const int per_cu = forced >= 0 ? forced : (int)std::min<size_t>(4, 1 + pairs / 2000000);
     return per_cu <= 0 ? 0 : per_cu * cus;
 }

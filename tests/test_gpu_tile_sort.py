@@ -99,6 +99,42 @@ def test_long_lists_large_class_and_fallback(P, expect):
         assert stats["exact" if attempt == "exact" else "hinted" if expect == "per_tile" else "missed"] == 1, (attempt, stats)
 
 
+@pytest.mark.parametrize("K", [2, 63, 64, 65, 255, 256, 257, 1023, 1025, 2047, 2048, 2049, 3071, 3072, 3073, 4095, 4096, 4097,
+                               8191, 8192, 8193])
+def test_list_lengths_at_the_class_boundaries(K):
+    """ONE tile's list of exactly K entries (K tiny Gaussians in the middle of a tile, a few hundred elsewhere): the wave /
+    round / class boundaries of the per-tile sort — 64, 256, 2048, 3072, 4096, 8192 — and one beyond the last (global rebuild);
+    depths drawn from few values so that equal keys (ties by id) and clustered buckets (the LSD route) both occur."""
+    import math
+    from ggrt_official_amd.rasterizer import clear_list_hints
+    W = H = 256
+    P = K + 300
+    sc = make_scene(P, W, H, sh_degree=0, profile="A", seed=K)
+    g = torch.Generator().manual_seed(K)
+    fpx = 0.5 / math.tan(math.radians(30.0)) * W
+    z = sc.means3D[:K, 2].clone()
+    if K % 3 == 0:
+        z = 2.0 + torch.randint(0, 7, (K,), generator=g).float() * 0.5            # seven depth planes: ties, big buckets
+    elif K % 3 == 1:
+        z = 3.0 + torch.rand(K, generator=g) * 1e-4                                # one tight cluster
+    u = 136.0 + torch.rand(K, generator=g) * 4.0                                   # inside tile (8, 8): pixels 128 … 143
+    v = 136.0 + torch.rand(K, generator=g) * 4.0
+    sc.means3D[:K, 0] = (u - 0.5 * W) / fpx * z
+    sc.means3D[:K, 1] = (v - 0.5 * H) / fpx * z
+    sc.means3D[:K, 2] = z
+    sc.cov3D[:K] = 0.0
+    s2 = (0.3 * z / fpx) ** 2                                                      # σ = 0.3 px: radius 3 → stays inside the tile
+    sc.cov3D[:K, 0] = s2; sc.cov3D[:K, 3] = s2; sc.cov3D[:K, 5] = s2
+    clear_list_hints()
+    glob, how_g = _state(sc, "global")
+    lens = glob["ranges"][:, 1] - glob["ranges"][:, 0]
+    assert int(lens.max()) >= K and how_g[1] == int(lens.max())
+    for attempt in range(2):      # exact (nothing known), then with guesses
+        tile, how = _state(sc, "per_tile")
+        assert how[0] == ("per_tile" if int(lens.max()) <= 8192 else "global"), how
+        _same_lists(tile, glob)
+
+
 def test_length_guess_too_small_is_repaired():
     """Two frames of one shape: the first with short lists, the second with a list of the large class — the second runs
     with the first's guesses (no large launch enqueued) and must repair itself."""
