@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libggr_raster.so")
 SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "tile_lists.hip", "tile_sort.hip", "blend_fwd.hip", "blend_bwd.hip",
            "preprocess_bwd.hip", "camera.hip", "util.hip"]
-HEADERS = ["ggr_common.h", "blend_common.h", "sh_stage.h", "sh_terms.h", os.path.join("..", "..", "include", "ggr_raster.h")]
+HEADERS = ["ggr_common.h", "blend_common.h", "tile_sort.h", "sh_stage.h", "sh_terms.h", os.path.join("..", "..", "include", "ggr_raster.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 # per-file additions.  The blend kernels are VALU-bound and the SLP vectoriser packs their fp32 math into v_pk_*
