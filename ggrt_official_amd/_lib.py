@@ -92,6 +92,7 @@ SYMBOLS = [
     ("ggr_backward", C.c_int, [C.POINTER(GgrSettings), C.POINTER(GgrBackwardIn), C.POINTER(GgrBackwardOut),
                                C.c_void_p]),
     ("ggr_image_bytes_inference", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    ("ggr_geom_bytes_inference", C.c_size_t, [C.c_int32, C.c_int32]),
     ("ggr_geom_bytes_views", C.c_size_t, [C.c_int32, C.c_int32]),
     ("ggr_image_bytes_views", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("ggr_work_bytes_views", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -436,7 +436,8 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     const bool dbg = st->debug != 0;
 
     const size_t segs = ggr_sort_segments((size_t)NV);  // the depth sort runs one segment per view
-    GeomLayout g = ggr_carve_geom(out->geom_buffer, (size_t)P, segs);
+    // (no_backward: the caller may have brought the smaller ggr_geom_bytes_inference buffer — nothing beyond it is touched)
+    GeomLayout g = ggr_carve_geom(out->geom_buffer, (size_t)P, segs, /*with_jac=*/out->no_backward == 0);
     ImageLayout im = ggr_carve_image(out->image_buffer, W, H, NV);
     StageTimer tm(s, out->stage_ms, GGR_FWD_STAGES);
 
@@ -858,6 +859,10 @@ int ggr_backward_views(const GgrSettings* st, const GgrViews* views, const GgrBa
     return backward_impl(st, vs, in, out, stream);
 }
 
+size_t ggr_geom_bytes_inference(int32_t P, int32_t V) {
+    const size_t v = (size_t)(V > 0 ? V : 1);
+    return ggr_carve_geom(nullptr, (size_t)(P > 0 ? P : 0) * v, ggr_sort_segments(v), /*with_jac=*/false).bytes;
+}
 size_t ggr_image_bytes_inference(int32_t W, int32_t H, int32_t V) { return ggr_carve_image(nullptr, W, H, V > 0 ? V : 1).bytes_no_ckpt; }
 size_t ggr_geom_bytes_views(int32_t P, int32_t V) {
     const size_t v = (size_t)(V > 0 ? V : 1);

@@ -177,8 +177,11 @@ struct GeomLayout {
     size_t bytes;
 };
 
-// P = (view, Gaussian) pairs of the launch set; `segments` = ggr_sort_segments(views)
-static inline GeomLayout ggr_carve_geom(void* base, size_t P, size_t segments = 1) {
+// P = (view, Gaussian) pairs of the launch set; `segments` = ggr_sort_segments(views).  `with_jac` = false: the geometry
+// buffer of a forward that no backward will follow (GgrForwardOut.no_backward, ggr_geom_bytes_inference) — the Jacobian planes
+// (48 B per pair, written by a training forward for its backward) come LAST and are left out; every other section sits where it
+// sits in the full layout
+static inline GeomLayout ggr_carve_geom(void* base, size_t P, size_t segments = 1, bool with_jac = true) {
     GeomLayout L;
     char* p = (char*)base;
     size_t o = 0;
@@ -186,7 +189,6 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P, size_t segments = 
     auto take = [&](size_t bytes) { char* r = p ? p + o : nullptr; o += ggr_align(bytes); return r; };
     L.splat = (float4*)take(Pp * 32);
     L.colour = (float4*)take(Pp * 16);
-    L.sh_jac = (float4*)take(Pp * 48);
     L.rect = (uint2*)take(Pp * 8);
     L.clamped = (uint32_t*)take(Pp * 4);
     L.cov3D = (float*)take(Pp * 24);
@@ -196,6 +198,7 @@ static inline GeomLayout ggr_carve_geom(void* base, size_t P, size_t segments = 
     L.vals_b = (uint32_t*)take(Pp * 4);
     L.counters = (uint32_t*)take(64 * 4);  // (before the sort area: its offset must not depend on `segments`)
     L.hist = (uint32_t*)take(ggr_sort_hist_words(Pp, segments) * 4);
+    L.sh_jac = with_jac ? (float4*)take(Pp * 48) : nullptr;
     L.bytes = o;
     return L;
 }

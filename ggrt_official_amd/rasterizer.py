@@ -345,13 +345,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             depth = torch.empty((H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
-            geom = torch.empty((lib.ggr_geom_bytes(P),), dtype=torch.uint8, device=dev)
             # nothing requires grad (torch.no_grad() / inference): no backward will replay this forward, so the
             # per-pixel checkpoints of the segmented backward are neither written nor allocated
             # (needs_input_grad mirrors tensor.requires_grad even under no_grad — the call site's means2D sink always
             #  requires grad — and inside a Function's forward the grad mode is always off: the caller's grad mode
             #  comes in as an argument)
             infer = (not grad_mode) or not any(getattr(ctx, "needs_input_grad", (True,)))  # (debug_forward_state: plain ctx)
+            # (… nor is the SH colour's Jacobian — 48 B per Gaussian of the geometry buffer — written or allocated)
+            geom = torch.empty((lib.ggr_geom_bytes_inference(P, 1) if infer else lib.ggr_geom_bytes(P),), dtype=torch.uint8,
+                               device=dev)
             img = torch.empty((lib.ggr_image_bytes_inference(W, H, 1) if infer else lib.ggr_image_bytes(W, H),),
                               dtype=torch.uint8, device=dev)
             holder = {}
@@ -526,8 +528,9 @@ class _RasterizeViews(torch.autograd.Function):
             color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
             depth = torch.empty((V, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((V, P), dtype=torch.int32, device=dev)
-            geom = torch.empty((lib.ggr_geom_bytes_views(P, V),), dtype=torch.uint8, device=dev)
             infer = (not grad_mode) or not any(ctx.needs_input_grad)
+            geom = torch.empty((lib.ggr_geom_bytes_inference(P, V) if infer else lib.ggr_geom_bytes_views(P, V),),
+                               dtype=torch.uint8, device=dev)
             img = torch.empty((lib.ggr_image_bytes_inference(W, H, V) if infer else lib.ggr_image_bytes_views(W, H, V),),
                               dtype=torch.uint8, device=dev)
             holder = {}

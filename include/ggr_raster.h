@@ -299,6 +299,10 @@ typedef struct GgrViews {
 
 /* image_buffer size of a forward with GgrForwardOut.no_backward = 1 (no checkpoint area); num_views = 1 for ggr_forward */
 size_t ggr_image_bytes_inference(int32_t width, int32_t height, int32_t num_views);
+/* ABI 10: geom_buffer size of a forward with GgrForwardOut.no_backward = 1 — without the 48 B per (view, Gaussian) of the SH
+ * colour's Jacobian that a training forward leaves for its backward (55 MB at GGRt's 1.15 M-Gaussian eval shape).  num_views = 1
+ * for ggr_forward.  The full ggr_geom_bytes buffer is accepted as well. */
+size_t ggr_geom_bytes_inference(int32_t num_points, int32_t num_views);
 
 size_t ggr_geom_bytes_views(int32_t num_points, int32_t num_views);
 size_t ggr_image_bytes_views(int32_t width, int32_t height, int32_t num_views);

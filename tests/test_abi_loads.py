@@ -75,6 +75,9 @@ def test_size_queries_are_consistent():
     assert lib.ggr_binning_bytes(10_000_000, 1920, 1080) >= 10_000_000 * 4
     assert lib.ggr_work_bytes(1_000_000, 1920, 1080) >= 977 * 8160 * 4
     assert lib.ggr_backward_scratch_bytes(1_000_000) >= 1_000_000 * 28
+    # an inference forward's geometry buffer leaves out the Jacobian planes (48 B per (view, Gaussian), carved last)
+    assert lib.ggr_geom_bytes(1_000_000) - lib.ggr_geom_bytes_inference(1_000_000, 1) == 48_000_000
+    assert lib.ggr_geom_bytes_views(1000, 4) - lib.ggr_geom_bytes_inference(1000, 4) == 4 * 1000 * 48
     for f, args in ((lib.ggr_geom_bytes, (12345,)), (lib.ggr_image_bytes, (333, 77)),
                     (lib.ggr_binning_bytes, (98765, 333, 77)), (lib.ggr_backward_scratch_bytes, (4321,)),
                     (lib.ggr_work_bytes, (4321, 333, 77))):
