@@ -104,6 +104,7 @@ SYMBOLS = [
     ("ggr_camera_setup", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ggr_forward_status", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_void_p]),
+    ("ggr_sort_stats_async", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     ("ggr_mark_visible", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ggr_debug_readback_wait", C.c_int, [C.c_int32, C.c_double, C.POINTER(C.c_uint32)]),
     ("ggr_debug_counters", C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),

@@ -583,10 +583,10 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         // nothing uninitialised is left for the blend.
         const uint32_t one_launch = 3072;
         if (upto <= one_launch || sorted_upto >= GGR_TSORT_CAP_SMALL) {
-            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, pair_list, sorted_upto, upto, s, 1);
+            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, pair_list, sorted_upto, upto, s, 1, g.counters + 3);
         } else {
-            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, pair_list, sorted_upto, GGR_TSORT_CAP_SMALL, s, 0);
-            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, pair_list, GGR_TSORT_CAP_SMALL, upto, s, 1);
+            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, pair_list, sorted_upto, GGR_TSORT_CAP_SMALL, s, 0, g.counters + 3);
+            ggr::launch_tile_depth_sort(tiles, im.ranges, point_list, pair_list, GGR_TSORT_CAP_SMALL, upto, s, 1, g.counters + 3);
         }
         sorted_upto = upto;
     };
@@ -730,7 +730,10 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
             // … which also leaves the status word's overflow bit standing: cleared below
         }
         if (cut || too_long) {
-            if (!too_long) HIP_TRY(hipMemsetAsync(g.counters + 1, 0, 4, s));   // the frame is complete after all (ggr_forward_status)
+            if (!too_long) {
+                HIP_TRY(hipMemsetAsync(g.counters + 1, 0, 4, s));   // the frame is complete after all (ggr_forward_status)
+                HIP_TRY(hipMemsetAsync(g.counters + 3, 0, 4, s));   // (the per-tile sort below counts its slow route anew)
+            }
             scatter_pass(per_tile, 0xFFFFFFFFu, longest);
             KCHECK(dbg, s, "tile_list_scatter (repair)");
         } else if (unsorted_left) {
@@ -887,6 +890,15 @@ int ggr_camera_setup(int32_t n, const float* extrinsics, const float* intrinsics
     ggr::launch_camera_setup(n, extrinsics, intrinsics, near, far, scale_invariant, viewmatrix, projmatrix, campos,
                              tanfov, scale, (hipStream_t)stream);
     KCHECK(false, (hipStream_t)stream, "camera_setup");
+    return GGR_OK;
+}
+
+int ggr_sort_stats_async(const void* geom_buffer, int32_t P, uint32_t* host_words, void* stream) {
+    g_err[0] = 0;
+    if (!geom_buffer || !host_words) return fail(GGR_E_INVALID, "null geom buffer / destination");
+    GeomLayout g = ggr_carve_geom((void*)geom_buffer, (size_t)(P > 0 ? P : 0));
+    // (the counters' place in the buffer depends on P alone: whether the forward was an inference one does not matter)
+    HIP_TRY(hipMemcpyAsync(host_words, g.counters, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return GGR_OK;
 }
 

@@ -413,7 +413,9 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
 // (others are left alone; max_len <= GGR_TSORT_CAP_LARGE)
 void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* pair_list, uint32_t min_len,
                             uint32_t max_len, hipStream_t s, int copy_longer /*1: lists longer than max_len are copied out
-                            unsorted (the last launch of a forward: the blend must find valid ids)*/);
+                            unsorted (the last launch of a forward: the blend must find valid ids)*/,
+                            uint32_t* lsd_entries = nullptr /*+= the entries of the lists that took the kernel's slow route
+                            (depths clustered in few buckets; tile_sort.h)*/);
 
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,

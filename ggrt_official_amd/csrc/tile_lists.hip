@@ -253,6 +253,7 @@ bin_group_prefix_kernel(uint32_t* __restrict__ wsum, uint32_t T, uint32_t nw, ui
         total_out[0] = n_all;
         total_out[1] = (n_all > capacity ? 1u : 0u) | (fault << 1) | (n_longest > list_limit ? 8u : 0u);
         total_out[2] = n_longest;
+        total_out[3] = 0u;   // (the per-tile depth sort counts the entries of its slow route here: tile_sort.h)
         if (host_total) {
             host_total[1] = n_longest;
             __hip_atomic_store(host_total, (fault & 1u) ? GGR_HOST_FAULT_SPIN : fault ? GGR_HOST_FAULT_RANGE : n_all,

@@ -52,7 +52,7 @@ __device__ __forceinline__ void ts_order() {
 // the workgroup must call it (barriers inside); n >= 2.
 template <int Q>
 __device__ __forceinline__ void tile_sort_body(uint32_t* __restrict__ lds, uint32_t cap, uint32_t n, uint32_t* __restrict__ list,
-                                               const uint2* __restrict__ pairs) {
+                                               const uint2* __restrict__ pairs, uint32_t* __restrict__ lsd_entries) {
     // LDS (words), the two routes below laid over each other:
     //   route 1  [ex: cap × (id, key) = 2·cap] [fill: BINS] [starts: BINS]
     //   route 2  [exw: cap]                    [cnt: 4 × BINS] [same: 4 × 64 × u64 = 512]
@@ -174,6 +174,9 @@ __device__ __forceinline__ void tile_sort_body(uint32_t* __restrict__ lds, uint3
     }
     // ---- route 2 (a bucket too large to rank by counting — depths clustered in few buckets): stable LSD passes over evenly
     // split digits.  It relies on the entries arriving in id order (the id-order scatter is stable): equal keys keep it.
+    // (what the frame's tiles of this kind hold is counted: a host that finds most of a frame here does better with the
+    //  global depth sort — ggr_sort_stats_async)
+    if (tid == 0 && lsd_entries) atomicAdd(lsd_entries, n);
     const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     uint32_t p0[Q];
     uint32_t* my_cnt = cnt + wave * GGR_TSORT_BINS;

@@ -35,7 +35,8 @@ namespace ggr {
 template <int Q>
 __global__ void __launch_bounds__(256) GGR_TSORT_WAVES(Q)
 tile_depth_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
-                       const uint2* __restrict__ pair_list, uint32_t min_len, uint32_t cap, int copy_longer) {
+                       const uint2* __restrict__ pair_list, uint32_t min_len, uint32_t cap, int copy_longer,
+                       uint32_t* __restrict__ lsd_entries) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tile = blockIdx.x;
     if (tile >= T) return;
@@ -57,29 +58,29 @@ tile_depth_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* _
         if (n == 1u && tid == 0) list[0] = pairs[0].x;
         return;
     }
-    tile_sort_body<Q>(lds, cap, n, list, pairs);
+    tile_sort_body<Q>(lds, cap, n, list, pairs, lsd_entries);
 }
 
 template <int Q>
 static void launch_tsort_class(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* keys, uint32_t min_len,
-                               uint32_t cap, int copy_longer, hipStream_t s) {
+                               uint32_t cap, int copy_longer, uint32_t* lsd_entries, hipStream_t s) {
     const size_t lds = (size_t)tsort_lds_words(cap) * 4;
     if (lds > 64 * 1024)   // (a workgroup may take the CU's whole 160 KB, but beyond 64 KB it has to be asked for)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_depth_sort_kernel<Q>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(tile_depth_sort_kernel<Q>, dim3((unsigned)T), dim3(256), lds, s, (uint32_t)T, ranges, point_list, keys,
-                       min_len, cap, copy_longer);
+                       min_len, cap, copy_longer, lsd_entries);
 }
 
 void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* keys, uint32_t min_len,
-                            uint32_t max_len, hipStream_t s, int copy_longer) {
+                            uint32_t max_len, hipStream_t s, int copy_longer, uint32_t* lsd_entries) {
     if (T == 0 || max_len == 0u || max_len <= min_len) return;   // (a list of ONE entry is still copied out of the pairs)
     const uint32_t cap = std::min<uint32_t>((max_len + 255u) & ~255u, GGR_TSORT_CAP_LARGE);   // the exchange buffer of the launch
     // the class = rounds per wave the registers hold: 8 (lists up to 2048: 6 workgroups per CU), 12 (3072), 16 (4096), 32 (8192)
-    if (cap <= 2048) launch_tsort_class<8>(T, ranges, point_list, keys, min_len, cap, copy_longer, s);
-    else if (cap <= 3072) launch_tsort_class<12>(T, ranges, point_list, keys, min_len, cap, copy_longer, s);
-    else if (cap <= 4096) launch_tsort_class<16>(T, ranges, point_list, keys, min_len, cap, copy_longer, s);
-    else launch_tsort_class<32>(T, ranges, point_list, keys, min_len, cap, copy_longer, s);
+    if (cap <= 2048) launch_tsort_class<8>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s);
+    else if (cap <= 3072) launch_tsort_class<12>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s);
+    else if (cap <= 4096) launch_tsort_class<16>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s);
+    else launch_tsort_class<32>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s);
 }
 
 }  // namespace ggr

@@ -168,6 +168,7 @@ def set_list_hint(enabled: bool) -> bool:
         prev, _HINTS_ON = _HINTS_ON, bool(enabled)
         if not enabled:
             _hints.clear()
+            _sort_watch.clear()
     return prev
 
 
@@ -190,6 +191,7 @@ def clear_list_hints() -> None:
     """Forgets every shape's list-size history (the next forward of each shape runs in upstream's order)."""
     with _hint_lock:
         _hints.clear()
+        _sort_watch.clear()
 
 
 def _scissor_key(rs):
@@ -257,6 +259,66 @@ def _forward_with_guess(call, fout, holder, lib, dev, W, H, key, user_capacity, 
     _note_rendered(key, int(fout.num_rendered), int(fout.max_list_len))
     if guess == 0:
         _hint_stats["exact"] += 1
+
+
+# ---- which depth sort "auto" means for a shape ----------------------------------------------------------------------------------
+# The library's AUTO picks the per-tile sort from sizes alone (csrc/api.hip).  What it cannot see is how the depths are
+# spread: tiles whose depth keys cluster in few buckets (a surface in front of a background) take the sort kernel's slow route,
+# and a frame made of such tiles renders faster through the global sort (NOTES r6 "clustered depths": forward 0.46-0.53 against
+# 0.39 ms at C3's sizes).  The sort kernel counts the entries of those tiles; the host looks at the count now and then —
+# ggr_sort_stats_async: a 16-byte copy queued behind the forward, read at a LATER call of the shape, never waited for — and
+# keeps a shape whose frames are mostly of that kind on the global sort for a while.  A hint like the list sizes: no result
+# depends on it.  Off with GGR_LIST_HINT=0 / set_list_hint(False), with an explicit depth_sort, or with GGR_DEPTH_SORT set.
+_SORT_LOOK_EVERY = 64      # after a shape's first two per-tile forwards: every 64th
+_SORT_KEEP_GLOBAL = 256    # calls for which a shape then stays on the global sort before the per-tile one is tried again
+_SORT_SLOW_SHARE = 0.30    # share of a frame's list entries in slow-route tiles from which the global sort is chosen
+_sort_watch: dict = {}
+
+
+def _sort_choice(key, rs, st) -> None:
+    """Before a forward: reads a finished look at an earlier frame of this shape, and turns AUTO into GLOBAL while the shape
+    is known to cluster."""
+    if not _HINTS_ON or st.depth_sort != _lib.DEPTH_SORT["auto"] or os.environ.get("GGR_DEPTH_SORT"):
+        return
+    with _hint_lock:
+        if len(_sort_watch) > 256 and key not in _sort_watch:
+            _sort_watch.clear()
+        w = _sort_watch.setdefault(key, {"calls": 0, "global_until": 0, "pending": None, "words": None, "slow_share": None})
+        pend = w["pending"]
+        if pend is not None and pend[0].query():
+            w["pending"] = None
+            n, slow = int(w["words"][0]), int(w["words"][3])
+            if n > 0:
+                w["slow_share"] = slow / n
+                if slow > _SORT_SLOW_SHARE * n:
+                    w["global_until"] = w["calls"] + _SORT_KEEP_GLOBAL
+        w["calls"] += 1
+        if w["calls"] <= w["global_until"]:
+            st.depth_sort = _lib.DEPTH_SORT["global"]
+
+
+def _sort_look(key, lib, fout, geom, rows: int, stream: int) -> None:
+    """Behind a forward that sorted per tile: now and then, the 16-byte copy of its counters (read by a later `_sort_choice`)."""
+    if int(fout.depth_sort_used) != _lib.DEPTH_SORT["per_tile"]:
+        return
+    with _hint_lock:
+        w = _sort_watch.get(key)
+        if w is None or w["pending"] is not None or (w["calls"] > 2 and w["calls"] % _SORT_LOOK_EVERY):
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if w["words"] is None:
+            w["words"] = torch.zeros(4, dtype=torch.int32).pin_memory()
+        _check(lib.ggr_sort_stats_async(geom.data_ptr(), rows, w["words"].data_ptr(), stream), "ggr_sort_stats_async")
+        ev = torch.cuda.Event()
+        ev.record()
+        w["pending"] = (ev, geom)   # (the buffer stays referenced until the copy has run)
+
+
+def sort_watch_stats() -> dict:
+    """{shape key: (calls, share of the last looked-at frame's entries in slow-route tiles or None, calls left on the global sort)}"""
+    with _hint_lock:
+        return {k: (w["calls"], w["slow_share"], max(0, w["global_until"] - w["calls"])) for k, w in _sort_watch.items()}
 
 
 _sh_warned = False
@@ -383,9 +445,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             if prof is not None:
                 fout.stage_ms = C.cast(prof.fwd, C.c_void_p)
                 prof.fwd_calls += 1
+            key = (dev.index, P, W, H, 1, _scissor_key(rs))
+            _sort_choice(key, rs, st)
             _forward_with_guess(lambda: lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream),
-                                fout, holder, lib, dev, W, H, (dev.index, P, W, H, 1, _scissor_key(rs)),
-                                capacity, prof is not None)
+                                fout, holder, lib, dev, W, H, key, capacity, prof is not None)
+            _sort_look(key, lib, fout, geom, P, stream)
 
         # exact mode: count known, nothing to keep.  Sync-free mode: count + flags live in the geometry buffer on the
         # device, so that (≈100 MB at P = 1 M) buffer stays referenced until this thread's next forward
@@ -561,10 +625,12 @@ class _RasterizeViews(torch.autograd.Function):
             if prof is not None:
                 fout.stage_ms = C.cast(prof.fwd, C.c_void_p)
                 prof.fwd_calls += 1
+            key = (dev.index, P, W, H, V, _scissor_key(rs))
+            _sort_choice(key, rs, st)
             _forward_with_guess(lambda: lib.ggr_forward_views(C.byref(st), C.byref(vw), C.byref(fin), C.byref(fout), cb,
                                                               None, stream),
-                                fout, holder, lib, dev, W, H, (dev.index, P, W, H, V, _scissor_key(rs)),
-                                capacity, prof is not None)
+                                fout, holder, lib, dev, W, H, key, capacity, prof is not None)
+            _sort_look(key, lib, fout, geom, P * V, stream)
         _tls.last_forward = (geom, P * V) if capacity > 0 else (None, int(fout.num_rendered))
         _tls.last_binning = (int(fout.depth_sort_used), int(fout.max_list_len))
         ctx.raster_settings = rs

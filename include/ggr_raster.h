@@ -347,6 +347,17 @@ int ggr_camera_setup(int32_t n, const float* extrinsics /*[n,4,4] camera-to-worl
 int ggr_forward_status(const void* geom_buffer, int32_t num_points, int64_t* num_rendered, int32_t* overflow,
                        void* stream);
 
+/* How the per-tile depth sort of the forward that filled `geom_buffer` went — WITHOUT a sync: queues a 16-byte copy on
+ * `stream` into `host_words` (4 words of page-locked host memory, valid once everything queued on the stream so far has run):
+ *   [0] num_rendered   [1] status bits (as ggr_forward_status)   [2] the longest tile list
+ *   [3] the list entries of the tiles whose depths cluster in few key buckets — those tiles take the sort kernel's slow
+ *       route (csrc/tile_sort.h, route 2).  0 after a forward that sorted globally.
+ * A frame with most of its entries in [3] renders faster with depth_sort = GGR_DEPTH_SORT_GLOBAL (measured: NOTES r6,
+ * "clustered depths"); AUTO cannot know that before the frame has been sorted once, so the host looks at a frame now and
+ * then and chooses for the next ones of the same shape (ggrt_official_amd/rasterizer.py does: first and second call of a
+ * shape, then every 64th).  No counterpart in the reference. */
+int ggr_sort_stats_async(const void* geom_buffer, int32_t num_points, uint32_t* host_words, void* stream);
+
 /* replaces diff_gaussian_rasterization._C.mark_visible: present[P] (uint8) = view z > 0.2 */
 int ggr_mark_visible(int32_t num_points, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present, void* stream);

@@ -184,6 +184,76 @@ def test_what_auto_picks(monkeypatch):
     assert _state(sparse, "auto")[1][0] == "global" and _state(sparse, "per_tile")[1][0] == "per_tile"
 
 
+def _on_depth_planes(sc, planes=(2.0, 9.0, 25.0), seed=1):
+    """the scene's Gaussians moved along their view rays onto a few planes of EXACTLY equal depth"""
+    g = torch.Generator().manual_seed(seed)
+    z = torch.tensor(planes)[torch.randint(0, len(planes), (sc.means3D.shape[0],), generator=g)]
+    s = z / sc.means3D[:, 2]
+    sc.means3D *= s[:, None]
+    sc.cov3D *= (s * s)[:, None]
+    return sc
+
+
+def test_clustered_depths_send_a_shape_back_to_the_global_sort(monkeypatch):
+    """Depths that cluster (planes: every tile's keys fall into two or three buckets) send the per-tile sort down its slow
+    route; the sort counts those entries (ggr_sort_stats_async word 3) and the host keeps such a shape on the global sort —
+    same lists either way.  A frame of spread-out depths stays per tile."""
+    import ggrt_official_amd
+    from ggrt_official_amd.rasterizer import clear_list_hints, sort_watch_stats
+    monkeypatch.delenv("GGR_DEPTH_SORT", raising=False)
+    clear_list_hints()
+    P, W, H = 150000, 1280, 720
+    planes = _on_depth_planes(make_scene(P, W, H, sh_degree=0, profile="A", seed=40))
+    ref, how = _state(planes, "global")
+    assert how[0] == "global"
+    used = []
+    for _ in range(4):
+        out, how = _state(planes, "auto")
+        torch.cuda.synchronize()   # (the look at the frame is a copy queued behind it: let it land before the next call)
+        used.append(how[0])
+        _same_lists(out, ref)
+    (calls, share, left), = sort_watch_stats().values()
+    assert used[0] == "per_tile" and used[-1] == "global", used
+    assert calls == 4 and share > 0.5 and left > 200
+    # the explicit setting is not overruled
+    assert _state(planes, "per_tile")[1][0] == "per_tile"
+    # spread-out depths: nothing to go back for
+    clear_list_hints()
+    spread = make_scene(P, W, H, sh_degree=0, profile="A", seed=41)
+    for _ in range(4):
+        how = _state(spread, "auto")[1]
+        torch.cuda.synchronize()
+        assert how[0] == "per_tile"
+    (calls, share, left), = sort_watch_stats().values()
+    assert share is not None and share < 0.05 and left == 0
+    # the raw words, through the C ABI: N, status, longest list, slow-route entries
+    from ggrt_official_amd import _lib
+    lib = _lib.load()
+    st = debug_state_geom(spread)
+    words = torch.zeros(4, dtype=torch.int32).pin_memory()
+    assert lib.ggr_sort_stats_async(st["geom"].data_ptr(), P, words.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert int(words[0]) == st["num_rendered"] and int(words[2]) == st["longest"] and 0 <= int(words[3]) <= int(words[0])
+    assert ggrt_official_amd.sort_watch_stats is sort_watch_stats
+
+
+def debug_state_geom(sc):
+    """one per-tile forward through the module, its geometry buffer kept"""
+    from ggrt_official_amd.rasterizer import _RasterizeGaussians, last_forward_binning
+
+    class Ctx:
+        needs_input_grad = (True,)
+        def set_materialize_grads(self, v): pass
+        def save_for_backward(self, *t): self.saved = t
+        def mark_non_differentiable(self, *t): pass
+    s = sc.to("cuda:0")
+    rs = s.settings()._replace(depth_sort="per_tile")
+    ctx = Ctx()
+    _RasterizeGaussians.forward(ctx, s.means3D, torch.zeros_like(s.means3D), s.shs, None, s.opacities, None, None, s.cov3D,
+                                rs.viewmatrix, rs.projmatrix, rs.campos, None, rs)
+    return {"geom": ctx.saved[12], "num_rendered": ctx.num_rendered, "longest": last_forward_binning()[1]}
+
+
 def test_views_and_sets_per_tile_equal_global():
     from ggrt_official_amd.rasterizer import rasterize_views
     from ggrt_official_amd.synthetic import camera_matrices
