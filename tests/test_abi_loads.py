@@ -181,6 +181,7 @@ def test_error_paths_return_codes_and_messages_without_touching_a_gpu():
     assert lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, None) != 0 and err()
     assert lib.ggr_camera_setup(2, None, None, None, None, 1, None, None, None, None, None, None) != 0 and err()
     assert lib.ggr_forward_status(None, 4, None, None, None) != 0 and err()
+    assert lib.ggr_sort_stats_async(None, 4, None, None) != 0 and err()
     # a successful query clears nothing it should not: size queries never fail
     assert lib.ggr_geom_bytes(0) > 0 and lib.ggr_backward_scratch_bytes(0) > 0
 
