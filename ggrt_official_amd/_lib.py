@@ -108,6 +108,7 @@ SYMBOLS = [
     ("ggr_mark_visible", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ggr_debug_readback_wait", C.c_int, [C.c_int32, C.c_double, C.POINTER(C.c_uint32)]),
     ("ggr_debug_counters", C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),
+    ("ggr_debug_host_slots", C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("ggr_debug_copy", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     ("ggr_debug_unpack_geom", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),

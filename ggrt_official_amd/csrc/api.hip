@@ -3,10 +3,12 @@
 // Replaces `RasterizeGaussiansCUDA` / `RasterizeGaussiansBackwardCUDA` of the extension GGRt
 // imports at reference ggrt/model/pixelsplat/decoder/cuda_splatting.py:6-9.
 // No global mutable state: the only statics are thread_local — an error string and, per device, one pinned word +
-// one event for the num_rendered read-back.
+// one event for the num_rendered read-back, a side stream — handed back to a process-wide pool when the thread ends (below).
 #include "../../include/ggr_raster.h"
 #include "ggr_common.h"
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -100,9 +102,44 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
     return GGR_OK;
 }
 
+// Per host thread and device: the library's two small host-side resources (the read-back slot and the side stream below).
+// A thread OWNS its slot while it lives — no lock on the forward's path — and hands it back to a process-wide pool when it
+// ends, without a HIP call (a thread_local destructor can run after the HIP runtime is gone): the next thread that needs
+// one for that device takes it from the pool, so short-lived host threads (autograd workers, data-loader threads that
+// render) reuse a handful of slots instead of leaking a pinned line, a stream and six events each.  The pool
+// itself is never destroyed (static destruction order).
+#define GGR_MAX_DEVICES 64
+template <class T>
+struct SlotPool {
+    std::mutex mu;
+    std::vector<T*> free_slots[GGR_MAX_DEVICES];
+    int created = 0;   // slots ever allocated (ggr_debug_host_slots)
+    static SlotPool& get() { static SlotPool* p = new SlotPool; return *p; }
+};
+template <class T>
+struct ThreadSlots {
+    T* slot[GGR_MAX_DEVICES] = {};
+    ~ThreadSlots() {
+        SlotPool<T>& pool = SlotPool<T>::get();
+        std::lock_guard<std::mutex> lk(pool.mu);
+        for (int d = 0; d < GGR_MAX_DEVICES; d++)
+            if (slot[d]) pool.free_slots[d].push_back(slot[d]);
+    }
+    // this thread's slot for the current device (nullptr: no current device, or its index is beyond GGR_MAX_DEVICES)
+    T* current() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GGR_MAX_DEVICES) { (void)hipGetLastError(); return nullptr; }
+        if (!slot[dev]) {
+            SlotPool<T>& pool = SlotPool<T>::get();
+            std::lock_guard<std::mutex> lk(pool.mu);
+            if (!pool.free_slots[dev].empty()) { slot[dev] = pool.free_slots[dev].back(); pool.free_slots[dev].pop_back(); }
+            else { slot[dev] = new T; pool.created++; }
+        }
+        return slot[dev];
+    }
+};
 // per host thread and device: one pinned word + one event for the num_rendered read-back of the exact mode (a
-// thread has at most one forward between its launch and its sync, so the slot is never shared; never freed — a
-// thread_local destructor could run after the HIP runtime is gone)
+// thread has at most one forward between its launch and its sync, so the slot is never shared)
 #define GGR_READBACK_ARMED GGR_HOST_ARMED  // (counts stop at 0x7FFFFFFF; GGR_HOST_FAULT_* report a sort fault)
 struct ReadbackSlot {
     uint32_t* host = nullptr;
@@ -110,10 +147,10 @@ struct ReadbackSlot {
     hipEvent_t ev_start = nullptr;  // in front of the tile-list kernels: the wait's time bound starts here
 };
 ReadbackSlot* readback_slot() {
-    static thread_local ReadbackSlot slots[32];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    ReadbackSlot& r = slots[dev];
+    static thread_local ThreadSlots<ReadbackSlot> slots;
+    ReadbackSlot* rp = slots.current();
+    if (!rp) return nullptr;
+    ReadbackSlot& r = *rp;
     if (!r.host) {
         void* p = nullptr;
         // coherent (fine-grained) on purpose: the kernel's system-scope store must become visible to the spinning
@@ -195,10 +232,10 @@ bool side_stream_is_concurrent(SideStream& r, hipStream_t s, hipStream_t cand) {
     return ok;
 }
 SideStream* side_stream(hipStream_t caller) {
-    static thread_local SideStream slots[32];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    SideStream& r = slots[dev];
+    static thread_local ThreadSlots<SideStream> slots;
+    SideStream* rp = slots.current();
+    if (!rp) return nullptr;
+    SideStream& r = *rp;
     if (r.failed) return nullptr;
     if (!r.fork) {
         bool ok = hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
@@ -252,9 +289,9 @@ int colour_grid_blocks(size_t pairs) {
     const int forced = (e_blocks && *e_blocks) ? atoi(e_blocks) : -1;
     // (the CU count of the CURRENT device, looked up once per device — ADVICE r5: a process that drives several devices must
     //  not throttle all of them by the first one's count)
-    static int cus_of[32] = {0};
+    static int cus_of[GGR_MAX_DEVICES] = {0};
     int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32) {
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < GGR_MAX_DEVICES) {
         int c = __atomic_load_n(&cus_of[dev], __ATOMIC_RELAXED);
         if (c == 0) {
             hipDeviceProp_t prop;
@@ -967,6 +1004,13 @@ int ggr_debug_counters(uint64_t* out, int32_t reset) {
 #else
     return fail(GGR_E_INVALID, "this library was built without -DGGR_DEV_COUNTERS: the counters are zero");
 #endif
+}
+
+int ggr_debug_host_slots(int32_t* readback_slots, int32_t* side_streams) {
+    g_err[0] = 0;
+    if (readback_slots) { SlotPool<ReadbackSlot>& p = SlotPool<ReadbackSlot>::get(); std::lock_guard<std::mutex> lk(p.mu); *readback_slots = p.created; }
+    if (side_streams) { SlotPool<SideStream>& p = SlotPool<SideStream>::get(); std::lock_guard<std::mutex> lk(p.mu); *side_streams = p.created; }
+    return GGR_OK;
 }
 
 int ggr_debug_copy(const void* src, void* dst, size_t bytes, int32_t blocks, void* stream) {

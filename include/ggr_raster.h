@@ -394,6 +394,12 @@ int ggr_debug_copy(const void* src, void* dst, size_t bytes, int32_t blocks, voi
  * entry) slots that survived, slots without a single valid pixel, valid (slot, pixel) pairs, batches culled.  Synchronises the device. */
 int ggr_debug_counters(uint64_t* out /*[8]*/, int32_t reset);
 
+/* Host-side slots the library has EVER allocated in this process (no counterpart in the reference): read-back slots (a pinned
+ * line + two events each) and side-stream slots (a stream + four events each).  A host thread owns one of each per device it
+ * renders on and returns them to a process-wide pool when it ends, so the numbers follow the largest number of threads that
+ * rendered AT THE SAME TIME, not the number of threads that ever did.  Either pointer may be NULL.  No GPU work. */
+int ggr_debug_host_slots(int32_t* readback_slots, int32_t* side_streams);
+
 #ifdef __cplusplus
 }
 #endif

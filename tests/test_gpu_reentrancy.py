@@ -70,3 +70,54 @@ def test_two_backwards_over_one_forward():
     for a, b, c in zip(g1, g2, g3):
         assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
         assert rel_l2(c.cpu().numpy(), 2.0 * a.cpu().numpy()) < 1e-5
+
+
+def test_short_lived_threads_reuse_the_host_slots():
+    """A host thread owns a read-back slot (pinned line + events) and, with the global depth sort, a side-stream slot per
+    device; when it ends they go back to a process-wide pool (api.hip SlotPool): twelve threads that render one
+    after the other must not allocate twelve of each — and what they render is what the main thread renders."""
+    import ctypes as C
+    from ggrt_official_amd import _lib
+    lib = _lib.load()
+
+    def slots():
+        a, b = C.c_int32(0), C.c_int32(0)
+        assert lib.ggr_debug_host_slots(C.byref(a), C.byref(b)) == 0
+        return a.value, b.value
+
+    sc = make_scene(8000, 160, 120, sh_degree=3, seed=5).to(dev)
+    dL = upstream_gradient(sc.width, sc.height, seed=6, device=dev)
+    import os
+    old = os.environ.get("GGR_DEPTH_SORT")
+    os.environ["GGR_DEPTH_SORT"] = "global"     # the form that uses the side stream
+    try:
+        ref = _fwd_bwd(sc, dL)
+        torch.cuda.synchronize()
+        before = slots()
+        out, errors = [], []
+
+        def work():
+            try:
+                out.append(_fwd_bwd(sc, dL))
+                torch.cuda.synchronize()
+            except Exception as e:                       # pragma: no cover
+                errors.append(repr(e))
+
+        for _ in range(12):
+            t = threading.Thread(target=work)
+            t.start()
+            t.join()
+        assert not errors, errors
+        after = slots()
+    finally:
+        if old is None:
+            os.environ.pop("GGR_DEPTH_SORT", None)
+        else:
+            os.environ["GGR_DEPTH_SORT"] = old
+    # (the forward runs on the thread itself, the backward on autograd's worker thread, which lives on: at most a slot or
+    #  two beyond the main thread's, never one per thread)
+    assert after[0] - before[0] <= 2 and after[1] - before[1] <= 2, (before, after)
+    for c1, r1, g1 in out:
+        assert torch.equal(ref[0], c1) and torch.equal(ref[1], r1)
+        for a, b in zip(ref[2], g1):
+            assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
