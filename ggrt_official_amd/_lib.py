@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libggr_raster.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -71,7 +71,9 @@ class GgrBackwardOut(C.Structure):
     ]
 
 FWD_STAGES = ["preprocess", "depth_sort", "tile_count", "tile_scatter", "blend", "colour_side_stream", "tile_sort"]
-DEPTH_SORT = {"auto": 0, "global": 1, "per_tile": 2}
+DEPTH_SORT = {"auto": 0, "global": 1, "per_tile": 2, "global_3pass": 0x101}
+DEPTH_SORT_NO_BUCKETS = 0x100      # IN flag: never the global sort's bucket form (include/ggr_raster.h)
+DEPTH_SORT_FELL_BACK = 0x201       # OUT: the bucket form gave a frame up; its lists were built again in three passes
 BWD_STAGES = ["clear", "blend", "preprocess"]
 
 

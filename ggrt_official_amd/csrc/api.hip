@@ -86,8 +86,8 @@ int validate(const GgrSettings* st, const GgrForwardIn* in) {
                     "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
     if (st->sh_max_degree != 0 && st->sh_max_degree != 3 && st->sh_max_degree != 4)
         return fail(GGR_E_INVALID, "sh_max_degree must be 0 (default), 3 or 4");
-    if (st->depth_sort < GGR_DEPTH_SORT_AUTO || st->depth_sort > GGR_DEPTH_SORT_PER_TILE)
-        return fail(GGR_E_INVALID, "depth_sort must be 0 (auto), 1 (global) or 2 (per tile)");
+    if ((st->depth_sort & ~GGR_DEPTH_SORT_NO_BUCKETS) < GGR_DEPTH_SORT_AUTO || (st->depth_sort & ~GGR_DEPTH_SORT_NO_BUCKETS) > GGR_DEPTH_SORT_PER_TILE)
+        return fail(GGR_E_INVALID, "depth_sort must be 0 (auto), 1 (global) or 2 (per tile), optionally | GGR_DEPTH_SORT_NO_BUCKETS");
     if ((st->scissor[0] | st->scissor[1] | st->scissor[2] | st->scissor[3]) &&
         (st->scissor[0] < 0 || st->scissor[1] < 0 || st->scissor[2] <= st->scissor[0] || st->scissor[3] <= st->scissor[1]))
         return fail(GGR_E_INVALID, "scissor must be x0 < x1, y0 < y1, all >= 0 (or all zero for none)");
@@ -486,10 +486,17 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     const bool hinted = sync_free && out->capacity_is_hint != 0;   // exact mode with a guessed buffer: N is awaited at the END
     if (out->binning_capacity >= 0x7FFFFFFF) return fail(GGR_E_LIMIT, "binning_capacity too large");
     int depth_sort = st->depth_sort;
+    // The global sort has two forms (binning.hip): three stable passes, or ONE partition pass into depth buckets + every bucket
+    // sorted in LDS.  The bucket form can meet a bucket it cannot sort (> 8192 different keys inside 1/4096 of the frame's
+    // depth range): it says so through the read-back and the call then sorts again in three passes — so it needs a read-back,
+    // like the per-tile form.  GGR_DEPTH_SORT_NO_BUCKETS (or GGR_GLOBAL_SORT=3pass) keeps the three passes.
+    bool three_pass = (depth_sort & GGR_DEPTH_SORT_NO_BUCKETS) != 0;
+    depth_sort &= ~GGR_DEPTH_SORT_NO_BUCKETS;
     if (const char* e = getenv("GGR_DEPTH_SORT")) {   // dev / A-B override of AUTO (read per call): "global" | "per_tile"
         if (depth_sort == GGR_DEPTH_SORT_AUTO && *e)
             depth_sort = (*e == 'g' || *e == '1') ? GGR_DEPTH_SORT_GLOBAL : (*e == 'p' || *e == '2') ? GGR_DEPTH_SORT_PER_TILE : depth_sort;
     }
+    if (const char* e = getenv("GGR_GLOBAL_SORT")) { if (*e == '3' || *e == 'l') three_pass = true; }   // dev / A-B: "3pass" | "buckets"
     // AUTO: per tile where its lists are short — at most 256 (view, Gaussian) pairs per tile on average (a 1080p frame with 1 M
     // Gaussians: 123; its longest list: 1 100 entries) and, when the caller knows, a longest list of at most 4096 entries — and
     // the call has a read-back to fall back with.  Measured (NOTES r6, fwd+bwd): C3 0.78 against 0.80 ms, 200 k Gaussians at
@@ -500,7 +507,8 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         depth_sort = ((!sync_free || hinted) && (size_t)P <= 256 * tiles && len_hint_in <= 4096) ? GGR_DEPTH_SORT_PER_TILE
                                                                                              : GGR_DEPTH_SORT_GLOBAL;
     bool per_tile = depth_sort == GGR_DEPTH_SORT_PER_TILE && P > 0 && tiles > 0;
-    out->depth_sort_used = per_tile ? GGR_DEPTH_SORT_PER_TILE : GGR_DEPTH_SORT_GLOBAL;
+    const bool buckets = !three_pass && (!sync_free || hinted) && P > 0 && ggr::radix_sort_buckets_ok((size_t)P / segs);
+    out->depth_sort_used = per_tile ? GGR_DEPTH_SORT_PER_TILE : buckets ? GGR_DEPTH_SORT_GLOBAL : GGR_DEPTH_SORT_GLOBAL_3PASS;
     const uint32_t len_hint = len_hint_in;
     out->max_list_len = -1;
 
@@ -588,13 +596,13 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // 2. stable sort of the Gaussians by depth bits (ties keep ascending id).  Its last pass also drops every
     //    Gaussian's tile rect at its sorted position (into the tile-list work area) and clears the per-tile totals.
     uint32_t *dk = nullptr, *order = nullptr;
-    auto global_sort = [&](bool area_cleared) {
+    auto global_sort = [&](bool area_cleared, bool bucket_form) {
         // (preprocess already wrote the keys into g.keys_a; the values are the identity, formed by the sort's first pass)
         ggr::radix_sort_pairs(g.keys_a, g.keys_b, g.vals_a, g.vals_b, g.hist, (size_t)P, (uint32_t)segs, &dk, &order, s,
                               /*hist_zeroed=*/area_cleared /*by preprocess_fwd*/,
                               /*block_max_ready=*/(uint32_t)((P1 + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS) * (uint32_t)vs.sets /*likewise*/,
                               /*identity_vals=*/true /*preprocess_fwd writes no values: the first pass forms them*/,
-                              g.rect, rect_sorted, totals_area, totals_words);
+                              g.rect, rect_sorted, totals_area, totals_words, bucket_form);
     };
     // 3. per-(chunk, tile) counts → list positions, tile ranges, num_rendered (+ the longest list)
     auto count_pass = [&](bool id_order, bool to_host) {
@@ -649,6 +657,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     };
     // what the host word(s) said: N, or a fault; the longest list
     uint32_t num_rendered = 0, longest = 0;
+    bool bucket_fault = false;   // the depth sort's bucket form left a bucket unsorted: the lists must be built again
     auto read_counts = [&]() -> int {
         if (rb) {
             // the single host sync of forward.  N is written by the FIRST block of the last tile-list kernel: the host
@@ -657,12 +666,15 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
                                          query_event, (void*)rb->ev_start);
             if (rc != GGR_OK) return rc;
             longest = ((volatile uint32_t*)rb->host)[1];   // (stored before N's release store)
+            bucket_fault = (longest >> 31) != 0u;
+            longest &= 0x7FFFFFFFu;
         } else {   // no pinned slot (hipHostMalloc / hipEventCreate failed): copy + sync — a frame is never returned unchecked
             uint32_t w4[4] = {0u, 0u, 0u, 0u};
             HIP_TRY(hipMemcpyAsync(w4, g.counters, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             num_rendered = (w4[1] & 2u) ? GGR_HOST_FAULT_SPIN : (w4[1] & 4u) ? GGR_HOST_FAULT_RANGE : w4[0];
             longest = w4[2];
+            bucket_fault = (w4[1] & 16u) != 0u;
         }
         // raised by the tile-list kernel that writes N (bin_group_prefix_kernel)
         if (num_rendered == GGR_HOST_FAULT_SPIN) return fail(GGR_E_HIP, "%s", kSpinFault);
@@ -676,10 +688,10 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // the sort's last pass clears the totals; its own work area was left untouched by preprocess_fwd)
     bool rebuilt = false;
     auto rebuild_global = [&]() {
+        out->depth_sort_used = per_tile ? GGR_DEPTH_SORT_GLOBAL_3PASS : GGR_DEPTH_SORT_GLOBAL_FELL_BACK;
         per_tile = false;
         rebuilt = true;
-        out->depth_sort_used = GGR_DEPTH_SORT_GLOBAL;
-        global_sort(/*area_cleared=*/false);
+        global_sort(/*area_cleared=*/false, /*bucket_form=*/false);
         tm.mark(GGR_FWD_DEPTH_SORT);
         count_pass(/*id_order=*/false, /*to_host=*/false);
         tm.mark(GGR_FWD_TILE_COUNT);
@@ -687,7 +699,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
 
     if (P > 0 && tiles > 0) {
         if (!per_tile) {
-            global_sort(/*area_cleared=*/true);
+            global_sort(/*area_cleared=*/true, buckets);
             KCHECK(dbg, s, "depth sort");
         }
         tm.mark(GGR_FWD_DEPTH_SORT);
@@ -710,7 +722,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         if (P > 0 && tiles > 0) { const int rc = read_counts(); if (rc != GGR_OK) return rc; }
         else { out->num_rendered = 0; out->max_list_len = 0; }
         tm.mark(GGR_FWD_TILE_COUNT);
-        if (per_tile && longest > GGR_TSORT_CAP_LARGE) rebuild_global();
+        if ((per_tile && longest > GGR_TSORT_CAP_LARGE) || (!per_tile && bucket_fault)) rebuild_global();
         // 2nd call: kept for backward (per tile: + the (id, key) scratch on its tail)
         void* bin_mem = alloc(alloc_ctx, ggr_point_list_bytes(num_rendered) + (per_tile ? ggr_pair_list_bytes(num_rendered) : 0));
         if (!bin_mem) return fail(GGR_E_ALLOC, "binning allocator returned NULL");
@@ -741,7 +753,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         out->num_rendered = 0;
         { const int rc = read_counts(); if (rc != GGR_OK) return rc; }
         const bool cut = num_rendered > capacity;
-        const bool too_long = per_tile && longest > GGR_TSORT_CAP_LARGE;
+        const bool too_long = (per_tile && longest > GGR_TSORT_CAP_LARGE) || (!per_tile && bucket_fault);   // → the lists once more, three-pass global sort
         const bool unsorted_left = per_tile && !too_long && longest > sorted_upto;   // the length guess was too small
         if (cut) {
             // The guess did not hold.  Everything up to the tile ranges is valid (the counts do not depend on the list

@@ -18,6 +18,7 @@
 // ("onesweep") that ranks stably with ballot-based digit matching + per-wave digit counters in LDS, scans the
 // digit totals itself (no separate scan launch) and obtains its tile's global offsets by decoupled look-back.
 #include "ggr_common.h"
+#include <algorithm>
 
 namespace ggr {
 
@@ -43,8 +44,7 @@ namespace ggr {
 #ifndef GGR_LOOKBACK
 #define GGR_LOOKBACK 8
 #endif
-#define GGR_FAULT_SPIN 1u   // a look-back spin hit its bound
-#define GGR_FAULT_RANGE 2u  // a key needs more than 3 × 10 bits (depth ≥ 6.8e37)
+// (GGR_FAULT_SPIN / _RANGE / _BUCKET: ggr_common.h)
 
 #ifdef GGR_SORT_PROBE  // dev build (tools/sort_bench.hip): per-tile phase timestamps, 100 MHz constant clock
 __device__ unsigned long long ggr_probe[3][8][2048];
@@ -132,18 +132,94 @@ radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per 
     }
 }
 
+// ---- the BUCKET form (round 6) -------------------------------------------------------------------------------------------------
+// Three dependent onesweep passes are three look-back chains and three launch floors for 8 MB of keys (78-105 µs per million keys,
+// 0.06 of the HBM roofline: NOTES r5).  The bucket form keeps ONE of them: a stable partition of the keys into <= 1024 depth
+// buckets per segment, then every bucket sorted by (key, id) in LDS by one workgroup — the per-tile sort's routine
+// (tile_sort.h), whose fast route ranks an entry among the few members of its sub-bucket.  The buckets are made EQUALLY FULL,
+// whatever the depth distribution: this kernel takes a 4096-bin histogram of the frame's own key range [kmin, kmax] (from the
+// preprocess blocks' maxima and minima; the culled Gaussians — key 0 — are counted apart), and every block of the partition
+// pass turns it into splitters: consecutive fine bins are merged into a bucket until it holds `target` keys.  A bucket that
+// still exceeds what a workgroup sorts (GGR_TSORT_CAP_LARGE keys inside ONE fine bin = 1/4096 of the frame's depth range) is
+// copied out as it is when all its keys are equal (a plane of constant depth: the stable partition left it in id order) and
+// raises GGR_FAULT_BUCKET otherwise: the caller sorts again with the three-pass form.
+__global__ void __launch_bounds__(GGR_HIST_THREADS)
+msd_hist_kernel(const uint32_t* __restrict__ keys, size_t n /*keys per segment*/, uint32_t blocks_per_seg,
+                uint32_t* __restrict__ hist, const uint32_t* __restrict__ block_max, const uint32_t* __restrict__ block_min,
+                uint32_t nmax, uint32_t* __restrict__ fine /*[segments][GGR_MSD_FINE_WORDS], zeroed*/) {
+    __shared__ uint32_t h[GGR_MSD_FINE + 1];
+    __shared__ uint32_t wm[GGR_HIST_THREADS / 64], wn[GGR_HIST_THREADS / 64];
+    GGR_CRITICAL_PRIO();
+    const int tid = threadIdx.x;
+    uint32_t ks[GGR_HIST_ITEMS];
+    const uint32_t seg = blockIdx.x / blocks_per_seg, bseg = blockIdx.x - seg * blocks_per_seg;
+    keys += (size_t)seg * n;
+    const size_t base = (size_t)bseg * (GGR_HIST_THREADS * GGR_HIST_ITEMS);
+#pragma unroll
+    for (int u = 0; u < GGR_HIST_ITEMS; u++) {
+        const size_t idx = base + (size_t)u * GGR_HIST_THREADS + tid;
+        ks[u] = idx < n ? keys[idx] : 0xFFFFFFFFu;   // (0xFFFFFFFF marks "no key": real keys are < 2^31)
+    }
+    uint32_t m = 0, mn = 0xFFFFFFFFu;
+    for (uint32_t i0 = 0; i0 < nmax; i0 += 4 * GGR_HIST_THREADS) {
+        uint32_t v[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = min(i0 + u * GGR_HIST_THREADS + tid, nmax - 1);
+            v[u] = block_max[i];
+            w[u] = block_min[i];
+        }
+        m = max(max(m, v[0]), max(v[1], max(v[2], v[3])));
+        mn = min(min(mn, w[0]), min(w[1], min(w[2], w[3])));
+    }
+    for (int x = tid; x < GGR_MSD_FINE + 1; x += GGR_HIST_THREADS) h[x] = 0;
+    m = wave_max_u32(m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    if ((tid & 63) == 0) { wm[tid >> 6] = m; wn[tid >> 6] = mn; }
+    __syncthreads();
+    m = wave_max_u32(wm[tid & (GGR_HIST_THREADS / 64 - 1)]);
+    mn = wn[tid & (GGR_HIST_THREADS / 64 - 1)];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    // (the blocks leave (smallest visible key) − 1, ~0 when they saw none)
+    const uint32_t kmin = mn == 0xFFFFFFFFu ? 1u : mn + 1u;
+    const uint32_t range = m >= kmin ? m - kmin : 0u;
+    const uint32_t nb = range ? 32u - (uint32_t)__builtin_clz(range) : 0u;
+    const uint32_t sh = nb > 12u ? nb - 12u : 0u;       // (range >> sh) < 4096
+    if (tid == 0 && blockIdx.x == 0) {
+        hist[GGR_HIST_PARAMS] = GGR_SORT_MAX_BITS;          // the partition pass ranks on a 10-bit "digit": the bucket
+        hist[GGR_HIST_MSD_KMIN] = kmin;
+        hist[GGR_HIST_MSD_SHIFT] = sh;
+    }
+#pragma unroll
+    for (int u = 0; u < GGR_HIST_ITEMS; u++)
+        if (ks[u] != 0xFFFFFFFFu) atomicAdd(&h[ks[u] == 0u ? (uint32_t)GGR_MSD_FINE : min((ks[u] - kmin) >> sh, (uint32_t)GGR_MSD_FINE - 1u)], 1u);
+    __syncthreads();
+    for (uint32_t x = tid; x < GGR_MSD_FINE + 1; x += GGR_HIST_THREADS) {
+        const uint32_t c = h[x];
+        if (c) atomicAdd(&fine[(size_t)seg * GGR_MSD_FINE_WORDS + x], c);
+    }
+}
+
 // GATHER (last pass of the depth sort only): every pair also carries an 8-byte payload looked up by its value,
 // gather_dst[final position] = gather_src[val] — the tile rect of the Gaussian, so that the tile-list kernels can
 // stream the rects in depth order without a separate gather launch; the pass also clears `zero_area`.
 // ITEMS keys per thread (8 … 16): a sort of a little more than 256 tiles of 4096 keys (GGRt's LLFF eval frame:
 // 1 146 880 Gaussians = 281 tiles on 256 CUs) runs with larger tiles instead of doubling up on 25 CUs.
-template <bool GATHER, int ITEMS>
+// MSD (the bucket form's partition pass; pass = 0, GATHER = false): the "digit" of a key is its BUCKET — 0 for a culled Gaussian
+// (key 0), else 1 + (keys in the fine bins before its own) / target, from the fine histogram `msd_fine` that every block scans
+// for itself (16 KB from L2: no launch of its own, and the look-up table is wanted in LDS anyway); the pairs leave as
+// (id, key) records in `pair_out`, the form the bucket sort reads, and the tile with ticket 0 writes the buckets' ranges.
+template <bool GATHER, int ITEMS, bool MSD = false>
 __global__ void __launch_bounds__(GGR_SORT_THREADS)
 radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n /*keys per segment*/,
                       int pass, uint32_t ntiles /*per segment*/, uint32_t nseg, int tree_lookback, uint32_t* __restrict__ hist,
                       const uint2* __restrict__ gather_src,
-                      uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area, uint32_t zero_words) {
+                      uint2* __restrict__ gather_dst, uint32_t* __restrict__ zero_area, uint32_t zero_words,
+                      const uint32_t* __restrict__ msd_fine = nullptr, uint2* __restrict__ msd_ranges = nullptr,
+                      uint2* __restrict__ pair_out = nullptr, uint32_t msd_target = 1u /*2^32 / (keys per bucket)*/) {
     constexpr int NW = GGR_SORT_THREADS / 64;
     constexpr int DPT = GGR_SORT_MAX_BINS / GGR_SORT_THREADS;  // digits per thread at the widest digit
     __shared__ uint16_t wcount[NW][GGR_SORT_MAX_BINS];  // per-wave digit counters (a wave holds 512 keys), later per-wave prefixes
@@ -152,6 +228,7 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     __shared__ uint2 sorted[(GGR_SORT_THREADS * ITEMS)];             // the tile's (key, val) pairs — then its payloads — in output order
     __shared__ uint32_t wsum[NW];
     __shared__ uint32_t tile_sh;
+    __shared__ uint16_t lut[MSD ? GGR_MSD_FINE : 2];   // MSD: fine bin → bucket
     GGR_CRITICAL_PRIO();
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -163,20 +240,62 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
         const size_t so = (size_t)seg * n;
         keys_in += so; keys_out += so; vals_out += so;
         if (!vals_in_null) vals_in += so;
-        if (GATHER) gather_dst += so;
+        if (GATHER || (MSD && gather_dst)) gather_dst += so;
+        if (MSD) pair_out += so;
     }
-    const uint32_t w = hist[GGR_HIST_PARAMS];            // bits per digit (block-uniform)
+    const uint32_t w = MSD ? (uint32_t)GGR_SORT_MAX_BITS : hist[GGR_HIST_PARAMS];   // bits per digit (block-uniform)
     const uint32_t bins = 1u << w, mask = bins - 1u;
     const uint32_t shift = (uint32_t)pass * w;
+    const uint32_t msd_kmin = MSD ? hist[GGR_HIST_MSD_KMIN] : 0u, msd_shift = MSD ? hist[GGR_HIST_MSD_SHIFT] : 0u;
+    // the digit of a key (MSD: its bucket; a slot beyond the segment's end never uses it)
+    auto digit_of = [&](uint32_t k) -> uint32_t {
+        if (MSD) return (k == 0u || k == 0xFFFFFFFFu) ? 0u : (uint32_t)lut[min((k - msd_kmin) >> msd_shift, (uint32_t)GGR_MSD_FINE - 1u)];
+        return (k >> shift) & mask;
+    };
     // this pass's digit totals, requested now (they are final: the histogram kernel has ended)
     uint32_t tot[DPT];
+    if (!MSD) {
 #pragma unroll
-    for (int q = 0; q < DPT; q++) {
-        const uint32_t d = tid + q * GGR_SORT_THREADS;
-        tot[q] = d < bins ? hist[GGR_HIST_TOTALS + (seg * GGR_SORT_PASSES + pass) * GGR_SORT_MAX_BINS + d] : 0u;
+        for (int q = 0; q < DPT; q++) {
+            const uint32_t d = tid + q * GGR_SORT_THREADS;
+            tot[q] = d < bins ? hist[GGR_HIST_TOTALS + (seg * GGR_SORT_PASSES + pass) * GGR_SORT_MAX_BINS + d] : 0u;
+        }
     }
     for (uint32_t x = tid; x < NW * GGR_SORT_MAX_BINS / 2; x += GGR_SORT_THREADS)
         reinterpret_cast<uint32_t*>(&wcount[0][0])[x] = 0u;
+    if (MSD) {
+        // splitters: thread t owns fine bins [FPT·t, FPT·(t+1)); bucket of a bin = 1 + (visible keys in the bins before it) / target
+        constexpr int FPT = GGR_MSD_FINE / GGR_SORT_THREADS;
+        const uint32_t* fseg = msd_fine + (size_t)seg * GGR_MSD_FINE_WORDS;
+        uint32_t c[FPT], tsum = 0u;
+#pragma unroll
+        for (int j = 0; j < FPT; j++) { c[j] = fseg[FPT * tid + j]; tsum += c[j]; }
+        const uint32_t culled = fseg[GGR_MSD_FINE];
+        uint32_t incl = tsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        for (uint32_t x = tid; x < GGR_SORT_MAX_BINS; x += GGR_SORT_THREADS) texcl[x] = 0u;   // (bucket totals, until the look-back)
+        __syncthreads();
+        uint32_t e = incl - tsum;
+#pragma unroll
+        for (int ww = 0; ww < NW; ww++) e += ww < wave ? wsum[ww] : 0u;
+#pragma unroll
+        for (int j = 0; j < FPT; j++) {
+            // (any non-decreasing function of e will do — every block computes the same one: a multiply-high, not a division)
+            const uint32_t b = min(1u + __umulhi(e, msd_target), (uint32_t)GGR_SORT_MAX_BINS - 1u);
+            lut[FPT * tid + j] = (uint16_t)b;
+            if (c[j]) atomicAdd(&texcl[b], c[j]);
+            e += c[j];
+        }
+        if (tid == 0) texcl[0] = culled;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < DPT; q++) tot[q] = texcl[tid + q * GGR_SORT_THREADS];
+    }
     __syncthreads();
     const uint32_t tile = tile_sh;
     PROBE(0);
@@ -234,6 +353,13 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
             }
         }
     }
+    if (MSD && tile == 0u) {   // the buckets' ranges in the whole array (what the bucket-sort launch walks)
+#pragma unroll
+        for (int q = 0; q < DPT; q++) {
+            const uint32_t d = tid + q * GGR_SORT_THREADS, st = (uint32_t)((size_t)seg * n) + dbase[d];
+            msd_ranges[(size_t)seg * GGR_SORT_MAX_BINS + d] = (tot[q] && d != 0u) ? make_uint2(st, st + tot[q]) : make_uint2(0u, 0u);
+        }
+    }
     PROBE(1);
     // wave-private counters: plain LDS accesses, ordered by wavefront-scope fences (LDS executes a wave's
     // operations in order; a `volatile` pointer here compiles to flat_load/flat_store + s_waitcnt vmcnt(0))
@@ -242,10 +368,16 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     // (b) then the chain through the wave's counters: two dependent LDS operations per round and nothing else
     // (with the ballots inside the chain a round cost ≈ 0.4 µs: tools/sort_bench.hip -DGGR_SORT_PROBE)
     uint32_t before[ITEMS], cnt[ITEMS];
+    uint32_t dig[MSD ? ITEMS : 1];   // MSD: a key's bucket costs an LDS look-up — once per key, not once per use
+    if (MSD) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) dig[MSD ? r : 0] = digit_of(key[r]);
+    }
+    auto digit_r = [&](int r) -> uint32_t { return MSD ? dig[MSD ? r : 0] : digit_of(key[r]); };
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
-        const uint32_t d = (key[r] >> shift) & mask;
+        const uint32_t d = digit_r(r);
         uint64_t m = __ballot(idx < n);
 #pragma unroll
         for (int b = 0; b < GGR_SORT_MAX_BITS; b++) {
@@ -263,7 +395,7 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     for (int r = 0; r < ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
         const bool valid = idx < n;
-        const uint32_t d = (key[r] >> shift) & mask;
+        const uint32_t d = digit_r(r);
         uint32_t prev = 0;
         if (valid) prev = wc[d];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -421,7 +553,7 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const size_t idx = base + r * 64 + lane;
-        const uint32_t d = (key[r] >> shift) & mask;
+        const uint32_t d = digit_r(r);
         lpos[r] = texcl[d] + wcount[wave][d] + rank[r];
         if (idx < n) sorted[lpos[r]] = make_uint2(key[r], val[r]);
     }
@@ -434,10 +566,20 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
         gpos[k] = 0;
         if (j < tile_n) {
             const uint2 kv = sorted[j];
-            const uint32_t d = (kv.x >> shift) & mask;
+            const uint32_t d = digit_of(kv.x);
             gpos[k] = dbase[d] + (j - texcl[d]);
-            keys_out[gpos[k]] = kv.x;
-            vals_out[gpos[k]] = kv.y;
+            if (MSD) {
+                // (id, key): what the bucket sort reads.  The culled Gaussians (bucket 0: key 0, often a tenth of the frame and
+                // far more than one workgroup should copy) are final as they stand — stable partition = id order — and leave here
+                if (d != 0u) pair_out[gpos[k]] = make_uint2(kv.y, kv.x);
+                else {
+                    vals_out[gpos[k]] = kv.y;
+                    if (gather_dst) gather_dst[gpos[k]] = gather_src[kv.y];
+                }
+            } else {
+                keys_out[gpos[k]] = kv.x;
+                vals_out[gpos[k]] = kv.y;
+            }
         }
     }
     if (GATHER) {
@@ -462,8 +604,51 @@ const uint32_t* radix_sort_fault_word(const uint32_t* hist) { return hist + GGR_
 void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                       uint32_t* hist, size_t n, uint32_t segments, uint32_t** keys_out, uint32_t** vals_out,
                       hipStream_t s, bool hist_zeroed, uint32_t block_max_ready, bool identity_vals, const uint2* gather_src, uint2* gather_dst,
-                      uint32_t* zero_area, uint32_t zero_words) {
+                      uint32_t* zero_area, uint32_t zero_words, bool buckets) {
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
+    if (n > 0 && buckets && identity_vals && block_max_ready && gather_src && gather_dst && radix_sort_buckets_ok(n / (segments ? segments : 1))) {
+        // ---- the bucket form: fine histogram → ONE partition pass → every bucket sorted in LDS (+ payload gather) -------------
+        const uint32_t S = segments ? segments : 1;
+        const size_t nseg = n / S;
+        int items = 8;
+        for (int it = 8; it <= 16 && S * ggr_sort_blocks(nseg) > 256; it += 2)
+            if (S * ((nseg + (size_t)it * GGR_SORT_THREADS - 1) / ((size_t)it * GGR_SORT_THREADS)) <= 256) { items = it; break; }
+        const uint32_t ntiles = (uint32_t)((nseg + (size_t)items * GGR_SORT_THREADS - 1) / ((size_t)items * GGR_SORT_THREADS));
+        const int tree = ggr_sort_blocks(nseg) * S <= GGR_SORT_TREE_MAX_TILES ? 1 : 0;
+        uint32_t* block_max = hist + ggr_sort_block_max_at(n, S);
+        uint32_t* block_min = hist + ggr_sort_block_min_at(n, S);
+        uint32_t* fine = hist + ggr_sort_lsd_zero_words(n, S);
+        uint2* ranges = reinterpret_cast<uint2*>(hist + ggr_sort_bucket_ranges_at(n, S));
+        // the (id, key) records of the partition pass: keys_b and the (unused: identity values) vals_a behind it are one region
+        uint2* pairs = reinterpret_cast<uint2*>(keys_b);
+        if (!hist_zeroed) (void)hipMemsetAsync(hist, 0, ggr_sort_zero_words(n, S) * sizeof(uint32_t), s);
+        const unsigned bps = (unsigned)((nseg + GGR_HIST_THREADS * GGR_HIST_ITEMS - 1) / (GGR_HIST_THREADS * GGR_HIST_ITEMS));
+        hipLaunchKernelGGL(msd_hist_kernel, dim3(bps * S), dim3(GGR_HIST_THREADS), 0, s, keys_a, nseg, bps, hist, block_max,
+                           block_min, block_max_ready, fine);
+        // buckets of `target` keys (+ what the last fine bin brings): at most 1022 of them per segment beside the culled one
+        const uint32_t target = std::max<uint32_t>(1024u, (uint32_t)(nseg / 1000) + 1u);
+        const uint32_t target_inv = (uint32_t)((1ull << 32) / target);   // bucket of the e-th visible key = 1 + (e · inv) >> 32
+#define GGR_PART(ITEMS_)                                                                                                   \
+    hipLaunchKernelGGL((radix_onesweep_kernel<false, ITEMS_, true>), dim3(ntiles * S), dim3(GGR_SORT_THREADS), 0, s, keys_a, \
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, vals_b, nseg, 0, ntiles, S, tree, hist,                 \
+                       gather_src, gather_dst, (uint32_t*)nullptr, 0u, fine, ranges, pairs, target_inv)
+        if (items == 8) GGR_PART(8);
+        else if (items == 10) GGR_PART(10);
+        else if (items == 12) GGR_PART(12);
+        else if (items == 14) GGR_PART(14);
+        else GGR_PART(16);
+#undef GGR_PART
+        // the buckets, each by one workgroup: first the class that holds a regular bucket, then (mostly an empty launch) what
+        // an overfull fine bin made longer; beyond GGR_TSORT_CAP_LARGE: copied if its keys are all equal, else the fault bit
+        const uint32_t cls1 = target <= 1280u ? 2048u : target <= 2200u ? 3072u : 4096u;
+        TileSortExtras ex{gather_src, gather_dst, zero_area, zero_words, hist + GGR_HIST_FAULT};
+        launch_tile_depth_sort((size_t)S * GGR_SORT_MAX_BINS, ranges, vals_b, pairs, 0u, cls1, s, 0, nullptr, &ex);
+        ex.zero_words = 0u;
+        launch_tile_depth_sort((size_t)S * GGR_SORT_MAX_BINS, ranges, vals_b, pairs, cls1, GGR_TSORT_CAP_LARGE, s, 1, nullptr, &ex);
+        *keys_out = nullptr;
+        *vals_out = vals_b;
+        return;
+    }
     if (n > 0) {
         const uint32_t S = segments ? segments : 1;
         const size_t nseg = n / S;  // (n is a multiple of S)
@@ -475,7 +660,7 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
         // (the status area was sized — and cleared — for tiles of 4096 keys: ggr_sort_zero_words; same rule here)
         const int tree = ggr_sort_blocks(nseg) * S <= GGR_SORT_TREE_MAX_TILES ? 1 : 0;
         const uint32_t nmax = block_max_ready ? block_max_ready : (uint32_t)((n + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS);
-        uint32_t* block_max = hist + ggr_sort_zero_words(n, S);
+        uint32_t* block_max = hist + ggr_sort_block_max_at(n, S);
         if (!hist_zeroed)  // (ggr_forward: preprocess_fwd clears the area — one launch less)
             (void)hipMemsetAsync(hist, 0, ggr_sort_zero_words(n, S) * sizeof(uint32_t), s);
         if (!block_max_ready)  // (ggr_forward: preprocess_fwd leaves them)

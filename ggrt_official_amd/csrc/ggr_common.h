@@ -151,15 +151,35 @@ __host__ __device__ static inline size_t ggr_sort_status_base(size_t S) { return
 #define GGR_SORT_TREE_MAX_TILES 512   // (tiles of 4096 keys) up to here all tiles of a sort are resident at once — as one
                                       // tile of up to 8192 keys per CU, or two per CU — and look back through the tree
                                       // (the tree's three levels span 8·8·8 tiles: do not raise without a fourth)
-static inline size_t ggr_sort_zero_words(size_t n, size_t S = 1) {
+// The BUCKET form of the depth sort (binning.hip, round 6): ONE stable partition pass into <= 1024 depth buckets per segment whose
+// boundaries are equal-frequency splitters of a 4096-bin histogram of the frame's own key range, then every bucket sorted in
+// LDS by the per-tile sort's workgroup routine.  Its words in the work area: the fine histogram (per segment 4096 bins of
+// visible keys + [4096] = the culled Gaussians, key 0), inside the zeroed part; one key MINIMUM (over the visible keys) per
+// preprocess block behind the maxima; the buckets' ranges for the bucket-sort launch.
+#define GGR_MSD_FINE 4096
+#define GGR_MSD_FINE_WORDS 4352          // per segment (4097 used)
+#define GGR_MSD_MAX_POINTS (2u << 20)    // per segment: beyond, buckets would exceed what a workgroup sorts in LDS
+#define GGR_HIST_MSD_KMIN (GGR_HIST_PARAMS + 1)   // smallest visible key of the frame
+#define GGR_HIST_MSD_SHIFT (GGR_HIST_PARAMS + 2)  // fine bin of a visible key = (key - kmin) >> shift
+#define GGR_FAULT_SPIN 1u    // a look-back spin hit its bound
+#define GGR_FAULT_RANGE 2u   // a key needs more than 3 x 10 bits (depth >= 6.8e37)
+#define GGR_FAULT_BUCKET 4u  // bucket form: a bucket of more than GGR_TSORT_CAP_LARGE keys that are not all equal was left unsorted
+static inline size_t ggr_sort_lsd_zero_words(size_t n, size_t S = 1) {
     const size_t tps = ggr_sort_blocks((n ? n : 1) / S ? (n ? n : 1) / S : 1);
     const size_t levels = tps * S <= GGR_SORT_TREE_MAX_TILES ? GGR_SORT_LEVELS : 1;
     return ggr_sort_status_base(S) + (size_t)GGR_SORT_PASSES * S * tps * GGR_SORT_MAX_BINS * levels;
 }
-static inline size_t ggr_sort_hist_words(size_t n, size_t S = 1) {
-    // (+ S: a launch set of several Gaussian sets rounds its preprocess blocks up per set — at most one block per view more)
-    return ggr_sort_zero_words(n, S) + ((n ? n : 1) + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS + GGR_SORT_MAX_SEGMENTS;
+// words of the work area that start from zero (cleared by preprocess_fwd): header, digit totals, status words, fine histogram
+static inline size_t ggr_sort_zero_words(size_t n, size_t S = 1) { return ggr_sort_lsd_zero_words(n, S) + S * GGR_MSD_FINE_WORDS; }
+__host__ __device__ static inline size_t ggr_sort_block_words(size_t n) {
+    // (+ MAX_SEGMENTS: a launch set of several Gaussian sets rounds its preprocess blocks up per set — at most one block per view more)
+    return ((n ? n : 1) + GGR_PRE_THREADS - 1) / GGR_PRE_THREADS + GGR_SORT_MAX_SEGMENTS;
 }
+// offsets (words) of the sections behind the zeroed part: block maxima | block minima | bucket ranges (uint2 per bucket)
+static inline size_t ggr_sort_block_max_at(size_t n, size_t S = 1) { return ggr_sort_zero_words(n, S); }
+static inline size_t ggr_sort_block_min_at(size_t n, size_t S = 1) { return ggr_sort_block_max_at(n, S) + ggr_sort_block_words(n); }
+static inline size_t ggr_sort_bucket_ranges_at(size_t n, size_t S = 1) { return (ggr_sort_block_min_at(n, S) + ggr_sort_block_words(n) + 1) & ~(size_t)1; }
+static inline size_t ggr_sort_hist_words(size_t n, size_t S = 1) { return ggr_sort_bucket_ranges_at(n, S) + S * 2 * GGR_SORT_MAX_BINS; }
 
 struct GeomLayout {
     float4* splat;    // [P][2]
@@ -374,7 +394,14 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
                       bool identity_vals = false /*vals_a holds nothing: the first pass uses val = index in the whole array*/,
                       const uint2* gather_src = nullptr /*last pass also writes gather_dst[pos] = gather_src[val]*/,
                       uint2* gather_dst = nullptr, uint32_t* zero_area = nullptr /*and clears these words*/,
-                      uint32_t zero_words = 0);
+                      uint32_t zero_words = 0,
+                      bool buckets = false /*the bucket form (binning.hip): needs identity_vals, block_max_ready (preprocess_fwd's
+                      block maxima AND minima), the payload gather and n / segments <= GGR_MSD_MAX_POINTS — else three passes; keys_out is not filled (NULL); a bucket it
+                      could not sort raises GGR_FAULT_BUCKET in the fault word — the order is then a permutation that is NOT
+                      fully sorted and the caller must sort again without `buckets`*/);
+// the bucket form is possible for this many keys per segment
+static inline bool radix_sort_buckets_ok(size_t n_per_segment) { return n_per_segment > 0 && n_per_segment <= GGR_MSD_MAX_POINTS; }
+
 
 // tile-list builder (tile_lists.hip)
 struct TileListPlan {
@@ -409,13 +436,22 @@ void launch_tile_list_scatter(const TileListPlan& pl, size_t P, size_t T, int gr
                               hipStream_t s, const uint32_t* keys = nullptr /*id order: the Gaussians' depth keys …*/,
                               uint2* pair_list = nullptr /*… and where the (id, key) entries go instead of point_list*/);
 
+// what the depth sort's bucket form (binning.hip) asks of the same kernels: its "tiles" are the depth buckets of the P keys
+struct TileSortExtras {
+    const uint2* gather_src;   // every sorted id also fetches its 8-byte payload: gather_dst[position] = gather_src[id]
+    uint2* gather_dst;
+    uint32_t* zero_area;       // … and the launch clears these words (the tile-list builder's totals)
+    uint32_t zero_words;
+    uint32_t* fault_word;      // a list longer than the launch sorts whose keys are NOT all equal ORs GGR_FAULT_BUCKET in here
+};
 // tile_sort.hip: stable sort of every tile's list by the Gaussians' depth keys — lists with min_len < length <= max_len
 // (others are left alone; max_len <= GGR_TSORT_CAP_LARGE)
 void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* pair_list, uint32_t min_len,
                             uint32_t max_len, hipStream_t s, int copy_longer /*1: lists longer than max_len are copied out
                             unsorted (the last launch of a forward: the blend must find valid ids)*/,
                             uint32_t* lsd_entries = nullptr /*+= the entries of the lists that took the kernel's slow route
-                            (depths clustered in few buckets; tile_sort.h)*/);
+                            (depths clustered in few buckets; tile_sort.h)*/,
+                            const TileSortExtras* extras = nullptr);
 
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* splat,

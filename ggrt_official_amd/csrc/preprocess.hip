@@ -115,7 +115,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       uint2* __restrict__ rect, uint32_t* __restrict__ clamped_out,
                       float* __restrict__ cov3D_out, uint32_t* __restrict__ zero_area, uint32_t zero_words,
                       uint32_t* __restrict__ zero_area2, uint32_t zero_words2,
-                      uint32_t* __restrict__ block_max, InputForm inf) {
+                      uint32_t* __restrict__ block_max, uint32_t* __restrict__ block_min, InputForm inf) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [256][sh_row_stride]
     // zero the depth sort's histogram / ticket / look-back words here instead of with a separate fill launch
     // (zero_area2: the tile-list builder's per-tile totals when NO depth sort runs in front of it — the sort's last pass
@@ -210,6 +210,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const bool in_range = i < P;  // (threads past P run on Gaussian P-1's inputs and store nothing)
     const int gy = (H + GGR_TILE - 1) / GGR_TILE;   // (tile rows per view: the views' tile rows are stacked)
     uint32_t km = 0u;  // largest sort key of this thread over all views
+    uint32_t kmn = 0xFFFFFFFFu;   // … and (smallest visible key) − 1
 
     // ---- one pass per view: the Gaussian's inputs (and its SH row in LDS) are read ONCE for all of them ----------
     const int NV = MULTI ? vs.vps : 1;
@@ -493,15 +494,23 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             }
         }
         km = max(km, key_out);
+        kmn = min(kmn, key_out - 1u);   // (a culled Gaussian's key 0 wraps to ~0: the minimum is over the VISIBLE keys, less one)
     }
     // the largest sort key of this block: the depth sort derives its digit width from these (binning.hip)
     if (PART == GGR_PRE_COLOUR) continue;
-    __shared__ uint32_t kmax[GGR_PRE_THREADS / 64];
+    // … and the smallest VISIBLE one (less one; ~0: none): the bucket form of the sort takes the frame's key range from both
+    __shared__ uint32_t kmax[GGR_PRE_THREADS / 64], kmin[GGR_PRE_THREADS / 64];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, off));
-    if ((threadIdx.x & 63) == 0) kmax[threadIdx.x >> 6] = km;
+    for (int off = 32; off > 0; off >>= 1) {
+        km = max(km, (uint32_t)__shfl_xor((int)km, off));
+        kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, off));
+    }
+    if ((threadIdx.x & 63) == 0) { kmax[threadIdx.x >> 6] = km; kmin[threadIdx.x >> 6] = kmn; }
     __syncthreads();
-    if (threadIdx.x == 0) block_max[blockIdx.y * nchunks + bx] = max(max(kmax[0], kmax[1]), max(kmax[2], kmax[3]));
+    if (threadIdx.x == 0) {
+        block_max[blockIdx.y * nchunks + bx] = max(max(kmax[0], kmax[1]), max(kmax[2], kmax[3]));
+        block_min[blockIdx.y * nchunks + bx] = min(min(kmin[0], kmin[1]), min(kmin[2], kmin[3]));
+    }
     }   // chunks
 }
 
@@ -536,7 +545,8 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     hipLaunchKernelGGL((preprocess_fwd_kernel<MULTI_, KC_, PART_, JAC_>), dim3(blocks, vs.sets), dim3(threads), lds, s, P, D, \
                        M, means3D, shs, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,       \
                        aux_precomp, vs, W, H, radii, g.splat, g.colour, g.sh_jac, (size_t)P * vs.V, g.keys_a, g.rect, g.clamped, g.cov3D,    \
-                       g.hist, zero_words, zero_area2, zero_words2, g.hist + sort_words, inf)
+                       g.hist, zero_words, zero_area2, zero_words2, g.hist + sort_words,                                  \
+                       g.hist + ggr_sort_block_min_at((size_t)P * vs.V, ggr_sort_segments((size_t)vs.V)), inf)
     const bool jac = keep_jacobian != 0 && shs != nullptr;
 #define GGR_LAUNCH_PFWD(MULTI_, KC_, PART_)                                                                               \
     do { if (jac) GGR_LAUNCH_PFWD_J(MULTI_, KC_, PART_, true); else GGR_LAUNCH_PFWD_J(MULTI_, KC_, PART_, false); } while (0)

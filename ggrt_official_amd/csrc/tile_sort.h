@@ -50,9 +50,15 @@ __device__ __forceinline__ void ts_order() {
 // One 256-thread workgroup sorts the n <= cap <= 256·Q entries `pairs[0..n)` = (id, key) by (key, id) and writes the ids to
 // `list[0..n)`.  `lds`: tsort_lds_words(cap) words (16-B aligned) that the caller may reuse behind a barrier.  Every thread of
 // the workgroup must call it (barriers inside); n >= 2.
-template <int Q>
+// REL (the depth sort's bucket form, binning.hip: the "list" is a depth bucket of the P Gaussians): the digits are cut out of
+// the keys' distance from the list's smallest key instead of the bits that differ (see below), and every id is also followed by
+// its 8-byte payload, gdst[position] = gsrc[id] (gdst: the list's own slice).  The per-tile sort (REL = false) compiles to what
+// it was: its small class lives at 64 registers, and the range form cost it nine more spilled ones (43 -> 52 µs at C3).
+template <int Q, bool REL = false>
 __device__ __forceinline__ void tile_sort_body(uint32_t* __restrict__ lds, uint32_t cap, uint32_t n, uint32_t* __restrict__ list,
-                                               const uint2* __restrict__ pairs, uint32_t* __restrict__ lsd_entries) {
+                                               const uint2* __restrict__ pairs, uint32_t* __restrict__ lsd_entries,
+                                               const uint2* __restrict__ gsrc = nullptr, uint2* __restrict__ gdst = nullptr) {
+    uint32_t fpos[REL ? Q : 1];   // REL: every entry's final position (ids and payloads are stored together at the end)
     // LDS (words), the two routes below laid over each other:
     //   route 1  [ex: cap × (id, key) = 2·cap] [fill: BINS] [starts: BINS]
     //   route 2  [exw: cap]                    [cnt: 4 × BINS] [same: 4 × 64 × u64 = 512]
@@ -86,21 +92,59 @@ __device__ __forceinline__ void tile_sort_body(uint32_t* __restrict__ lds, uint3
 #pragma unroll
     for (int r = 0; r < Q; r++) { id[r] = 0u; ky[r] = 0u; valid[r] = (uint32_t)r < q && p_lo + 64u * r < n; }
     TS_GROUPS({ const uint2 e = pairs[min(p_lo + 64u * r, n - 1u)]; id[r] = e.x; ky[r] = e.y; })
-    uint32_t k_or = 0u, k_and = 0xFFFFFFFFu;
+    // REL: the payloads are requested NOW — random 8-byte reads, 20 of the kernel's 39 µs when they were issued behind the
+    // sort — and wait in registers until their entry knows its position (an unused slot repeats the list's last entry)
+    uint2 payq[REL ? Q : 1];
+    if (REL) { TS_GROUPS({ payq[REL ? r : 0] = gsrc[id[r]]; }) }
+    auto finish_rel = [&]() {
+        if (!REL) return;
+        TS_GROUPS({ if (valid[r]) { list[fpos[REL ? r : 0]] = id[r]; gdst[fpos[REL ? r : 0]] = payq[REL ? r : 0]; } })
+    };
+    // Which bits count.  Per tile: the bits that DIFFER inside the list (OR ^ AND over its keys — a tile's keys spread over
+    // octaves).  REL: the keys' RANGE — from here on a key is its distance from the list's smallest (same order): a depth
+    // bucket is a narrow range, and a narrow range that straddles a high bit's boundary differs in that bit and in nothing
+    // between it and its own width: its top nine "differing" bits take two values and every bucket went down the slow route.
+    uint32_t diff;
+    if (REL) {
+        uint32_t k_max = 0u, k_min = 0xFFFFFFFFu;
 #pragma unroll
-    for (int r = 0; r < Q; r++)
-        if (valid[r]) { k_or |= ky[r]; k_and &= ky[r]; }
+        for (int r = 0; r < Q; r++)
+            if (valid[r]) { k_max = max(k_max, ky[r]); k_min = min(k_min, ky[r]); }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        k_or |= (uint32_t)__shfl_xor((int)k_or, off);
-        k_and &= (uint32_t)__shfl_xor((int)k_and, off);
+        for (int off = 32; off > 0; off >>= 1) {
+            k_max = max(k_max, (uint32_t)__shfl_xor((int)k_max, off));
+            k_min = min(k_min, (uint32_t)__shfl_xor((int)k_min, off));
+        }
+        for (uint32_t d = tid; d < GGR_TSORT_BINS; d += 256) fill[d] = 0u;
+        if (lane == 0) { red[wave] = k_max; red[4 + wave] = k_min; }
+        __syncthreads();
+        const uint32_t lo_key = min(min(red[4], red[5]), min(red[6], red[7]));
+        diff = max(max(red[0], red[1]), max(red[2], red[3])) - lo_key;
+#pragma unroll
+        for (int r = 0; r < Q; r++) ky[r] = valid[r] ? ky[r] - lo_key : 0u;
+    } else {
+        uint32_t k_or = 0u, k_and = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < Q; r++)
+            if (valid[r]) { k_or |= ky[r]; k_and &= ky[r]; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            k_or |= (uint32_t)__shfl_xor((int)k_or, off);
+            k_and &= (uint32_t)__shfl_xor((int)k_and, off);
+        }
+        for (uint32_t d = tid; d < GGR_TSORT_BINS; d += 256) fill[d] = 0u;
+        if (lane == 0) { red[wave] = k_or; red[4 + wave] = k_and; }
+        __syncthreads();
+        diff = (red[0] | red[1] | red[2] | red[3]) ^ (red[4] & red[5] & red[6] & red[7]);
     }
-    for (uint32_t d = tid; d < GGR_TSORT_BINS; d += 256) fill[d] = 0u;
-    if (lane == 0) { red[wave] = k_or; red[4 + wave] = k_and; }
-    __syncthreads();
-    const uint32_t diff = (red[0] | red[1] | red[2] | red[3]) ^ (red[4] & red[5] & red[6] & red[7]);
     if (diff == 0u) {   // every key equal: the entries are in id order already
-        TS_GROUPS({ if (valid[r]) list[p_lo + 64u * r] = id[r]; })
+        if (REL) {
+#pragma unroll
+            for (int r = 0; r < Q; r++) fpos[REL ? r : 0] = p_lo + 64u * r;
+            finish_rel();
+        } else {
+            TS_GROUPS({ if (valid[r]) list[p_lo + 64u * r] = id[r]; })
+        }
         return;
     }
     const uint32_t nbits = 32u - (uint32_t)__builtin_clz(diff);
@@ -166,9 +210,11 @@ __device__ __forceinline__ void tile_sort_body(uint32_t* __restrict__ lds, uint3
                         uint32_t rank = 0u;
                         if (valid[r])
                             for (uint32_t j = bs[u]; j < be[u]; j++) rank += ex64[j] < mine ? 1u : 0u;
-                        if (valid[r]) list[bs[u] + rank] = id[r];
+                        if (REL) fpos[REL ? r : 0] = bs[u] + rank;
+                        else if (valid[r]) list[bs[u] + rank] = id[r];
                     }
                 }
+            finish_rel();
             return;
         }
     }
@@ -177,7 +223,6 @@ __device__ __forceinline__ void tile_sort_body(uint32_t* __restrict__ lds, uint3
     // (what the frame's tiles of this kind hold is counted: a host that finds most of a frame here does better with the
     //  global depth sort — ggr_sort_stats_async)
     if (tid == 0 && lsd_entries) atomicAdd(lsd_entries, n);
-    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     uint32_t p0[Q];
     uint32_t* my_cnt = cnt + wave * GGR_TSORT_BINS;
     unsigned long long* my_same = same + wave * 64;
@@ -285,7 +330,16 @@ __device__ __forceinline__ void tile_sort_body(uint32_t* __restrict__ lds, uint3
         for (uint32_t d = lane; d < GGR_TSORT_BINS; d += 64) my_cnt[d] = 0u;
         counting_pass(pass * bits, bits);
         if (pass + 1 == npass) {
-            TS_GROUPS({ if (valid[r]) list[p0[r]] = id[r]; })
+            if (REL) {
+                // (this route's passes hand the ids on from thread to thread: the payloads requested at the start belong to
+                //  other entries by now — fetched again, for the ids held at last)
+                TS_GROUPS({ payq[REL ? r : 0] = gsrc[valid[r] ? id[r] : 0u]; })
+#pragma unroll
+                for (int r = 0; r < Q; r++) fpos[REL ? r : 0] = p0[r];
+                finish_rel();
+            } else {
+                TS_GROUPS({ if (valid[r]) list[p0[r]] = id[r]; })
+            }
             break;
         }
         // the exchange buffer holds one word per entry: the ids first, then the keys

@@ -61,10 +61,74 @@ tile_depth_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* _
     tile_sort_body<Q>(lds, cap, n, list, pairs, lsd_entries);
 }
 
+// The same for the depth sort's bucket form (binning.hip): a "tile" is a depth bucket of the P Gaussians — a thousand
+// workgroups, not eight thousand, so the small class need not be held to 64 registers (no spills; four workgroups per CU).
+template <int Q>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Q <= 8 ? 4 : Q <= 16 ? 2 : 1, 8)))
+bucket_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
+                   const uint2* __restrict__ pair_list, uint32_t min_len, uint32_t cap, int copy_longer, TileSortExtras ex) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    if (ex.zero_words)   // (the words the three-pass form's last pass clears)
+        for (uint32_t wz = blockIdx.x * 256u + tid; wz < ex.zero_words; wz += gridDim.x * 256u) ex.zero_area[wz] = 0u;
+    if (tile >= T) return;
+    const uint2 range = ranges[tile];
+    const uint32_t n = range.y - range.x;
+    if (n <= min_len) return;
+    uint32_t* list = point_list + range.x;
+    const uint2* pairs = pair_list + range.x;
+    uint2* gdst = ex.gather_dst + range.x;
+    if (n > cap) {
+        // a bucket of more keys than a workgroup sorts (an overfull fine bin): left in id order — the stable partition's —
+        // it is sorted iff all its keys are equal (a plane of constant depth); otherwise the fault bit, and the caller
+        // sorts the frame again in three passes
+        if (copy_longer) {
+            uint32_t k_or = 0u, k_and = 0xFFFFFFFFu;
+            // (one workgroup, n of any size: eight entries per thread and trip, every load of a trip in flight together)
+            for (uint32_t i0 = 0; i0 < n; i0 += 8u * 256u) {
+                uint2 e[8], pay[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) e[u] = pairs[min(i0 + (uint32_t)u * 256u + tid, n - 1u)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) pay[u] = ex.gather_src[e[u].x];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * 256u + tid;
+                    if (i < n) {
+                        list[i] = e[u].x;
+                        k_or |= e[u].y; k_and &= e[u].y;
+                        gdst[i] = pay[u];
+                    }
+                }
+            }
+            if (ex.fault_word && k_or != k_and) atomicOr(ex.fault_word, GGR_FAULT_BUCKET);
+        }
+        return;
+    }
+    if (n < 2u) {
+        if (n == 1u && tid == 0) {
+            const uint32_t id = pairs[0].x;
+            list[0] = id;
+            gdst[0] = ex.gather_src[id];
+        }
+        return;
+    }
+    tile_sort_body<Q, true>(lds, cap, n, list, pairs, nullptr, ex.gather_src, gdst);
+}
+
 template <int Q>
 static void launch_tsort_class(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* keys, uint32_t min_len,
-                               uint32_t cap, int copy_longer, uint32_t* lsd_entries, hipStream_t s) {
+                               uint32_t cap, int copy_longer, uint32_t* lsd_entries, hipStream_t s, const TileSortExtras* ex) {
     const size_t lds = (size_t)tsort_lds_words(cap) * 4;
+    if (ex) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel<Q>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(bucket_sort_kernel<Q>, dim3((unsigned)T), dim3(256), lds, s, (uint32_t)T, ranges, point_list, keys,
+                           min_len, cap, copy_longer, *ex);
+        return;
+    }
     if (lds > 64 * 1024)   // (a workgroup may take the CU's whole 160 KB, but beyond 64 KB it has to be asked for)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_depth_sort_kernel<Q>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -73,14 +137,15 @@ static void launch_tsort_class(size_t T, const uint2* ranges, uint32_t* point_li
 }
 
 void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* keys, uint32_t min_len,
-                            uint32_t max_len, hipStream_t s, int copy_longer, uint32_t* lsd_entries) {
+                            uint32_t max_len, hipStream_t s, int copy_longer, uint32_t* lsd_entries, const TileSortExtras* extras) {
     if (T == 0 || max_len == 0u || max_len <= min_len) return;   // (a list of ONE entry is still copied out of the pairs)
+    const TileSortExtras* ex = extras;   // (the depth sort's bucket form: gather_src / gather_dst must be given)
     const uint32_t cap = std::min<uint32_t>((max_len + 255u) & ~255u, GGR_TSORT_CAP_LARGE);   // the exchange buffer of the launch
     // the class = rounds per wave the registers hold: 8 (lists up to 2048: 6 workgroups per CU), 12 (3072), 16 (4096), 32 (8192)
-    if (cap <= 2048) launch_tsort_class<8>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s);
-    else if (cap <= 3072) launch_tsort_class<12>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s);
-    else if (cap <= 4096) launch_tsort_class<16>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s);
-    else launch_tsort_class<32>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s);
+    if (cap <= 2048) launch_tsort_class<8>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s, ex);
+    else if (cap <= 3072) launch_tsort_class<12>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s, ex);
+    else if (cap <= 4096) launch_tsort_class<16>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s, ex);
+    else launch_tsort_class<32>(T, ranges, point_list, keys, min_len, cap, copy_longer, lsd_entries, s, ex);
 }
 
 }  // namespace ggr

@@ -297,6 +297,29 @@ def _sort_choice(key, rs, st) -> None:
             st.depth_sort = _lib.DEPTH_SORT["global"]
 
 
+def _sort_no_buckets(key, st) -> None:
+    """Before a forward: a shape whose frames the global sort's bucket form recently gave up keeps the three passes for a while."""
+    if not _HINTS_ON or os.environ.get("GGR_GLOBAL_SORT"):
+        return
+    with _hint_lock:
+        w = _sort_watch.get(key)
+        if w is not None and w.get("no_buckets_left", 0) > 0:
+            w["no_buckets_left"] -= 1
+            st.depth_sort |= _lib.DEPTH_SORT_NO_BUCKETS
+
+
+def _sort_fell_back(key, fout) -> None:
+    """Behind a forward: the global sort's bucket form gave this frame up (a bucket of > 8192 different keys inside 1/4096 of
+    the frame's depth range) and the call built the lists again in three passes — about one binning more.  Frames of a shape
+    tend to look alike: the shape keeps the three passes for a while.  A hint like the others: no result depends on it."""
+    if int(fout.depth_sort_used) != _lib.DEPTH_SORT_FELL_BACK or not _HINTS_ON:
+        return
+    with _hint_lock:
+        w = _sort_watch.setdefault(key, {"calls": 0, "global_until": 0, "pending": None, "words": None, "slow_share": None})
+        w["no_buckets_left"] = _SORT_KEEP_GLOBAL
+        w["fell_back"] = w.get("fell_back", 0) + 1
+
+
 def _sort_look(key, lib, fout, geom, rows: int, stream: int) -> None:
     """Behind a forward that sorted per tile: now and then, the 16-byte copy of its counters (read by a later `_sort_choice`)."""
     if int(fout.depth_sort_used) != _lib.DEPTH_SORT["per_tile"]:
@@ -447,9 +470,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 prof.fwd_calls += 1
             key = (dev.index, P, W, H, 1, _scissor_key(rs))
             _sort_choice(key, rs, st)
+            _sort_no_buckets(key, st)
             _forward_with_guess(lambda: lib.ggr_forward(C.byref(st), C.byref(fin), C.byref(fout), cb, None, stream),
                                 fout, holder, lib, dev, W, H, key, capacity, prof is not None)
             _sort_look(key, lib, fout, geom, P, stream)
+            _sort_fell_back(key, fout)
 
         # exact mode: count known, nothing to keep.  Sync-free mode: count + flags live in the geometry buffer on the
         # device, so that (≈100 MB at P = 1 M) buffer stays referenced until this thread's next forward
@@ -627,10 +652,12 @@ class _RasterizeViews(torch.autograd.Function):
                 prof.fwd_calls += 1
             key = (dev.index, P, W, H, V, _scissor_key(rs))
             _sort_choice(key, rs, st)
+            _sort_no_buckets(key, st)
             _forward_with_guess(lambda: lib.ggr_forward_views(C.byref(st), C.byref(vw), C.byref(fin), C.byref(fout), cb,
                                                               None, stream),
                                 fout, holder, lib, dev, W, H, key, capacity, prof is not None)
             _sort_look(key, lib, fout, geom, P * V, stream)
+            _sort_fell_back(key, fout)
         _tls.last_forward = (geom, P * V) if capacity > 0 else (None, int(fout.num_rendered))
         _tls.last_binning = (int(fout.depth_sort_used), int(fout.max_list_len))
         ctx.raster_settings = rs
@@ -786,6 +813,15 @@ def last_forward_status():
         _check(lib.ggr_forward_status(geom.data_ptr(), P, C.byref(n), C.byref(ov),
                                       torch.cuda.current_stream(geom.device).cuda_stream), "ggr_forward_status")
     return int(n.value), bool(ov.value)
+
+
+def last_forward_sort_form() -> str:
+    """"per_tile" | "buckets" | "3pass" | "fell_back": GgrForwardOut.depth_sort_used of this thread's most recent forward in full
+    (the global sort's bucket form, its three-pass form, or three passes after the bucket form gave the frame up)."""
+    last = getattr(_tls, "last_binning", None)
+    if last is None:
+        raise RuntimeError("no forward has run on this thread")
+    return {2: "per_tile", 1: "buckets", 0x101: "3pass", _lib.DEPTH_SORT_FELL_BACK: "fell_back"}.get(last[0], str(last[0]))
 
 
 def last_forward_binning():

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GGR_ABI_VERSION 10
+#define GGR_ABI_VERSION 11
 
 enum {
     GGR_OK = 0,
@@ -112,7 +112,19 @@ typedef struct GgrSettings {
                                 fwd+bwd; 200 k Gaussians at 504 x 378: 26 %); global otherwise (GGRt's own 660-tile frames
                                 hold lists of 4 000-6 000 entries: the global sort is 10 % faster there). */
 } GgrSettings;
-enum { GGR_DEPTH_SORT_AUTO = 0, GGR_DEPTH_SORT_GLOBAL = 1, GGR_DEPTH_SORT_PER_TILE = 2 };
+enum { GGR_DEPTH_SORT_AUTO = 0, GGR_DEPTH_SORT_GLOBAL = 1, GGR_DEPTH_SORT_PER_TILE = 2,
+       /* ABI 11.  The global sort has two forms with the same result: three stable radix passes over the P keys, or ONE stable
+          partition pass into <= 1024 equally full depth buckets + every bucket sorted in LDS by one workgroup (about half the
+          time: a million keys in 50 instead of 100 us).  The bucket form is what GGR_DEPTH_SORT_GLOBAL (and AUTO, where it
+          resolves to global) runs when the call has a read-back (exact mode, capacity_is_hint) and a segment holds at most
+          2 M keys.  It can meet a bucket it cannot sort — more than 8192 DIFFERENT keys inside 1/4096 of the frame's depth
+          range (keys that are all equal, a plane of constant depth, are fine) — and the call then builds the lists again with
+          the three passes: same frame, about one binning (0.15 ms at 1 M Gaussians) later. */
+       GGR_DEPTH_SORT_NO_BUCKETS = 0x100,       /* IN flag, OR-ed into any of the three above: never the bucket form */
+       GGR_DEPTH_SORT_GLOBAL_3PASS = 0x101,     /* IN: GLOBAL | NO_BUCKETS.  OUT (depth_sort_used): three passes built the lists */
+       GGR_DEPTH_SORT_GLOBAL_FELL_BACK = 0x201  /* OUT only: the bucket form met such a bucket and the call sorted again in three
+                                                   passes (complete and correct); a host that sees this for a shape does better
+                                                   setting NO_BUCKETS for it for a while */ };
 
 /* Inputs of GaussianRasterizer.forward (cuda_splatting.py:118-125).
  * Exactly one of {shs, colors_precomp} and one of {cov3D_precomp, (scales, rotations)}. */
@@ -190,7 +202,8 @@ typedef struct GgrForwardOut {
                               1.25 x the previous frame's; 0 = no idea) — decides whether the launch for lists of 2049..8192
                               entries is enqueued up front.  A guess that was too small is repaired inside the call (those
                               lists are sorted and the frame blended once more). */
-    int32_t depth_sort_used; /* ABI 10.  OUT: GGR_DEPTH_SORT_GLOBAL or GGR_DEPTH_SORT_PER_TILE — what built this frame's lists */
+    int32_t depth_sort_used; /* ABI 10.  OUT: what built this frame's lists — GGR_DEPTH_SORT_PER_TILE, GGR_DEPTH_SORT_GLOBAL (ABI 11: its
+                              bucket form), GGR_DEPTH_SORT_GLOBAL_3PASS or GGR_DEPTH_SORT_GLOBAL_FELL_BACK (ABI 11, below the enum) */
 } GgrForwardOut;
 
 /* stage indices for GgrForwardOut.stage_ms / GgrBackwardOut.stage_ms */

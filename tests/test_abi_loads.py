@@ -19,7 +19,7 @@ def test_library_builds_and_loads():
     path = _build.build_library()
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.ggr_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.ggr_abi_version() == _lib.ABI_VERSION == 11
     assert lib.ggr_source_hash().decode() == _build.source_hash() == _build.embedded_hash()
 
 
