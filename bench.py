@@ -150,6 +150,9 @@ def algorithmic_bytes(P: int, N: int, W: int, H: int, K: int, M: int, N_built: i
         # depth sort = 3 passes × (key + id read and written) + one histogram read of the keys;
         # tile scatter = the ids written + each Gaussian's (id, rect) read once + the per-chunk start table read once
         "depth_sort_compulsory": P * (3 * 16 + 4),
+        # the global sort's bucket form (round 6, csrc/binning.hip): the keys read for the fine histogram (4), the partition pass
+        # (key read 4, (id, key) written 8), the bucket sort ((id, key) read 8, id written 4, the rect fetched 8 and written 8)
+        "depth_sort_buckets_compulsory": P * (4 + 12 + 28),
         "tile_scatter_compulsory": (N if N_built is None else N_built) * 4 + P * 12,   # (the ids this build writes)
         # the per-tile form of the binning (round 6, csrc/tile_sort.hip): the id-order scatter writes (id, key) — 8 B per entry —
         # and reads rect 8 + key 4 per Gaussian; the per-tile sort reads the 8-B entries and writes the 4-B ids
@@ -410,6 +413,18 @@ class Workload:
                                    ("tile_scatter", "fwd_tile_scatter_ms", "tile_scatter_compulsory")))
             if stages.get(key, 0.0) > 0}
         out["binning_form"] = "per_tile" if stages.get("fwd_tile_sort_ms", 0.0) > 0 else "global"
+        try:   # which form of the global sort built the lists (ABI 11: "buckets" | "3pass" | "fell_back")
+            from ggrt_official_amd.rasterizer import last_forward_sort_form
+            form = last_forward_sort_form()
+            if out["binning_form"] == "global" and form != "per_tile":
+                out["global_sort_form"] = form
+                if form == "buckets" and "depth_sort" in out["binning_kernels"]:
+                    d = out["binning_kernels"]["depth_sort"]
+                    d["compulsory_bytes"] = ab["depth_sort_buckets_compulsory"]
+                    d["achieved_GBps"] = round(d["compulsory_bytes"] / (d["ms"] * 1e-3) / 1e9, 1)
+                    d["hbm_frac"] = round(d["compulsory_bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        except Exception:
+            pass
         if not self.fwd_only:
             t_bwd = sum(v for k, v in stages.items() if k.startswith("bwd_"))
             b_bwd = ab["bwd_blend"] + ab["bwd_preprocess"]
