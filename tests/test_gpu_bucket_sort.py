@@ -126,6 +126,26 @@ def test_thin_slab_falls_back_to_three_passes_inside_the_call_and_the_host_remem
         set_list_hint(True)
 
 
+def test_fault_in_the_guessed_buffer_mode_is_repaired_at_the_end_of_the_call():
+    """The default mode enqueues scatter and blend behind a GUESSED list buffer and reads the counts at the end of the call: a
+    bucket fault shows up there, with the frame already blended from mis-ordered lists — the call builds the lists again in
+    three passes, scatters and blends once more.  (A shape's first frames establish the guess; the faulting frame has the same
+    shape.)"""
+    from ggrt_official_amd.rasterizer import list_hint_stats
+    P = 150000
+    spread = make_scene(P, 640, 480, sh_degree=0, profile="A", seed=21)
+    for _ in range(2):
+        _, how = _state(spread, "global")
+        assert how == "buckets"
+    slab = _thin_slab_scene(P=P, seed=22)
+    three, _ = _state(slab, "global_3pass")
+    list_hint_stats(reset=True)
+    out, how = _state(slab, "global")
+    assert how == "fell_back"
+    assert list_hint_stats()["exact"] == 0        # (it was a guessed-buffer forward)
+    _same_lists(out, three)
+
+
 def test_culled_gaussians_and_tiny_frames():
     sc = make_scene(50000, 200, 120, sh_degree=0, profile="A", seed=10)
     sc.means3D[::3, 2] = -1.0       # a third behind the camera: key 0, the bucket of its own
