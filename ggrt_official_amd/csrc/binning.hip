@@ -238,7 +238,8 @@ radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __re
     if (tid == 0) tile_sh = atomicAdd(&hist[GGR_HIST_TICKETS + pass * GGR_SORT_MAX_SEGMENTS + seg], 1u);
     {
         const size_t so = (size_t)seg * n;
-        keys_in += so; keys_out += so; vals_out += so;
+        keys_in += so; vals_out += so;
+        if (!MSD) keys_out += so;   // (MSD: no keys_out — the pairs leave as records)
         if (!vals_in_null) vals_in += so;
         if (GATHER || (MSD && gather_dst)) gather_dst += so;
         if (MSD) pair_out += so;
@@ -644,7 +645,7 @@ void radix_sort_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint
         TileSortExtras ex{gather_src, gather_dst, zero_area, zero_words, hist + GGR_HIST_FAULT};
         launch_tile_depth_sort((size_t)S * GGR_SORT_MAX_BINS, ranges, vals_b, pairs, 0u, cls1, s, 0, nullptr, &ex);
         ex.zero_words = 0u;
-        launch_tile_depth_sort((size_t)S * GGR_SORT_MAX_BINS, ranges, vals_b, pairs, cls1, GGR_TSORT_CAP_LARGE, s, 1, nullptr, &ex);
+        launch_bucket_sort_big(S, ranges, vals_b, pairs, cls1, s, ex);
         *keys_out = nullptr;
         *vals_out = vals_b;
         return;

@@ -444,6 +444,13 @@ struct TileSortExtras {
     uint32_t zero_words;
     uint32_t* fault_word;      // a list longer than the launch sorts whose keys are NOT all equal ORs GGR_FAULT_BUCKET in here
 };
+// tile_sort.hip, for the depth sort's bucket form: the buckets of more than `min_len` keys (what an overfull fine bin made longer
+// than the regular class sorts) of `segments` x GGR_SORT_MAX_BINS ranges — up to GGR_TSORT_CAP_LARGE sorted, beyond copied if all
+// keys are equal, else the fault bit.  A SMALL grid (64 workgroups per segment, each looking at 16 ranges): the class that sorts
+// 8192 keys takes a CU's registers, and one such workgroup per bucket — all but a few with nothing to do — cost 5 to 60 µs
+// depending on what else was resident.
+void launch_bucket_sort_big(uint32_t segments, const uint2* ranges, uint32_t* point_list, const uint2* pair_list, uint32_t min_len,
+                            hipStream_t s, TileSortExtras ex);
 // tile_sort.hip: stable sort of every tile's list by the Gaussians' depth keys — lists with min_len < length <= max_len
 // (others are left alone; max_len <= GGR_TSORT_CAP_LARGE)
 void launch_tile_depth_sort(size_t T, const uint2* ranges, uint32_t* point_list, const uint2* pair_list, uint32_t min_len,

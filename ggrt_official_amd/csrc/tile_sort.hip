@@ -64,18 +64,11 @@ tile_depth_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* _
 // The same for the depth sort's bucket form (binning.hip): a "tile" is a depth bucket of the P Gaussians — a thousand
 // workgroups, not eight thousand, so the small class need not be held to 64 registers (no spills; four workgroups per CU).
 template <int Q>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Q <= 8 ? 4 : Q <= 16 ? 2 : 1, 8)))
-bucket_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
-                   const uint2* __restrict__ pair_list, uint32_t min_len, uint32_t cap, int copy_longer, TileSortExtras ex) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t tile = blockIdx.x;
+__device__ __forceinline__ void bucket_sort_one(uint32_t* lds, uint2 range, uint32_t* __restrict__ point_list,
+                                                const uint2* __restrict__ pair_list, uint32_t cap, int copy_longer,
+                                                const TileSortExtras& ex) {
     const uint32_t tid = threadIdx.x;
-    if (ex.zero_words)   // (the words the three-pass form's last pass clears)
-        for (uint32_t wz = blockIdx.x * 256u + tid; wz < ex.zero_words; wz += gridDim.x * 256u) ex.zero_area[wz] = 0u;
-    if (tile >= T) return;
-    const uint2 range = ranges[tile];
     const uint32_t n = range.y - range.x;
-    if (n <= min_len) return;
     uint32_t* list = point_list + range.x;
     const uint2* pairs = pair_list + range.x;
     uint2* gdst = ex.gather_dst + range.x;
@@ -115,6 +108,43 @@ bucket_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __res
         return;
     }
     tile_sort_body<Q, true>(lds, cap, n, list, pairs, nullptr, ex.gather_src, gdst);
+}
+
+template <int Q>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Q <= 8 ? 4 : Q <= 16 ? 2 : 1, 8)))
+bucket_sort_kernel(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
+                   const uint2* __restrict__ pair_list, uint32_t min_len, uint32_t cap, int copy_longer, TileSortExtras ex) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t tile = blockIdx.x;
+    if (ex.zero_words)   // (the words the three-pass form's last pass clears)
+        for (uint32_t wz = blockIdx.x * 256u + threadIdx.x; wz < ex.zero_words; wz += gridDim.x * 256u) ex.zero_area[wz] = 0u;
+    if (tile >= T) return;
+    const uint2 range = ranges[tile];
+    if (range.y - range.x <= min_len) return;
+    bucket_sort_one<Q>(lds, range, point_list, pair_list, cap, copy_longer, ex);
+}
+
+// the buckets beyond the regular class: workgroup (x, segment) looks at ranges [16·x, 16·x + 16) of its segment
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 8)))
+bucket_sort_big_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list, const uint2* __restrict__ pair_list,
+                       uint32_t min_len, TileSortExtras ex) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t first = blockIdx.y * GGR_SORT_MAX_BINS + blockIdx.x * 16u;
+    const uint2 mine = ranges[first + (threadIdx.x & 15u)];   // (lanes 0-15 of every wave hold the sixteen ranges)
+    for (int j = 0; j < 16; j++) {
+        const uint2 range = make_uint2((uint32_t)__shfl((int)mine.x, j), (uint32_t)__shfl((int)mine.y, j));
+        if (range.y - range.x <= min_len) continue;   // (uniform)
+        __syncthreads();   // (the previous bucket's LDS)
+        bucket_sort_one<32>(lds, range, point_list, pair_list, GGR_TSORT_CAP_LARGE, 1, ex);
+    }
+}
+
+void launch_bucket_sort_big(uint32_t segments, const uint2* ranges, uint32_t* point_list, const uint2* pair_list, uint32_t min_len,
+                            hipStream_t s, TileSortExtras ex) {
+    const size_t lds = (size_t)tsort_lds_words(GGR_TSORT_CAP_LARGE) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bucket_sort_big_kernel, dim3(GGR_SORT_MAX_BINS / 16, segments ? segments : 1), dim3(256), lds, s, ranges, point_list,
+                       pair_list, min_len, ex);
 }
 
 template <int Q>
