@@ -74,6 +74,7 @@ FWD_STAGES = ["preprocess", "depth_sort", "tile_count", "tile_scatter", "blend",
 DEPTH_SORT = {"auto": 0, "global": 1, "per_tile": 2, "global_3pass": 0x101}
 DEPTH_SORT_NO_BUCKETS = 0x100      # IN flag: never the global sort's bucket form (include/ggr_raster.h)
 DEPTH_SORT_FELL_BACK = 0x201       # OUT: the bucket form gave a frame up; its lists were built again in three passes
+DEPTH_SORT_SLOW = 0x401            # OUT: the bucket form built the lists, the slow way (depths concentrated: include/ggr_raster.h)
 BWD_STAGES = ["clear", "blend", "preprocess"]
 
 

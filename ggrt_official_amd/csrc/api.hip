@@ -658,6 +658,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
     // what the host word(s) said: N, or a fault; the longest list
     uint32_t num_rendered = 0, longest = 0;
     bool bucket_fault = false;   // the depth sort's bucket form left a bucket unsorted: the lists must be built again
+    bool bucket_slow = false;    // … or sorted everything, much of it the slow way: advisory (GGR_DEPTH_SORT_GLOBAL_SLOW)
     auto read_counts = [&]() -> int {
         if (rb) {
             // the single host sync of forward.  N is written by the FIRST block of the last tile-list kernel: the host
@@ -667,7 +668,8 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
             if (rc != GGR_OK) return rc;
             longest = ((volatile uint32_t*)rb->host)[1];   // (stored before N's release store)
             bucket_fault = (longest >> 31) != 0u;
-            longest &= 0x7FFFFFFFu;
+            bucket_slow = ((longest >> 30) & 1u) != 0u;
+            longest &= 0x3FFFFFFFu;
         } else {   // no pinned slot (hipHostMalloc / hipEventCreate failed): copy + sync — a frame is never returned unchecked
             uint32_t w4[4] = {0u, 0u, 0u, 0u};
             HIP_TRY(hipMemcpyAsync(w4, g.counters, 16, hipMemcpyDeviceToHost, s));
@@ -675,6 +677,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
             num_rendered = (w4[1] & 2u) ? GGR_HOST_FAULT_SPIN : (w4[1] & 4u) ? GGR_HOST_FAULT_RANGE : w4[0];
             longest = w4[2];
             bucket_fault = (w4[1] & 16u) != 0u;
+            bucket_slow = (w4[1] & 32u) != 0u;
         }
         // raised by the tile-list kernel that writes N (bin_group_prefix_kernel)
         if (num_rendered == GGR_HOST_FAULT_SPIN) return fail(GGR_E_HIP, "%s", kSpinFault);
@@ -805,6 +808,7 @@ int forward_impl(const GgrSettings* st, const ViewSet& vs, const GgrForwardIn* i
         if (two[1] & 2u) return fail(GGR_E_HIP, "%s", kSpinFault);
         if (two[1] & 4u) return fail(GGR_E_LIMIT, "%s", kRangeFault);
     }
+    if (bucket_slow && out->depth_sort_used == GGR_DEPTH_SORT_GLOBAL) out->depth_sort_used = GGR_DEPTH_SORT_GLOBAL_SLOW;
     tm.finish();
     if (out->stage_ms && side) {   // the colour kernel's own duration (it ran BESIDE stages 1-3, not in addition to them)
         float ms = 0.f;

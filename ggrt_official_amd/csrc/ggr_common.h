@@ -161,6 +161,8 @@ __host__ __device__ static inline size_t ggr_sort_status_base(size_t S) { return
 #define GGR_MSD_MAX_POINTS (2u << 20)    // per segment: beyond, buckets would exceed what a workgroup sorts in LDS
 #define GGR_HIST_MSD_KMIN (GGR_HIST_PARAMS + 1)   // smallest visible key of the frame
 #define GGR_HIST_MSD_SHIFT (GGR_HIST_PARAMS + 2)  // fine bin of a visible key = (key - kmin) >> shift
+#define GGR_HIST_MSD_BIG (GGR_HIST_PARAMS + 3)    // buckets beyond the regular class that a workgroup of the small launch sorted BEHIND its first (zeroed)
+#define GGR_MSD_BIG_MANY 16u                      // from here on the frame's depths are too concentrated for the bucket form
 #define GGR_FAULT_SPIN 1u    // a look-back spin hit its bound
 #define GGR_FAULT_RANGE 2u   // a key needs more than 3 x 10 bits (depth >= 6.8e37)
 #define GGR_FAULT_BUCKET 4u  // bucket form: a bucket of more than GGR_TSORT_CAP_LARGE keys that are not all equal was left unsorted

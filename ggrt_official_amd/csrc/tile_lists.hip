@@ -251,15 +251,18 @@ bin_group_prefix_kernel(uint32_t* __restrict__ wsum, uint32_t T, uint32_t nw, ui
         // (the depth sort's bucket form left a bucket unsorted: the lists are complete but not in depth order everywhere — the
         //  host sorts again in three passes; status bit 4, and bit 31 of the host's second word)
         const uint32_t bucket = (fault_word & GGR_FAULT_BUCKET) ? 1u : 0u;
+        // … or sorted them all, but many of them the slow way (depths concentrated in a small part of the frame's range):
+        // advisory — status bit 5, bit 30 of the host's second word
+        const uint32_t slow = (sort_fault && sort_fault[GGR_HIST_MSD_BIG - GGR_HIST_FAULT] >= GGR_MSD_BIG_MANY) ? 1u : 0u;
         // the frame's longest tile list: what the per-tile depth sort must be able to hold (status bit 3: it cannot; the
         // host's second pinned word carries the length itself, written BEFORE the release store of N)
         const uint32_t n_longest = max(max(w_max[0], w_max[1]), max(w_max[2], w_max[3]));
         total_out[0] = n_all;
-        total_out[1] = (n_all > capacity ? 1u : 0u) | (fault << 1) | (n_longest > list_limit ? 8u : 0u) | (bucket << 4);
+        total_out[1] = (n_all > capacity ? 1u : 0u) | (fault << 1) | (n_longest > list_limit ? 8u : 0u) | (bucket << 4) | (slow << 5);
         total_out[2] = n_longest;
         total_out[3] = 0u;   // (the per-tile depth sort counts the entries of its slow route here: tile_sort.h)
         if (host_total) {
-            host_total[1] = n_longest | (bucket << 31);
+            host_total[1] = n_longest | (bucket << 31) | (slow << 30);
             __hip_atomic_store(host_total, (fault & 1u) ? GGR_HOST_FAULT_SPIN : fault ? GGR_HOST_FAULT_RANGE : n_all,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }

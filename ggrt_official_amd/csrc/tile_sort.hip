@@ -131,12 +131,19 @@ bucket_sort_big_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t first = blockIdx.y * GGR_SORT_MAX_BINS + blockIdx.x * 16u;
     const uint2 mine = ranges[first + (threadIdx.x & 15u)];   // (lanes 0-15 of every wave hold the sixteen ranges)
+    uint32_t nbig = 0u;
     for (int j = 0; j < 16; j++) {
         const uint2 range = make_uint2((uint32_t)__shfl((int)mine.x, j), (uint32_t)__shfl((int)mine.y, j));
         if (range.y - range.x <= min_len) continue;   // (uniform)
         __syncthreads();   // (the previous bucket's LDS)
         bucket_sort_one<32>(lds, range, point_list, pair_list, GGR_TSORT_CAP_LARGE, 1, ex);
+        nbig++;
     }
+    // how much of this was serial — buckets a workgroup sorted behind its first: much = depths concentrated in a small part of
+    // the frame's range (a few far outliers and the rest inside an octave: every bucket is a single overfull fine bin), and then
+    // this launch, 64 workgroups per view, is the slow way to sort them: the host is told (GGR_DEPTH_SORT_GLOBAL_SLOW) and keeps
+    // such a shape on the three passes
+    if (nbig > 1u && threadIdx.x == 0 && ex.fault_word) atomicAdd(ex.fault_word + (GGR_HIST_MSD_BIG - GGR_HIST_FAULT), nbig - 1u);
 }
 
 void launch_bucket_sort_big(uint32_t segments, const uint2* ranges, uint32_t* point_list, const uint2* pair_list, uint32_t min_len,

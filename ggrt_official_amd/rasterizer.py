@@ -312,7 +312,7 @@ def _sort_fell_back(key, fout) -> None:
     """Behind a forward: the global sort's bucket form gave this frame up (a bucket of > 8192 different keys inside 1/4096 of
     the frame's depth range) and the call built the lists again in three passes — about one binning more.  Frames of a shape
     tend to look alike: the shape keeps the three passes for a while.  A hint like the others: no result depends on it."""
-    if int(fout.depth_sort_used) != _lib.DEPTH_SORT_FELL_BACK or not _HINTS_ON:
+    if int(fout.depth_sort_used) not in (_lib.DEPTH_SORT_FELL_BACK, _lib.DEPTH_SORT_SLOW) or not _HINTS_ON:
         return
     with _hint_lock:
         w = _sort_watch.setdefault(key, {"calls": 0, "global_until": 0, "pending": None, "words": None, "slow_share": None})
@@ -816,12 +816,13 @@ def last_forward_status():
 
 
 def last_forward_sort_form() -> str:
-    """"per_tile" | "buckets" | "3pass" | "fell_back": GgrForwardOut.depth_sort_used of this thread's most recent forward in full
+    """"per_tile" | "buckets" | "3pass" | "fell_back" | "buckets_slow": GgrForwardOut.depth_sort_used of this thread's most recent forward in full
     (the global sort's bucket form, its three-pass form, or three passes after the bucket form gave the frame up)."""
     last = getattr(_tls, "last_binning", None)
     if last is None:
         raise RuntimeError("no forward has run on this thread")
-    return {2: "per_tile", 1: "buckets", 0x101: "3pass", _lib.DEPTH_SORT_FELL_BACK: "fell_back"}.get(last[0], str(last[0]))
+    return {2: "per_tile", 1: "buckets", 0x101: "3pass", _lib.DEPTH_SORT_FELL_BACK: "fell_back",
+            _lib.DEPTH_SORT_SLOW: "buckets_slow"}.get(last[0], str(last[0]))
 
 
 def last_forward_binning():

@@ -122,6 +122,10 @@ enum { GGR_DEPTH_SORT_AUTO = 0, GGR_DEPTH_SORT_GLOBAL = 1, GGR_DEPTH_SORT_PER_TI
           the three passes: same frame, about one binning (0.15 ms at 1 M Gaussians) later. */
        GGR_DEPTH_SORT_NO_BUCKETS = 0x100,       /* IN flag, OR-ed into any of the three above: never the bucket form */
        GGR_DEPTH_SORT_GLOBAL_3PASS = 0x101,     /* IN: GLOBAL | NO_BUCKETS.  OUT (depth_sort_used): three passes built the lists */
+       GGR_DEPTH_SORT_GLOBAL_SLOW = 0x401,      /* OUT only: the bucket form built the lists, but the frame's depths are so concentrated
+                                                   in a small part of its depth range (a few far outliers, the rest inside an octave)
+                                                   that most buckets were overfull fine bins, sorted by a launch of few workgroups:
+                                                   correct, and slower than the three passes — same advice as for _FELL_BACK */
        GGR_DEPTH_SORT_GLOBAL_FELL_BACK = 0x201  /* OUT only: the bucket form met such a bucket and the call sorted again in three
                                                    passes (complete and correct); a host that sees this for a shape does better
                                                    setting NO_BUCKETS for it for a while */ };

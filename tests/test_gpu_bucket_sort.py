@@ -146,6 +146,26 @@ def test_fault_in_the_guessed_buffer_mode_is_repaired_at_the_end_of_the_call():
     _same_lists(out, three)
 
 
+def test_concentrated_depths_are_sorted_the_slow_way_once_and_the_host_remembers():
+    """A few far outliers and everything else inside a seventh of an octave: 4096 fine bins over the frame's range leave the bulk
+    some forty of them, every bucket is one overfull fine bin and the small launch sorts them a few workgroups wide — correct,
+    slow, and said so (GGR_DEPTH_SORT_GLOBAL_SLOW): the shape then keeps the three passes."""
+    P = 200000
+    sc = make_scene(P, 640, 480, sh_degree=0, profile="A", seed=31)
+    g = torch.Generator().manual_seed(31)
+    z = 5.0 + 0.5 * torch.rand(P, generator=g)
+    z[:5] = 0.3
+    z[5:10] = 3000.0
+    sc = _at_depths(sc, z)
+    three, _ = _state(sc, "global_3pass")
+    forms = []
+    for _ in range(3):
+        out, how = _state(sc, "global")
+        forms.append(how)
+        _same_lists(out, three)
+    assert forms == ["buckets_slow", "3pass", "3pass"], forms
+
+
 def test_culled_gaussians_and_tiny_frames():
     sc = make_scene(50000, 200, 120, sh_degree=0, profile="A", seed=10)
     sc.means3D[::3, 2] = -1.0       # a third behind the camera: key 0, the bucket of its own
