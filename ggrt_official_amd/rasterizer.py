@@ -75,7 +75,9 @@ class GaussianRasterizationSettings(NamedTuple):
     #                         the tile-list build; "per_tile" = lists built in index order, then every tile's list sorted by
     #                         depth in LDS (no global dependency on the forward's critical path); "auto" = per tile for
     #                         frames with <= 256 Gaussians per tile on average and (once known) a longest list <= 4096,
-    #                         outside the sync-free mode; global otherwise (GGRt's 660-tile frames)
+    #                         outside the sync-free mode; global otherwise (GGRt's 660-tile frames).  The global sort runs in
+    #                         its BUCKET form where it can (ABI 11: one partition pass + every bucket sorted in LDS; falls
+    #                         back inside the call); "global_3pass" keeps the three radix passes
 
 
 class StageProfile:
