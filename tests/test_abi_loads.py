@@ -234,3 +234,19 @@ def test_sh_cap_is_an_explicit_choice(monkeypatch):
         assert rasterizer.GaussianRasterizer(rs)._settings_for_call().sh_max_degree == 0   # the raw rasterizer: not chosen
     finally:
         splatting.set_sh_max_degree(prev)
+
+
+def test_depth_sort_constants_match_the_header():
+    """ABI 11: the flag and the OUT-only values of GgrSettings.depth_sort / GgrForwardOut.depth_sort_used that the Python host
+    acts on (rasterizer._sort_no_buckets / _sort_fell_back) are the header's."""
+    import os
+    import re
+    from ggrt_official_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ggr_raster.h")).read()
+    vals = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"(GGR_DEPTH_SORT_[A-Z0-9_]+)\s*=\s*(0x[0-9a-fA-F]+|\d+)", text)}
+    assert vals["GGR_DEPTH_SORT_AUTO"] == _lib.DEPTH_SORT["auto"] and vals["GGR_DEPTH_SORT_GLOBAL"] == _lib.DEPTH_SORT["global"]
+    assert vals["GGR_DEPTH_SORT_PER_TILE"] == _lib.DEPTH_SORT["per_tile"]
+    assert vals["GGR_DEPTH_SORT_NO_BUCKETS"] == _lib.DEPTH_SORT_NO_BUCKETS
+    assert vals["GGR_DEPTH_SORT_GLOBAL_3PASS"] == _lib.DEPTH_SORT["global_3pass"] == (_lib.DEPTH_SORT["global"] | _lib.DEPTH_SORT_NO_BUCKETS)
+    assert vals["GGR_DEPTH_SORT_GLOBAL_FELL_BACK"] == _lib.DEPTH_SORT_FELL_BACK
+    assert vals["GGR_DEPTH_SORT_GLOBAL_SLOW"] == _lib.DEPTH_SORT_SLOW
